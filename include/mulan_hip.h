@@ -1,0 +1,147 @@
+/* libmulan_hip.so -- C ABI of the MI355X (gfx950) MuLAN training / eval-BPD hot path.
+ *
+ * The reference (s-sahoo/MuLAN) has no native layer: every device op is whatever XLA lowers from
+ * JAX/Flax.  This header is therefore the boundary a maintainer would bind (ctypes / XLA custom-call)
+ * to run the path on MI355X; each entry point names the reference code it replaces (file:line are
+ * relative to the reference checkout).  See INTEGRATION.md for the binding stubs.
+ *
+ * Conventions
+ *   - all tensors are contiguous fp32 device buffers unless stated; images are NHWC with W == 32 and
+ *     H*W == 1024 (the model never resamples: ldm/model_vdm.py:353-371), matrices are row-major;
+ *   - the caller owns every buffer including workspaces; the library never allocates, frees or
+ *     synchronises; every call is asynchronous on `stream` and re-entrant;
+ *   - the return value is a hipError_t as int (0 == hipSuccess); no exceptions cross the boundary;
+ *   - `hipStream_t` is passed as an opaque pointer so plain C callers need no HIP headers.
+ */
+#ifndef MULAN_HIP_H_
+#define MULAN_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __HIP_PLATFORM_AMD__
+#include <hip/hip_runtime_api.h>
+typedef hipStream_t mulan_stream_t;
+#else
+typedef void* mulan_stream_t;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* mulan_version(void);
+
+/* ---- 3x3 SAME convolution, NHWC, HWIO weights [3,3,C,N] --------------------------------------
+ * flax nn.Conv(kernel_size=(3,3)) in ResnetBlock conv1/conv2 (ldm/model_vdm.py:633-634,645-650;
+ * ldm/ldm_unet.py:33-34,49-54), conv_in / conv_out (model_vdm.py:348-349,378-383;
+ * ldm/model_mulan_epsilon.py:125-126,146-151).
+ * y = conv(x, w) + bias + cbias + res.  cbias_mode 1: cbias is [B,N] (per-sample FiLM bias,
+ * model_vdm.py:639-641); 2: cbias is [B,H,W,N] (per-pixel, ldm_unet.py:38-45); 0/NULL: none.
+ * res (nullable) is the residual/shortcut branch added in the epilogue (model_vdm.py:656, :386). */
+int mulan_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* cbias, int cbias_mode,
+                      const float* res, float* y, int B, int H, int W, int C, int N, mulan_stream_t stream);
+/* wT[t][n][c] = w[8-t][c][n]: input gradient = mulan_conv3x3_fwd(dy, wT) with C and N swapped
+ * (autodiff of the above under jax.value_and_grad, ldm/experiment.py:339). */
+int mulan_conv3x3_wflip(const float* w, float* wT, int C, int N, mulan_stream_t stream);
+/* dw[3,3,C,N] (+)= sum_{b,h,w} x (x) dy.  workspace: mulan_conv3x3_wgrad_workspace() bytes. */
+size_t mulan_conv3x3_wgrad_workspace(int B, int H, int W, int C, int N);
+int mulan_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int H, int W, int C,
+                        int N, int accumulate, mulan_stream_t stream);
+
+/* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
+ * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),
+ * q,k,v,proj_out and the attention products (model_vdm.py:676-685,775-796), dense0/dense1/cond_proj
+ * (model_vdm.py:337-338,639-641), gamma MLP (model_mulan_epsilon.py:531-538), encoder head
+ * (model_mulan_epsilon.py:153-154).  transA: A stored [K][lda]; transB: B stored [N][ldb]. */
+int mulan_gemm(const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N, int K,
+               int lda, int ldb, int ldc, int ldr, int transA, int transB, int batch, long long strideA,
+               long long strideB, long long strideC, long long strideR, float alpha, float beta,
+               mulan_stream_t stream);
+
+/* ---- GroupNorm (+SiLU) (+dropout), input = virtual channel concat [x1|x2] --------------------
+ * nn.GroupNorm() + nn.swish + nn.Dropout in ResnetBlock (model_vdm.py:622-623,632,643-644), final
+ * norm (model_vdm.py:376-377), AttnBlock norm (model_vdm.py:672-674).  hw must be 1024.
+ * act: 0 none, 1 SiLU.  keep < 1 enables dropout with Philox4x32-10(seed, offset + element/4). */
+int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                        float* y, float* mean, float* rstd, int B, int hw, int G, float eps, int act, float keep,
+                        unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
+/* dgamma_part / dbeta_part are [B, C1+C2] per-sample partials (reduce with mulan_colsum). */
+int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
+                        float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
+                        unsigned long long seed, unsigned long long offset, int accumulate, mulan_stream_t stream);
+
+/* ---- small fused elementwise / reduction kernels ---------------------------------------------- */
+/* kind 1: SiLU (nn.swish); kind 2: shift + softplus (model_mulan_epsilon.py:537). */
+int mulan_act_fwd(const float* x, float* y, size_t n, int kind, float shift, mulan_stream_t stream);
+int mulan_act_bwd(const float* x, const float* dy, float* dx, size_t n, int kind, mulan_stream_t stream);
+/* out[s][c] (+)= sum_{r<seg} x[s*seg + r][c]  (bias and per-sample cond-bias gradients) */
+int mulan_colsum(const float* x, float* out, int nseg, int seg, int C, int ld, int accumulate,
+                 mulan_stream_t stream);
+/* row softmax of the attention weights (model_vdm.py:786) and its backward */
+int mulan_softmax_fwd(const float* x, float* y, size_t rows, int cols, mulan_stream_t stream);
+int mulan_softmax_bwd(const float* p, const float* dp, float* ds, size_t rows, int cols, mulan_stream_t stream);
+/* Base2FourierFeatures(start=6, stop=8) + concat, padded to 16 channels (model_vdm.py:341-343,812-829) */
+int mulan_fourier_fwd(const float* z, float* out, size_t npix, mulan_stream_t stream);
+int mulan_fourier_bwd(const float* z, const float* dout, float* dz, size_t npix, int accumulate,
+                      mulan_stream_t stream);
+/* get_timestep_embedding (model_vdm.py:391-413): out[r][col0 .. col0+E) = [sin, cos](1000 t_r w_k) */
+int mulan_temb_fwd(const float* t, float* out, int n, int E, int ld, int col0, mulan_stream_t stream);
+int mulan_temb_bwd(const float* t, const float* dout, float* dt, int n, int E, int ld, int col0,
+                   mulan_stream_t stream);
+/* y[r][col0 + c] = x[r / rep][c]  (conditioning broadcast of ldm_unet.py:85-87 / concat of model_vdm.py:336) */
+int mulan_rowbcast(const float* x, float* y, size_t rows, int cols, int rep, int ld, int col0,
+                   mulan_stream_t stream);
+/* EncDec.encode (model_vdm.py:274-280): f = 2 ((x + .5) / 256) - 1 */
+int mulan_encode_u8(const unsigned char* x, float* f, size_t n, mulan_stream_t stream);
+int mulan_axpby(const float* x, float* y, size_t n, float a, float b, mulan_stream_t stream);
+
+/* ---- MuLAN closed-form terms; d must be 3072 ------------------------------------------------- */
+/* NoiseSchedule_polynomial_fixedend._eval_polynomial / _grad_t (model_mulan_epsilon.py:514-555).
+ * g0, g1, gprime may be NULL. */
+int mulan_poly_gamma_fwd(const float* a, const float* b, const float* c, const float* t, float* g0, float* g1,
+                         float* gt, float* gprime, int B, int d, float gamma_min, float gamma_max,
+                         mulan_stream_t stream);
+int mulan_poly_gamma_bwd(const float* a, const float* b, const float* c, const float* t, const float* dgt,
+                         const float* dgprime, float* da, float* db, float* dc, int B, int d, float gamma_min,
+                         float gamma_max, mulan_stream_t stream);
+/* VDM.__call__ up to the score-model call (model_mulan_velocity.py:208-236, model_mulan_epsilon.py:300-328,
+ * model_vdm.py:119-151) with EncDec.encode/decode/logprob (model_vdm.py:274-303) fused in.
+ * per_element_gamma: g* are [B,d] (MuLAN) or [B] (scalar schedule of model_vdm.VDM). */
+int mulan_qsample_fwd(const unsigned char* x, const float* g0, const float* g1, const float* gt,
+                      int per_element_gamma, const float* eps0, const float* eps, float* zt, float* gbar,
+                      float* loss_recon, float* loss_klz, float* var0, float* var1, int B, int d,
+                      mulan_stream_t stream);
+int mulan_qsample_bwd(const unsigned char* x, const float* g0, const float* g1, const float* gt,
+                      int per_element_gamma, const float* eps0, const float* eps, const float* dzt,
+                      const float* dgbar, const float* drecon, const float* dklz, float* dgt, float* dg0,
+                      float* dg1, int B, int d, mulan_stream_t stream);
+/* mode 0: velocity (model_mulan_velocity.py:250-260); 1: velocity_from_epsilon (:246-249);
+ * 2: epsilon with weight gprime (model_mulan_epsilon.py:338-355, model_vdm.py:156-170). */
+int mulan_diffloss_fwd(int mode, const unsigned char* x, const float* gt, const float* gprime,
+                       int per_element_gamma, const float* eps, const float* zt, const float* net,
+                       float* loss_diff, int B, int d, mulan_stream_t stream);
+int mulan_diffloss_bwd(int mode, const unsigned char* x, const float* gt, const float* gprime,
+                       int per_element_gamma, const float* eps, const float* zt, const float* net,
+                       const float* dloss, float* dnet, float* dgt, float* dgprime, float* dzt, int B, int d,
+                       mulan_stream_t stream);
+/* _topk_embedding_and_loss + _gamma_noise + _gumbel_kl_loss (model_mulan_velocity.py:78-120).
+ * gnoise: [10,B,L] raw Gamma(1/k,1) draws. */
+int mulan_topk_fwd(const float* logits, const float* gnoise, float* emb, float* kl, float* soft, float* nrm,
+                   int B, int L, int k, float tau, mulan_stream_t stream);
+int mulan_topk_bwd(const float* logits, const float* soft, const float* nrm, const float* demb, const float* dkl,
+                   float* dlogits, int B, int L, mulan_stream_t stream);
+
+/* ---- optimiser + RNG ------------------------------------------------------------------------- */
+/* TrainState.apply_gradients (ldm/train_state.py:70-102) with optax.adamw of ldm/experiment.py:132-182
+ * on one flat buffer; elements [0, n_decay) are weight-decayed.  step >= 1 is the Adam count. */
+int mulan_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay,
+                         float lr, float b1, float b2, float eps, float weight_decay, int step, float ema_rate,
+                         float grad_scale, mulan_stream_t stream);
+/* N(0,1) draws: Philox4x32-10 + Box-Muller (stands in for jax.random.normal, model_mulan_velocity.py:223,235) */
+int mulan_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULAN_HIP_H_ */

@@ -1,0 +1,388 @@
+// 3x3 / stride 1 / SAME convolution on NHWC fp32 images with W == 32, as an implicit GEMM on the
+// exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).  Replaces the XLA-lowered flax nn.Conv calls
+// of the reference ResnetBlock (ldm/model_vdm.py:633-634,645-650; ldm/ldm_unet.py:33-34,49-54),
+// conv_in/conv_out (model_vdm.py:348-349,378-383) and their autodiff (experiment.py:339).
+//
+//   forward   y[b,h,w,n]  = sum_{kh,kw,c} x[b,h+kh-1,w+kw-1,c] * wgt[kh,kw,c,n]  (+bias +cond bias +res)
+//   dgrad     = the same kernel on dy with wflip(wgt)[t][n][c] = wgt[8-t][c][n]
+//   wgrad     dW[t,c,n]   = sum_{b,h,w} x[b,h+kh-1,w+kw-1,c] * dy[b,h,w,n]        (split over images)
+//
+// One MFMA M-tile (32 rows) is one image row, so the im2col gather is just an LDS address shift
+// into a halo patch [rows+2][34][channel chunk]; nothing is materialised in HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int kW = 32;          // image width the tiling is built around
+constexpr int kPW = 34;         // patch width with the zero halo
+constexpr int CK = 16;          // input-channel chunk per pipeline stage
+constexpr int PS = CK + 4;      // patch pixel stride in floats: (PS/4) odd => ds_read_b128 conflict free
+constexpr int TROWS = 4;        // image rows per block tile (BM = 128 pixels)
+constexpr int PATCH_F = (TROWS + 2) * kPW * PS;   // floats per patch buffer (4080)
+
+struct ConvArgs {
+  const float* x;      // [B,H,32,C]
+  const float* w;      // [9,C,N]   (HWIO)
+  const float* bias;   // [N] or null
+  const float* cbias;  // cond bias: mode 1 [B,N], mode 2 [B,H,32,N]
+  const float* res;    // [B,H,32,N] or null
+  float* y;            // [B,H,32,N]
+  int B, H, C, N, cbias_mode;
+};
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
+  constexpr int MT = TROWS / WM;        // image rows per wave
+  constexpr int NT = BN / 32 / WN;      // 32-wide cout tiles per wave
+  constexpr int WT_F = CK * BN;         // floats per weight buffer
+  constexpr int WV = (WT_F / 4 + 255) / 256;  // float4 weight slots per thread
+  constexpr int PV = (PATCH_F / PS * (CK / 4) + 255) / 256;  // float4 patch slots per thread (4)
+  __shared__ __attribute__((aligned(16))) float smem[2 * PATCH_F + 2 * WT_F];
+  float* pbuf0 = smem;
+  float* wbuf0 = smem + 2 * PATCH_F;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_per_img = p.H / TROWS;
+  const int b = blockIdx.x / tiles_per_img;
+  const int h0 = (blockIdx.x % tiles_per_img) * TROWS;
+  const int n0 = blockIdx.y * BN;
+  const int C = p.C, N = p.N;
+  const bool vec_in = (C & 3) == 0;
+  const bool vec_w = (N & 3) == 0;
+  const int nchunks = (C + CK - 1) / CK;
+  const float* xb = p.x + (size_t)b * p.H * kW * C;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 preg[PV];
+  f32x4 wreg[WV];
+
+  auto gload_patch = [&](int cc) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) {
+      const int slot = tid + s * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (slot < (TROWS + 2) * kPW * (CK / 4)) {
+        const int q = slot & 3, pix = slot >> 2;
+        const int prow = pix / kPW, pcol = pix - prow * kPW;
+        const int hh = h0 + prow - 1, ww = pcol - 1;
+        const int c = cc * CK + q * 4;
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C) {
+          const float* src = xb + ((size_t)hh * kW + ww) * C + c;
+          if (vec_in) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+            v[0] = src[0];
+            if (c + 1 < C) v[1] = src[1];
+            if (c + 2 < C) v[2] = src[2];
+            if (c + 3 < C) v[3] = src[3];
+          }
+        }
+      }
+      preg[s] = v;
+    }
+  };
+  auto store_patch = [&](float* pb) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) {
+      const int slot = tid + s * 256;
+      if (slot < (TROWS + 2) * kPW * (CK / 4)) {
+        const int q = slot & 3, pix = slot >> 2;
+        *reinterpret_cast<f32x4*>(pb + pix * PS + q * 4) = preg[s];
+      }
+    }
+  };
+  auto gload_w = [&](int cc, int tap) {
+#pragma unroll
+    for (int s = 0; s < WV; ++s) {
+      const int slot = tid + s * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (slot < WT_F / 4) {
+        const int k = slot / (BN / 4), nq = slot - k * (BN / 4);
+        const int c = cc * CK + k, n = n0 + nq * 4;
+        if (c < C && n < N) {
+          const float* src = p.w + ((size_t)tap * C + c) * N + n;
+          if (vec_w) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+            v[0] = src[0];
+            if (n + 1 < N) v[1] = src[1];
+            if (n + 2 < N) v[2] = src[2];
+            if (n + 3 < N) v[3] = src[3];
+          }
+        }
+      }
+      wreg[s] = v;
+    }
+  };
+  auto store_w = [&](float* wb) {
+#pragma unroll
+    for (int s = 0; s < WV; ++s) {
+      const int slot = tid + s * 256;
+      if (slot < WT_F / 4) *reinterpret_cast<f32x4*>(wb + slot * 4) = wreg[s];
+    }
+  };
+
+  // prologue: stage chunk 0 / tap 0
+  gload_patch(0);
+  gload_w(0, 0);
+  store_patch(pbuf0);
+  store_w(wbuf0);
+  __syncthreads();
+
+  int step = 0;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    const float* pb = pbuf0 + (cc & 1) * PATCH_F;
+    const bool more_chunks = cc + 1 < nchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const float* wb = wbuf0 + (step & 1) * WT_F;
+      float* wb_next = wbuf0 + ((step + 1) & 1) * WT_F;
+      const bool has_next = (tap < 8) || more_chunks;
+      if (has_next) {
+        if (tap < 8) gload_w(cc, tap + 1); else gload_w(cc + 1, 0);
+      }
+      if (tap == 7 && more_chunks) gload_patch(cc + 1);
+
+#pragma unroll
+      for (int k8 = 0; k8 < CK / 8; ++k8) {
+        f32x4 a4[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int prow = wm * MT + mt + kh, pcol = li + kw;
+          a4[mt] = *reinterpret_cast<const f32x4*>(pb + (prow * kPW + pcol) * PS + k8 * 8 + 4 * lh);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = k8 * 8 + 4 * lh + j;   // k permutation shared by A and B
+          float bf[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[nt] = wb[kk * BN + (wn * NT + nt) * 32 + li];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(a4[mt][j], bf[nt], acc[mt][nt]);
+        }
+      }
+
+      if (has_next) store_w(wb_next);
+      if (tap == 8 && more_chunks) store_patch(pbuf0 + ((cc + 1) & 1) * PATCH_F);
+      __syncthreads();
+    }
+  }
+
+  // epilogue
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + (wn * NT + nt) * 32 + li;
+    if (n >= N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+    const float cb1 = (p.cbias_mode == 1) ? p.cbias[(size_t)b * N + n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int hh = h0 + wm * MT + mt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ww = mfma32_row(r, lane);
+        const size_t o = (((size_t)b * p.H + hh) * kW + ww) * N + n;
+        float v = acc[mt][nt][r] + bv + cb1;
+        if (p.cbias_mode == 2) v += p.cbias[o];
+        if (p.res) v += p.res[o];
+        p.y[o] = v;
+      }
+    }
+  }
+}
+
+// wT[t][n][c] = w[8-t][c][n]  (tap flip + channel transpose) so dgrad reuses the forward kernel.
+__global__ void conv3x3_wflip_kernel(const float* __restrict__ w, float* __restrict__ wT, int C, int N) {
+  const int total = 9 * C * N;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int t = i / (C * N), rem = i - t * C * N;
+    const int n = rem / C, c = rem - n * C;           // i indexes wT[t][n][c]
+    wT[i] = w[((size_t)(8 - t) * C + c) * N + n];
+  }
+}
+
+// ---------------------------------------------------------------------------------- wgrad
+constexpr int WG_T = 64;       // ci tile == co tile
+constexpr int WG_ROWS = 2;     // image rows per K chunk (64 pixels)
+constexpr int WG_XP = (WG_ROWS + 2) * kPW * WG_T;   // 8704 floats
+constexpr int WG_DY = WG_ROWS * kW * WG_T;          // 4096 floats
+
+struct WgradArgs {
+  const float* x;    // [B,H,32,C]
+  const float* dy;   // [B,H,32,N]
+  float* slab;       // [S,9,C,N]
+  int B, H, C, N, S;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[WG_XP + WG_DY];
+  float* xp = smem;
+  float* dyt = smem + WG_XP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wci = wave >> 1, wco = wave & 1;
+  const int C = p.C, N = p.N;
+  const int c0 = blockIdx.y * WG_T, n0 = blockIdx.z * WG_T;
+  const bool vec_x = (C & 3) == 0, vec_dy = (N & 3) == 0;
+  const int pairs_per_img = p.H / WG_ROWS;
+  const int total_pairs = p.B * pairs_per_img;
+  const int per_split = (total_pairs + p.S - 1) / p.S;
+  const int pair_begin = blockIdx.x * per_split;
+  const int pair_end = min(total_pairs, pair_begin + per_split);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
+    const float* xb = p.x + (size_t)b * p.H * kW * C;
+    const float* dyb = p.dy + ((size_t)b * p.H + h0) * kW * N;
+    __syncthreads();   // previous chunk fully consumed
+    // x halo patch: [4][34][64]
+    for (int slot = tid; slot < (WG_ROWS + 2) * kPW * (WG_T / 4); slot += 256) {
+      const int q = slot & 15, pix = slot >> 4;
+      const int prow = pix / kPW, pcol = pix - prow * kPW;
+      const int hh = h0 + prow - 1, ww = pcol - 1;
+      const int c = c0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C) {
+        const float* src = xb + ((size_t)hh * kW + ww) * C + c;
+        if (vec_x) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          v[0] = src[0];
+          if (c + 1 < C) v[1] = src[1];
+          if (c + 2 < C) v[2] = src[2];
+          if (c + 3 < C) v[3] = src[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(xp + pix * WG_T + q * 4) = v;
+    }
+    // dy tile: [64 px][64]
+    for (int slot = tid; slot < WG_ROWS * kW * (WG_T / 4); slot += 256) {
+      const int q = slot & 15, pix = slot >> 4;
+      const int n = n0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < N) {
+        const float* src = dyb + (size_t)pix * N + n;
+        if (vec_dy) {
+          v = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          v[0] = src[0];
+          if (n + 1 < N) v[1] = src[1];
+          if (n + 2 < N) v[2] = src[2];
+          if (n + 3 < N) v[3] = src[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(dyt + pix * WG_T + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < WG_ROWS * kW / 2; ++s) {
+      const int pix = 2 * s + lh;            // K index = pixel inside the 2-row chunk
+      const int r = pix >> 5, ww = pix & 31;
+      const float bf = dyt[pix * WG_T + wco * 32 + li];
+      const float* xa = xp + (r * kPW + ww) * WG_T + wci * 32 + li;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t - kh * 3;
+        acc[t] = mfma32(xa[(kh * kPW + kw) * WG_T], bf, acc[t]);
+      }
+    }
+  }
+
+  float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
+  const int n = n0 + wco * 32 + li;
+  if (n < N) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wci * 32 + mfma32_row(r, lane);
+        if (c < C) slab[((size_t)t * C + c) * N + n] = acc[t][r];
+      }
+  }
+}
+
+// dw[e] (+)= sum_s slab[s][e]   -- fixed summation order => bitwise reproducible
+__global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int S, int E,
+                                   int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float s = 0.f;
+  for (int i = 0; i < S; ++i) s += slab[(size_t)i * E + e];
+  out[e] = accumulate ? out[e] + s : s;
+}
+
+int wgrad_splits(int B, int H, int C, int N) {
+  const int tiles = ((C + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
+  const int pairs = B * (H / WG_ROWS);
+  int S = 1024 / tiles;             // aim at ~4 resident blocks per CU worth of work
+  if (S < 1) S = 1;
+  if (S > pairs) S = pairs;
+  // keep at least 4 row pairs per split so the slab traffic stays small next to the MFMA work
+  while (S > 1 && pairs / S < 4) --S;
+  return S;
+}
+
+}  // namespace
+
+MULAN_API int mulan_conv3x3_fwd(const float* x, const float* w, const float* bias, const float* cbias,
+                                int cbias_mode, const float* res, float* y, int B, int H, int W, int C, int N,
+                                hipStream_t stream) {
+  if (W != kW || H % TROWS != 0 || B <= 0 || C <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+  ConvArgs a{x, w, bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0};
+  const int mtiles = B * (H / TROWS);
+  if (N > 64) {
+    dim3 grid(mtiles, (N + 127) / 128);
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<128, 2, 2>), grid, dim3(256), 0, stream, a);
+  } else if (N > 32) {
+    dim3 grid(mtiles, 1);
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<64, 2, 2>), grid, dim3(256), 0, stream, a);
+  } else {
+    dim3 grid(mtiles, 1);
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<32, 4, 1>), grid, dim3(256), 0, stream, a);
+  }
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_conv3x3_wflip(const float* w, float* wT, int C, int N, hipStream_t stream) {
+  const int total = 9 * C * N;
+  const int blocks = min(2048, (total + 255) / 256);
+  hipLaunchKernelGGL(conv3x3_wflip_kernel, dim3(blocks), dim3(256), 0, stream, w, wT, C, N);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API size_t mulan_conv3x3_wgrad_workspace(int B, int H, int W, int C, int N) {
+  if (W != kW || H % WG_ROWS != 0) return 0;
+  return (size_t)wgrad_splits(B, H, C, N) * 9 * C * N * sizeof(float);
+}
+
+MULAN_API int mulan_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int H, int W,
+                                  int C, int N, int accumulate, hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0) return (int)hipErrorInvalidValue;
+  const int S = wgrad_splits(B, H, C, N);
+  WgradArgs a{x, dy, workspace, B, H, C, N, S};
+  dim3 grid(S, (C + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T);
+  hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), 0, stream, a);
+  const int E = 9 * C * N;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E,
+                     accumulate);
+  MULAN_CHECK_LAUNCH();
+}

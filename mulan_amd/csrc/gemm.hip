@@ -1,0 +1,218 @@
+// Batched fp32 GEMM on v_mfma_f32_32x32x2_f32 for every Dense / 1x1 / attention contraction of the
+// path: nin_shortcut (ldm/model_vdm.py:652-653), attention q,k,v,proj_out and QK^T / PV
+// (model_vdm.py:676-685,775-796), cond MLP dense0/dense1 + cond_proj (model_vdm.py:337-338,639-641;
+// ldm/ldm_unet.py:38-45,89-90), the gamma MLP (ldm/model_mulan_epsilon.py:531-538) and the
+// encoder head (model_mulan_epsilon.py:153-154), plus their autodiff transposes.
+//
+//   C[b] = alpha * op(A[b]) @ op(B[b]) + bias[n] + beta * R[b]
+//
+// op(A) is [M,K]: TA=0 -> A stored [M][lda] (k contiguous), TA=1 -> stored [K][lda] (m contiguous).
+// op(B) is [K,N]: TB=0 -> B stored [K][ldb] (n contiguous), TB=1 -> stored [N][ldb] (k contiguous).
+// k-contiguous operands are staged [row][k] (stride KC+4) and read with ds_read_b128 under the
+// k permutation k = 8c + 4*(lane>>5) + j; k-major operands are staged [k][row] and read with
+// ds_read_b32 under the same permutation, so any TA/TB combination shares one MFMA loop.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 16;
+constexpr int KS = KC + 4;   // row stride for k-contiguous staging ((KS/4) odd)
+
+struct GemmArgs {
+  const float* A; const float* B; float* C; const float* bias; const float* R;
+  int M, N, K, lda, ldb, ldc, ldr;
+  long long sA, sB, sC, sR;   // batch strides (elements)
+  float alpha, beta;
+};
+
+template <int BM, int BN, int WM, int WN, int TA, int TB, int VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  constexpr int MT = BM / 32 / WM, NT = BN / 32 / WN;
+  constexpr int A_F = TA ? KC * BM : BM * KS;
+  constexpr int B_F = TB ? BN * KS : KC * BN;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_F + B_F)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, bz = blockIdx.z;
+  const float* A = p.A + (size_t)bz * p.sA;
+  const float* B = p.B + (size_t)bz * p.sB;
+  const int M = p.M, N = p.N, K = p.K;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  constexpr int AV = (BM * KC / 4 + 255) / 256;
+  constexpr int BV = (BN * KC / 4 + 255) / 256;
+  f32x4 areg[AV], breg[BV];
+
+  // Generic tile loader: `rows` x KC tile of a matrix stored either [row][k] (kcontig) or [k][row].
+  auto gload = [&](f32x4* reg, const float* base, int ld, int row0, int rows_total, int k0, bool kcontig,
+                   int TILE, int nslots) {
+#pragma unroll
+    for (int s = 0; s < nslots; ++s) {
+      const int slot = tid + s * 256;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (slot < TILE * KC / 4) {
+        if (kcontig) {
+          const int r = slot / (KC / 4), kq = slot - r * (KC / 4);
+          const int row = row0 + r, k = k0 + kq * 4;
+          if (row < rows_total && k < K) {
+            const float* src = base + (size_t)row * ld + k;
+            if (VEC) {
+              v = *reinterpret_cast<const f32x4*>(src);
+            } else {
+              v[0] = src[0];
+              if (k + 1 < K) v[1] = src[1];
+              if (k + 2 < K) v[2] = src[2];
+              if (k + 3 < K) v[3] = src[3];
+            }
+          }
+        } else {
+          const int k = slot / (TILE / 4), rq = slot - k * (TILE / 4);
+          const int row = row0 + rq * 4, kk = k0 + k;
+          if (kk < K && row < rows_total) {
+            const float* src = base + (size_t)kk * ld + row;
+            if (VEC) {
+              v = *reinterpret_cast<const f32x4*>(src);
+            } else {
+              v[0] = src[0];
+              if (row + 1 < rows_total) v[1] = src[1];
+              if (row + 2 < rows_total) v[2] = src[2];
+              if (row + 3 < rows_total) v[3] = src[3];
+            }
+          }
+        }
+      }
+      reg[s] = v;
+    }
+  };
+  auto lstore = [&](const f32x4* reg, float* dst, bool kcontig, int TILE, int nslots) {
+#pragma unroll
+    for (int s = 0; s < nslots; ++s) {
+      const int slot = tid + s * 256;
+      if (slot < TILE * KC / 4) {
+        if (kcontig) {
+          const int r = slot / (KC / 4), kq = slot - r * (KC / 4);
+          *reinterpret_cast<f32x4*>(dst + r * KS + kq * 4) = reg[s];
+        } else {
+          *reinterpret_cast<f32x4*>(dst + slot * 4) = reg[s];   // [k][TILE]
+        }
+      }
+    }
+  };
+
+  const int nk = (K + KC - 1) / KC;
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * A_F;
+  gload(areg, A, p.lda, m0, M, 0, !TA, BM, AV);
+  gload(breg, B, p.ldb, n0, N, 0, TB, BN, BV);
+  lstore(areg, As0, !TA, BM, AV);
+  lstore(breg, Bs0, TB, BN, BV);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* As = As0 + (kt & 1) * A_F;
+    const float* Bs = Bs0 + (kt & 1) * B_F;
+    const bool has_next = kt + 1 < nk;
+    if (has_next) {
+      gload(areg, A, p.lda, m0, M, (kt + 1) * KC, !TA, BM, AV);
+      gload(breg, B, p.ldb, n0, N, (kt + 1) * KC, TB, BN, BV);
+    }
+#pragma unroll
+    for (int k8 = 0; k8 < KC / 8; ++k8) {
+      f32x4 a4[MT], b4[NT];
+      if (!TA) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          a4[mt] = *reinterpret_cast<const f32x4*>(As + ((wm * MT + mt) * 32 + li) * KS + k8 * 8 + 4 * lh);
+      }
+      if (TB) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          b4[nt] = *reinterpret_cast<const f32x4*>(Bs + ((wn * NT + nt) * 32 + li) * KS + k8 * 8 + 4 * lh);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k8 * 8 + 4 * lh + j;
+        float af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          af[mt] = TA ? As[kk * BM + (wm * MT + mt) * 32 + li] : a4[mt][j];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          bf[nt] = TB ? b4[nt][j] : Bs[kk * BN + (wn * NT + nt) * 32 + li];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(af[mt], bf[nt], acc[mt][nt]);
+      }
+    }
+    if (has_next) {
+      lstore(areg, As0 + ((kt + 1) & 1) * A_F, !TA, BM, AV);
+      lstore(breg, Bs0 + ((kt + 1) & 1) * B_F, TB, BN, BV);
+    }
+    __syncthreads();
+  }
+
+  float* Cb = p.C + (size_t)bz * p.sC;
+  const float* Rb = p.R ? p.R + (size_t)bz * p.sR : nullptr;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + (wn * NT + nt) * 32 + li;
+    if (n >= N) continue;
+    const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * MT + mt) * 32 + mfma32_row(r, lane);
+        if (m < M) {
+          float v = p.alpha * acc[mt][nt][r] + bv;
+          if (Rb) v += p.beta * Rb[(size_t)m * p.ldr + n];
+          Cb[(size_t)m * p.ldc + n] = v;
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch(const GemmArgs& a, int ta, int tb, int vec, int batch, hipStream_t st) {
+  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), blk(256);
+#define L(TA, TB, V) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, TA, TB, V>), grid, blk, 0, st, a)
+  if (vec) {
+    if (!ta && !tb) L(0, 0, 1); else if (!ta && tb) L(0, 1, 1); else if (ta && !tb) L(1, 0, 1); else L(1, 1, 1);
+  } else {
+    if (!ta && !tb) L(0, 0, 0); else if (!ta && tb) L(0, 1, 0); else if (ta && !tb) L(1, 0, 0); else L(1, 1, 0);
+  }
+#undef L
+}
+
+}  // namespace
+
+MULAN_API int mulan_gemm(const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N,
+                         int K, int lda, int ldb, int ldc, int ldr, int transA, int transB, int batch,
+                         long long strideA, long long strideB, long long strideC, long long strideR, float alpha,
+                         float beta, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return (int)hipErrorInvalidValue;
+  GemmArgs a{A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, strideA, strideB, strideC, strideR, alpha, beta};
+  // float4 global loads need 16-byte aligned rows along the contiguous dimension of both operands.
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int contigA = transA ? M : K, contigB = transB ? K : N;
+  const int vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (contigA % 4 == 0) && (contigB % 4 == 0) &&
+                  (strideA % 4 == 0) && (strideB % 4 == 0);
+  const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+  if (M >= 128 && N >= 128 && tiles128 >= 256) {
+    launch<128, 128, 2, 2>(a, transA, transB, vec, batch, stream);
+  } else if (N <= 32) {
+    launch<128, 32, 4, 1>(a, transA, transB, vec, batch, stream);
+  } else {
+    launch<64, 64, 2, 2>(a, transA, transB, vec, batch, stream);
+  }
+  MULAN_CHECK_LAUNCH();
+}

@@ -1,0 +1,232 @@
+// Fused GroupNorm (+ SiLU) (+ dropout) forward / backward on NHWC fp32, HW = 1024.
+// Replaces flax nn.GroupNorm() [32 groups, eps 1e-6, E[x^2]-E[x]^2 variance] followed by nn.swish and
+// nn.Dropout in the reference ResnetBlock (ldm/model_vdm.py:622-623,632,643-644), the final
+// normalisation (model_vdm.py:376-377) and the activation-free one of AttnBlock (model_vdm.py:672-674).
+//
+// The input may be a virtual channel concat [x1 | x2] (up blocks: model_vdm.py:369); the output is
+// written as one tensor with C1+C2 channels, so the concat is never materialised on its own.
+// One 256-thread block owns (sample, 32-channel slab): 1024 px x 128 B, kept in registers.
+#include "common.h"
+
+namespace {
+
+constexpr int HW = 1024;
+constexpr int NP = HW / 32;   // pixels per thread
+
+struct GnArgs {
+  const float* x1; const float* x2; int C1, C2;
+  const float* gamma; const float* beta;     // [C1+C2]
+  float* y;                                   // [B,HW,C1+C2]
+  float* mean; float* rstd;                   // [B,G]
+  int B, G; float eps; int act;               // act: 0 none, 1 silu
+  float keep; unsigned long long seed, offset;  // dropout: keep == 1 -> off
+};
+
+__device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
+  // keep-mask = (u32 < floor(keep * 2^32)); jax.random.bernoulli(keep) semantics, scaled by 1/keep
+  // (flax nn.Dropout).  Integer compare so the numpy oracle reproduces the mask bit for bit.
+  const Philox4 r = philox4x32_10(seed, ctr, 0ull);
+  const uint32_t thr = (uint32_t)((double)keep * 4294967296.0);
+  const float inv = 1.f / keep;
+  v[0] = (r.x < thr) ? v[0] * inv : 0.f;
+  v[1] = (r.y < thr) ? v[1] * inv : 0.f;
+  v[2] = (r.z < thr) ? v[2] * inv : 0.f;
+  v[3] = (r.w < thr) ? v[3] * inv : 0.f;
+}
+
+// Sums `a`,`b` over all threads of the block that share quad-group id gq = quad / qpg.
+// red: 2 * 4 * 8 floats.  Returns the group totals for this thread's group.
+__device__ __forceinline__ void group_reduce2(float& a, float& b, int quad, int qpg, float* red) {
+  // lanes: tid = prow*8 + quad; reduce over prow bits inside the wave (lane bits 3..5)
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane < 8) { red[wave * 8 + lane] = a; red[32 + wave * 8 + lane] = b; }
+  __syncthreads();
+  const int g0 = (quad / qpg) * qpg;
+  float sa = 0.f, sb = 0.f;
+  for (int q = g0; q < g0 + qpg; ++q)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sa += red[w * 8 + q]; sb += red[32 + w * 8 + q]; }
+  a = sa; b = sb;
+}
+
+__global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
+  __shared__ float red[64];
+  const int tid = threadIdx.x, quad = tid & 7, prow = tid >> 3;
+  const int b = blockIdx.x, Ct = p.C1 + p.C2;
+  const int c0 = blockIdx.y * 32;
+  const int cpg = Ct / p.G, qpg = cpg >> 2;       // channels / float4-quads per group
+  const float* src; int ld, cs;
+  if (c0 < p.C1) { src = p.x1; ld = p.C1; cs = c0; } else { src = p.x2; ld = p.C2; cs = c0 - p.C1; }
+  src += (size_t)b * HW * ld + cs + quad * 4;
+
+  f32x4 v[NP];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(prow + 32 * i) * ld);
+    s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    s2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+  }
+  group_reduce2(s1, s2, quad, qpg, red);
+  const float inv_n = 1.f / (float)(HW * cpg);
+  const float mean = s1 * inv_n;
+  const float var = fmaxf(0.f, s2 * inv_n - mean * mean);
+  const float rstd = rsqrtf(var + p.eps);
+  const int c = c0 + quad * 4;
+  const int g = c / cpg;
+  if (prow == 0 && (quad % qpg) == 0) { p.mean[b * p.G + g] = mean; p.rstd[b * p.G + g] = rstd; }
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  float* dst = p.y + (size_t)b * HW * Ct + c;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int px = prow + 32 * i;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = (v[i][e] - mean) * (rstd * ga[e]) + be[e];
+      o[e] = p.act ? silu_f(u) : u;
+    }
+    if (p.keep < 1.f) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + px) * Ct + c) >> 2;
+      drop4(o, p.keep, p.seed, p.offset + idx4);
+    }
+    *reinterpret_cast<f32x4*>(dst + (size_t)px * Ct) = o;
+  }
+}
+
+struct GnBwdArgs {
+  const float* dy;                             // [B,HW,C1+C2]
+  const float* x1; const float* x2; int C1, C2;
+  const float* gamma; const float* beta; const float* mean; const float* rstd;
+  float* dx1; float* dx2;                      // [B,HW,C1], [B,HW,C2]
+  float* dgamma_part; float* dbeta_part;       // [B,C1+C2] per-sample partials
+  int B, G; int act; float keep; unsigned long long seed, offset;
+  int accumulate;                              // dx += instead of dx =
+};
+
+__global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
+  __shared__ float red[64];
+  __shared__ float cred[2 * 4 * 32];
+  const int tid = threadIdx.x, quad = tid & 7, prow = tid >> 3;
+  const int b = blockIdx.x, Ct = p.C1 + p.C2;
+  const int c0 = blockIdx.y * 32;
+  const int cpg = Ct / p.G, qpg = cpg >> 2;
+  const float* src; float* dxp; int ld, cs;
+  if (c0 < p.C1) { src = p.x1; dxp = p.dx1; ld = p.C1; cs = c0; }
+  else { src = p.x2; dxp = p.dx2; ld = p.C2; cs = c0 - p.C1; }
+  src += (size_t)b * HW * ld + cs + quad * 4;
+  dxp += (size_t)b * HW * ld + cs + quad * 4;
+  const int c = c0 + quad * 4, g = c / cpg;
+  const float mean = p.mean[b * p.G + g], rstd = p.rstd[b * p.G + g];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  const float* dyp = p.dy + (size_t)b * HW * Ct + c;
+
+  // pass 1: accumulate group sums and per-channel partials (x, dy are re-read in pass 2: L2/MALL)
+  float s1 = 0.f, s2 = 0.f;
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int px = prow + 32 * i;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(src + (size_t)px * ld);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct);
+    if (p.keep < 1.f) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + px) * Ct + c) >> 2;
+      drop4(d, p.keep, p.seed, p.offset + idx4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xhat = (xv[e] - mean) * rstd;
+      const float u = xhat * ga[e] + be[e];
+      const float gu = p.act ? d[e] * silu_grad_f(u) : d[e];
+      dg[e] += gu * xhat;
+      db[e] += gu;
+      const float dxh = gu * ga[e];
+      s1 += dxh;
+      s2 += dxh * xhat;
+    }
+  }
+  group_reduce2(s1, s2, quad, qpg, red);
+  // per-channel partial sums over the 32 prow lanes
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cred[wave * 32 + lane * 4 + e] = dg[e]; cred[128 + wave * 32 + lane * 4 + e] = db[e]; }
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const float a = cred[tid] + cred[32 + tid] + cred[64 + tid] + cred[96 + tid];
+    const float bb = cred[128 + tid] + cred[160 + tid] + cred[192 + tid] + cred[224 + tid];
+    p.dgamma_part[(size_t)b * Ct + c0 + tid] = a;
+    p.dbeta_part[(size_t)b * Ct + c0 + tid] = bb;
+  }
+  const float inv_n = 1.f / (float)(HW * cpg);
+  const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+  // pass 2: dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat))
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int px = prow + 32 * i;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(src + (size_t)px * ld);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct);
+    if (p.keep < 1.f) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + px) * Ct + c) >> 2;
+      drop4(d, p.keep, p.seed, p.offset + idx4);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xhat = (xv[e] - mean) * rstd;
+      const float u = xhat * ga[e] + be[e];
+      const float gu = p.act ? d[e] * silu_grad_f(u) : d[e];
+      o[e] = rstd * (gu * ga[e] - m1 - xhat * m2);
+    }
+    float* dp = dxp + (size_t)px * ld;
+    if (p.accumulate) {
+      const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
+      o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3];
+    }
+    *reinterpret_cast<f32x4*>(dp) = o;
+  }
+}
+
+}  // namespace
+
+MULAN_API int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                  const float* beta, float* y, float* mean, float* rstd, int B, int hw, int G,
+                                  float eps, int act, float keep, unsigned long long seed,
+                                  unsigned long long offset, hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
+  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset};
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C1, int C2,
+                                  const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                  float* dx1, float* dx2, float* dgamma_part, float* dbeta_part, int B, int hw,
+                                  int G, int act, float keep, unsigned long long seed, unsigned long long offset,
+                                  int accumulate, hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
+  GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
+              B, G, act, keep, seed, offset, accumulate};
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}

@@ -1,0 +1,385 @@
+// MuLAN-specific closed-form math as fused per-sample kernels (D = 32*32*3 = 3072 per sample):
+//   poly_gamma : per-pixel polynomial noise schedule gamma(t), gamma'(t) with fixed end points
+//                (ldm/model_mulan_epsilon.py:514-529 _eval_polynomial, :540-555 _grad_t)
+//   qsample    : encode, z_0 reconstruction log-prob over the 256 bins, KL(z_1 || N(0,1)), q(z_t|x) sample,
+//                mean gamma_t  (ldm/model_mulan_velocity.py:208-236; ldm/model_vdm.py:274-303)
+//   diffloss   : velocity / velocity-from-epsilon / epsilon diffusion loss
+//                (model_mulan_velocity.py:246-260; model_mulan_epsilon.py:338-355; model_vdm.py:156-170)
+//   topk       : relaxed top-k straight-through latent + KL to uniform (model_mulan_velocity.py:78-120)
+// Every backward is analytic; noise is an explicit input so the CPU oracle sees identical draws.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 3072;
+constexpr int EPT = D / 256;   // elements per thread
+
+// ------------------------------------------------------------------ polynomial schedule
+struct Poly {
+  float S, P, Q;   // scale, polynomial(t), (a t^2 + b t + c)
+};
+__device__ __forceinline__ float poly_scale(float a, float b, float c) {
+  return a * a / 5.f + (b * b + 2.f * a * c) / 3.f + a * b / 2.f + b * c + c * c;
+}
+__device__ __forceinline__ float poly_eval(float a, float b, float c, float t) {
+  const float t2 = t * t, t3 = t2 * t, t4 = t3 * t, t5 = t4 * t;
+  return a * a * t5 / 5.f + (b * b + 2.f * a * c) * t3 / 3.f + a * b * t4 / 2.f + b * c * t2 + c * c * t;
+}
+
+__global__ void poly_gamma_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                      const float* __restrict__ c, const float* __restrict__ t, float* g0, float* g1,
+                                      float* gt, float* gp, int B, float gmin, float R) {
+  const size_t n = (size_t)B * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float av = a[i], bv = b[i], cv = c[i], tv = t[i / D];
+    const float S = poly_scale(av, bv, cv);
+    if (g0) g0[i] = gmin + R * poly_eval(av, bv, cv, 0.f) / S;
+    if (g1) g1[i] = gmin + R * poly_eval(av, bv, cv, 1.f) / S;
+    gt[i] = gmin + R * poly_eval(av, bv, cv, tv) / S;
+    if (gp) {
+      const float t2 = tv * tv;
+      const float q = av * av * t2 * t2 + (bv * bv + 2.f * av * cv) * t2 + av * bv * (t2 * tv) * 2.f + bv * cv * tv * 2.f +
+                      cv * cv;
+      gp[i] = R * q / S;
+    }
+  }
+}
+// (da, db, dc) from upstream d gamma_t and d gamma'_t.  gamma_0 / gamma_1 are constants of (a,b,c).
+__global__ void poly_gamma_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                      const float* __restrict__ c, const float* __restrict__ t,
+                                      const float* __restrict__ dgt, const float* __restrict__ dgp, float* da,
+                                      float* db, float* dc, int B, float R) {
+  const size_t n = (size_t)B * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float av = a[i], bv = b[i], cv = c[i], tv = t[i / D];
+    const float t2 = tv * tv, t3 = t2 * tv, t4 = t3 * tv, t5 = t4 * tv;
+    const float S = poly_scale(av, bv, cv), P = poly_eval(av, bv, cv, tv);
+    const float Q = av * t2 + bv * tv + cv;
+    const float Pa = 2.f * av * t5 / 5.f + 2.f * cv * t3 / 3.f + bv * t4 / 2.f;
+    const float Pb = 2.f * bv * t3 / 3.f + av * t4 / 2.f + cv * t2;
+    const float Pc = 2.f * av * t3 / 3.f + bv * t2 + 2.f * cv * tv;
+    const float Sa = 2.f * av / 5.f + 2.f * cv / 3.f + bv / 2.f;
+    const float Sb = 2.f * bv / 3.f + av / 2.f + cv;
+    const float Sc = 2.f * av / 3.f + bv + 2.f * cv;
+    const float inv = 1.f / S, inv2 = inv * inv;
+    const float u = dgt ? dgt[i] * R : 0.f;   // d/d(P/S)
+    const float w = dgp ? dgp[i] * R : 0.f;   // d/d(Q^2/S)
+    const float Q2 = Q * Q;
+    da[i] = u * (Pa * S - P * Sa) * inv2 + w * (2.f * Q * t2 * S - Q2 * Sa) * inv2;
+    db[i] = u * (Pb * S - P * Sb) * inv2 + w * (2.f * Q * tv * S - Q2 * Sb) * inv2;
+    dc[i] = u * (Pc * S - P * Sc) * inv2 + w * (2.f * Q * S - Q2 * Sc) * inv2;
+  }
+}
+
+// ------------------------------------------------------------------ q-sample + ELBO "pre" terms
+__device__ __forceinline__ float encode_u8(unsigned char x) { return 2.f * (((float)x + 0.5f) / 256.f) - 1.f; }
+__device__ __forceinline__ float bin_val(int j) { return 2.f * (((float)j + 0.5f) / 256.f) - 1.f; }
+
+struct QsArgs {
+  const unsigned char* x;                       // [B,D]
+  const float* g0; const float* g1; const float* gt; int gstride;  // gstride D (per element) or 0 (per sample)
+  const float* eps0; const float* eps;
+  float* zt; float* gbar; float* recon; float* klz; float* var0; float* var1;   // [B,D], [B] x5
+};
+
+__global__ __launch_bounds__(256) void qsample_fwd_kernel(QsArgs p) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s_rec = 0.f, s_kl = 0.f, s_g = 0.f, s_v0 = 0.f, s_v1 = 0.f;
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + e * 256;
+    const size_t o = (size_t)b * D + i;
+    const size_t og = p.gstride ? o : (size_t)b;
+    const unsigned char xv = p.x[o];
+    const float f = encode_u8(xv);
+    const float g0 = p.g0[og], g1 = p.g1[og], gt = p.gt[og];
+    // reconstruction: -log softmax_j(-0.5 ((z - v_j) e^{-g0/2})^2)[x]
+    const float z0 = f + expf(0.5f * g0) * p.eps0[o];
+    const float istd = expf(-0.5f * g0);
+    float mx = -INFINITY;
+    for (int j = 0; j < 256; ++j) {
+      const float u = (z0 - bin_val(j)) * istd;
+      mx = fmaxf(mx, -0.5f * u * u);
+    }
+    float se = 0.f;
+    for (int j = 0; j < 256; ++j) {
+      const float u = (z0 - bin_val(j)) * istd;
+      se += expf(-0.5f * u * u - mx);
+    }
+    const float ux = (z0 - bin_val((int)xv)) * istd;
+    s_rec -= (-0.5f * ux * ux - mx) - logf(se);
+    // latent KL
+    const float v1 = sigmoid_f(g1);
+    s_kl += 0.5f * ((1.f - v1) * f * f + v1 - logf(v1) - 1.f);
+    // z_t
+    const float vt = sigmoid_f(gt);
+    p.zt[o] = sqrtf(1.f - vt) * f + sqrtf(vt) * p.eps[o];
+    s_g += gt;
+    s_v0 += sigmoid_f(g0);
+    s_v1 += v1;
+  }
+  s_rec = block_sum_256(s_rec, red);
+  s_kl = block_sum_256(s_kl, red);
+  s_g = block_sum_256(s_g, red);
+  s_v0 = block_sum_256(s_v0, red);
+  s_v1 = block_sum_256(s_v1, red);
+  if (threadIdx.x == 0) {
+    p.recon[b] = s_rec; p.klz[b] = s_kl; p.gbar[b] = s_g / (float)D;
+    p.var0[b] = s_v0 / (float)D; p.var1[b] = s_v1 / (float)D;
+  }
+}
+
+struct QsBwdArgs {
+  const unsigned char* x;
+  const float* g0; const float* g1; const float* gt; int gstride;
+  const float* eps0; const float* eps;
+  const float* dzt;     // [B,D]
+  const float* dgbar;   // [B] or null
+  const float* drecon;  // [B] or null (with dg0)
+  const float* dklz;    // [B] or null (with dg1)
+  float* dgt; float* dg0; float* dg1;   // [B,D] per-element grads (dg0/dg1 optional)
+};
+
+__global__ __launch_bounds__(256) void qsample_bwd_kernel(QsBwdArgs p) {
+  const int b = blockIdx.x;
+  const float dgb = p.dgbar ? p.dgbar[b] / (float)D : 0.f;
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + e * 256;
+    const size_t o = (size_t)b * D + i;
+    const size_t og = p.gstride ? o : (size_t)b;
+    const unsigned char xv = p.x[o];
+    const float f = encode_u8(xv);
+    const float gt = p.gt[og];
+    const float s = sigmoid_f(gt);
+    const float al = sqrtf(1.f - s), sg = sqrtf(s);
+    // d alpha/dg = -0.5 s alpha ; d sigma/dg = 0.5 (1-s) sigma
+    p.dgt[o] = p.dzt[o] * (f * (-0.5f * s * al) + p.eps[o] * (0.5f * (1.f - s) * sg)) + dgb;
+    if (p.dg1) {
+      const float g1 = p.g1[og], v1 = sigmoid_f(g1);
+      p.dg1[o] = p.dklz[b] * (0.5f * v1 * (1.f - v1) * (1.f - f * f) - 0.5f * (1.f - v1));
+    }
+    if (p.dg0) {
+      const float g0 = p.g0[og], e0 = p.eps0[o];
+      const float z0 = f + expf(0.5f * g0) * e0, istd = expf(-0.5f * g0);
+      float mx = -INFINITY;
+      for (int j = 0; j < 256; ++j) { const float u = (z0 - bin_val(j)) * istd; mx = fmaxf(mx, -0.5f * u * u); }
+      float se = 0.f, sd = 0.f;
+      for (int j = 0; j < 256; ++j) {
+        const float u = (z0 - bin_val(j)) * istd;
+        const float w = expf(-0.5f * u * u - mx);
+        se += w;
+        sd += w * (0.5f * u * (u - e0));     // d logit_j / d g0
+      }
+      const float ux = (z0 - bin_val((int)xv)) * istd;
+      const float dl = 0.5f * ux * (ux - e0) - sd / se;   // d log p(x) / d g0
+      p.dg0[o] = -p.drecon[b] * dl;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ diffusion loss
+struct DlArgs {
+  int mode;                                   // 0 velocity, 1 velocity-from-epsilon, 2 epsilon
+  const unsigned char* x;
+  const float* gt; const float* gp; int gstride;
+  const float* eps; const float* zt; const float* net;
+  float* loss;                                // [B]
+  // backward only
+  const float* dloss;                         // [B]
+  float* dnet; float* dgt; float* dgp; float* dzt;   // [B,D]; dzt only written in mode 1
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void diffloss_kernel(DlArgs p) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  const float dL = BWD ? p.dloss[b] : 0.f;
+  for (int e = 0; e < EPT; ++e) {
+    const int i = threadIdx.x + e * 256;
+    const size_t o = (size_t)b * D + i;
+    const size_t og = p.gstride ? o : (size_t)b;
+    const float gt = p.gt[og], gp = p.gp[og], eps = p.eps[o], net = p.net[o];
+    if (p.mode == 2) {
+      const float r = eps - net;
+      if (!BWD) { acc += 0.5f * gp * r * r; }
+      else { p.dnet[o] = -dL * gp * r; p.dgp[o] = 0.5f * dL * r * r; p.dgt[o] = 0.f; }
+    } else {
+      const float f = encode_u8(p.x[o]);
+      const float s = sigmoid_f(gt), al = sqrtf(1.f - s), sg = sqrtf(s);
+      const float vstar = al * eps - sg * f;
+      float vhat = net, eg2 = 0.f, sq = 1.f, zt = 0.f;
+      if (p.mode == 1) {
+        zt = p.zt[o];
+        eg2 = expf(0.5f * gt);
+        sq = sqrtf(1.f + expf(gt));
+        vhat = -eg2 * zt + sq * net;
+      }
+      const float r = vstar - vhat;
+      if (!BWD) { acc += 0.5f * (1.f - s) * gp * r * r; }
+      else {
+        const float wr = dL * (1.f - s) * gp * r;     // d/d vstar ; -d/d vhat
+        float dg = -s * (1.f - s) * (0.5f * dL * gp * r * r);
+        dg += wr * (eps * (-0.5f * s * al) - f * (0.5f * (1.f - s) * sg));
+        p.dgp[o] = 0.5f * dL * (1.f - s) * r * r;
+        if (p.mode == 1) {
+          p.dnet[o] = -wr * sq;
+          p.dzt[o] = wr * eg2;
+          dg += -wr * (-0.5f * eg2 * zt + 0.5f * expf(gt) / sq * net);
+        } else {
+          p.dnet[o] = -wr;
+        }
+        p.dgt[o] = dg;
+      }
+    }
+  }
+  if (!BWD) {
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) p.loss[b] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ relaxed top-k latent
+// One 64-lane block per row; L <= 64 logits.  gnoise: [10][B][L] raw Gamma(1/k) draws.
+struct TkArgs {
+  const float* logits; const float* gnoise; int B, L, k; float tau;
+  float* emb; float* kl; float* soft; float* nrm;   // [B,L],[B],[B,L],[B]
+  // bwd
+  const float* demb; const float* dkl; float* dlogits;
+};
+
+__global__ __launch_bounds__(64) void topk_fwd_kernel(TkArgs p) {
+  __shared__ float sh[64];
+  const int b = blockIdx.x, j = threadIdx.x, L = p.L;
+  const bool on = j < L;
+  const float lg = on ? p.logits[(size_t)b * L + j] : 0.f;
+  // KL(softmax(logits) || uniform)
+  const float mx = wave_max(on ? lg : -INFINITY);
+  const float ex = on ? expf(lg - mx) : 0.f;
+  const float se = wave_sum(ex);
+  const float logq = (lg - mx) - logf(se);
+  const float q = ex / se;
+  const float klv = wave_sum(on ? q * (logq - logf(1.0f / (float)L)) : 0.f);
+  // sum-of-gammas noise (model_mulan_velocity.py:94-104)
+  float s = 0.f;
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const float beta = (float)p.k / (float)(i + 1);
+      s += p.gnoise[((size_t)i * p.B + b) * L + j] / beta;
+    }
+    s = s - logf(10.0f);
+    s = p.tau * (s / (float)p.k);
+  }
+  float l = lg + s;
+  const float mean = wave_sum(on ? l : 0.f) / (float)L;
+  l -= mean;
+  const float nrm = sqrtf(wave_sum(on ? l * l : 0.f));
+  const float soft = l / nrm;
+  sh[j] = on ? l : -INFINITY;
+  __syncthreads();
+  int gt = 0, ge = 0;
+  for (int m = 0; m < L; ++m) { gt += sh[m] > l; ge += sh[m] >= l; }
+  const bool is_kth = on && gt < p.k && p.k <= ge;
+  const float thr = wave_max(is_kth ? l : -INFINITY);
+  if (on) {
+    const float hard = (l >= thr) ? 1.f : 0.f;
+    p.emb[(size_t)b * L + j] = (hard - soft) + soft;
+    p.soft[(size_t)b * L + j] = soft;
+  }
+  if (j == 0) { p.kl[b] = klv; p.nrm[b] = nrm; }
+}
+
+__global__ __launch_bounds__(64) void topk_bwd_kernel(TkArgs p) {
+  const int b = blockIdx.x, j = threadIdx.x, L = p.L;
+  const bool on = j < L;
+  const float lg = on ? p.logits[(size_t)b * L + j] : 0.f;
+  const float soft = on ? p.soft[(size_t)b * L + j] : 0.f;
+  const float ds = on ? p.demb[(size_t)b * L + j] : 0.f;   // straight-through: d emb / d soft = 1
+  const float dot = wave_sum(soft * ds);
+  float dl = (ds - soft * dot) / p.nrm[b];
+  if (!on) dl = 0.f;
+  dl -= wave_sum(dl) / (float)L;
+  // KL term
+  const float mx = wave_max(on ? lg : -INFINITY);
+  const float ex = on ? expf(lg - mx) : 0.f;
+  const float se = wave_sum(ex);
+  const float logq = (lg - mx) - logf(se);
+  const float q = ex / se;
+  const float term = logq - logf(1.0f / (float)L);
+  const float klv = wave_sum(on ? q * term : 0.f);
+  if (on) p.dlogits[(size_t)b * L + j] = dl + p.dkl[b] * q * (term - klv);
+}
+
+inline int nblocks(size_t n) { size_t b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b ? b : 1)); }
+
+}  // namespace
+
+MULAN_API int mulan_poly_gamma_fwd(const float* a, const float* b, const float* c, const float* t, float* g0,
+                                   float* g1, float* gt, float* gprime, int B, int d, float gamma_min,
+                                   float gamma_max, hipStream_t stream) {
+  if (d != D || B <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(poly_gamma_fwd_kernel, dim3(nblocks((size_t)B * D)), dim3(256), 0, stream, a, b, c, t, g0, g1, gt,
+                     gprime, B, gamma_min, gamma_max - gamma_min);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_poly_gamma_bwd(const float* a, const float* b, const float* c, const float* t, const float* dgt,
+                                   const float* dgprime, float* da, float* db, float* dc, int B, int d,
+                                   float gamma_min, float gamma_max, hipStream_t stream) {
+  if (d != D || B <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(poly_gamma_bwd_kernel, dim3(nblocks((size_t)B * D)), dim3(256), 0, stream, a, b, c, t, dgt,
+                     dgprime, da, db, dc, B, gamma_max - gamma_min);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_qsample_fwd(const unsigned char* x, const float* g0, const float* g1, const float* gt,
+                                int per_element_gamma, const float* eps0, const float* eps, float* zt, float* gbar,
+                                float* loss_recon, float* loss_klz, float* var0, float* var1, int B, int d,
+                                hipStream_t stream) {
+  if (d != D || B <= 0) return (int)hipErrorInvalidValue;
+  QsArgs a{x, g0, g1, gt, per_element_gamma ? D : 0, eps0, eps, zt, gbar, loss_recon, loss_klz, var0, var1};
+  hipLaunchKernelGGL(qsample_fwd_kernel, dim3(B), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_qsample_bwd(const unsigned char* x, const float* g0, const float* g1, const float* gt,
+                                int per_element_gamma, const float* eps0, const float* eps, const float* dzt,
+                                const float* dgbar, const float* drecon, const float* dklz, float* dgt, float* dg0,
+                                float* dg1, int B, int d, hipStream_t stream) {
+  if (d != D || B <= 0) return (int)hipErrorInvalidValue;
+  if ((dg0 && !drecon) || (dg1 && !dklz)) return (int)hipErrorInvalidValue;
+  QsBwdArgs a{x, g0, g1, gt, per_element_gamma ? D : 0, eps0, eps, dzt, dgbar, drecon, dklz, dgt, dg0, dg1};
+  hipLaunchKernelGGL(qsample_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_diffloss_fwd(int mode, const unsigned char* x, const float* gt, const float* gprime,
+                                 int per_element_gamma, const float* eps, const float* zt, const float* net,
+                                 float* loss_diff, int B, int d, hipStream_t stream) {
+  if (d != D || B <= 0 || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  DlArgs a{mode, x, gt, gprime, per_element_gamma ? D : 0, eps, zt, net, loss_diff, nullptr, nullptr, nullptr, nullptr,
+           nullptr};
+  hipLaunchKernelGGL(diffloss_kernel<false>, dim3(B), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_diffloss_bwd(int mode, const unsigned char* x, const float* gt, const float* gprime,
+                                 int per_element_gamma, const float* eps, const float* zt, const float* net,
+                                 const float* dloss, float* dnet, float* dgt, float* dgprime, float* dzt, int B,
+                                 int d, hipStream_t stream) {
+  if (d != D || B <= 0 || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  DlArgs a{mode, x, gt, gprime, per_element_gamma ? D : 0, eps, zt, net, nullptr, dloss, dnet, dgt, dgprime, dzt};
+  hipLaunchKernelGGL(diffloss_kernel<true>, dim3(B), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_topk_fwd(const float* logits, const float* gnoise, float* emb, float* kl, float* soft,
+                             float* nrm, int B, int L, int k, float tau, hipStream_t stream) {
+  if (L > 64 || L <= 0 || k <= 0 || k > L || B <= 0) return (int)hipErrorInvalidValue;
+  TkArgs a{logits, gnoise, B, L, k, tau, emb, kl, soft, nrm, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(topk_fwd_kernel, dim3(B), dim3(64), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_topk_bwd(const float* logits, const float* soft, const float* nrm, const float* demb,
+                             const float* dkl, float* dlogits, int B, int L, hipStream_t stream) {
+  if (L > 64 || L <= 0 || B <= 0) return (int)hipErrorInvalidValue;
+  TkArgs a{logits, nullptr, B, L, 0, 0.f, nullptr, nullptr, const_cast<float*>(soft), const_cast<float*>(nrm), demb, dkl,
+           dlogits};
+  hipLaunchKernelGGL(topk_bwd_kernel, dim3(B), dim3(64), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}

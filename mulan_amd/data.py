@@ -1,0 +1,126 @@
+"""Input batches for the hot path (host side; counterpart of ldm/dataset.py:248-322,379-410).
+
+The reference streams TFDS -> tf.data; neither is installed on the target image and the metric is
+quoted on synthetic batches, so this module provides
+  * 'synthetic'  : uniform random uint8 images, seeded per rank (bench / smoke / plumbing);
+  * 'cifar10'    : the python-pickle CIFAR-10 archive (cifar-10-batches-py) read from
+                   $MULAN_DATA_DIR, test split unshuffled for create_one_time_eval_dataset;
+  * 'npz:<path>' : any .npz with uint8 `images` [N,32,32,3] (e.g. a downsampled-ImageNet-32 dump).
+Batch dict keys follow _preprocess_cifar10 (ldm/dataset.py:310-322): images u8, labels, conditioning.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+
+def _cifar_split(root, train):
+    d = os.path.join(root, "cifar-10-batches-py")
+    names = [f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]
+    xs, ys = [], []
+    for n in names:
+        with open(os.path.join(d, n), "rb") as f:
+            e = pickle.load(f, encoding="bytes")
+        xs.append(np.asarray(e[b"data"], dtype=np.uint8).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+        ys.append(np.asarray(e[b"labels"], dtype=np.int32))
+    return np.concatenate(xs), np.concatenate(ys)
+
+
+def load_arrays(name, train):
+    if name == "synthetic":
+        return None, None
+    if name.startswith("npz:"):
+        z = np.load(name[4:])
+        key = "images" if train or "test_images" not in z else "test_images"
+        x = np.asarray(z[key], dtype=np.uint8)
+        return x, np.zeros(len(x), dtype=np.int32)
+    root = os.environ.get("MULAN_DATA_DIR", "")
+    if name in ("cifar10", "cifar10_aug"):
+        if not os.path.isdir(os.path.join(root, "cifar-10-batches-py")):
+            raise FileNotFoundError(
+                "CIFAR-10 not found: set MULAN_DATA_DIR to the directory holding cifar-10-batches-py/ "
+                "(or use --config.data.dataset=synthetic)")
+        return _cifar_split(root, train)
+    raise NotImplementedError(f"dataset {name!r}: supported are synthetic, cifar10, npz:<file>")
+
+
+class BatchStream:
+    """Infinite (train/eval) or one-pass iterator of per-rank batches on `device`."""
+
+    def __init__(self, name, batch_size, *, train, device, seed=0, rank=0, world=1, substeps=None, one_pass=False):
+        if batch_size % world != 0:
+            raise ValueError("Batch size must be divisible by the number of devices")   # ldm/dataset.py:256-259
+        self.local = batch_size // world
+        self.device = device
+        self.substeps = substeps
+        self.one_pass = one_pass
+        self.rank, self.world = rank, world
+        self.x, self.y = load_arrays(name, train)
+        self.gen = np.random.default_rng([int(seed), int(rank), int(train)])
+        self.pos = 0
+        if self.x is not None and not one_pass and train:
+            self.perm = self.gen.permutation(len(self.x))
+        else:
+            self.perm = None if self.x is None else np.arange(len(self.x))
+
+    def __len__(self):
+        if self.x is None or not self.one_pass:
+            raise TypeError("infinite stream")
+        return len(self.x) // (self.local * self.world)
+
+    def _take(self, n):
+        if self.x is None:
+            img = self.gen.integers(0, 256, size=(n, 32, 32, 3), dtype=np.uint8)
+            lab = np.zeros(n, dtype=np.int32)
+            return img, lab
+        idx = []
+        while len(idx) < n:
+            # rank r reads a strided shard of the (shuffled) index stream
+            if self.pos * self.world + self.rank >= len(self.perm):
+                if self.one_pass:
+                    break
+                self.pos = 0
+                if self.perm is not None and not self.one_pass:
+                    self.perm = self.gen.permutation(len(self.x))
+            idx.append(self.perm[self.pos * self.world + self.rank])
+            self.pos += 1
+        idx = np.asarray(idx, dtype=np.int64)
+        return self.x[idx], self.y[idx]
+
+    def _batch(self, n):
+        img, lab = self._take(n)
+        if len(img) < n:
+            raise StopIteration
+        return img, lab
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        s = self.substeps
+        n = self.local * (s or 1)
+        img, lab = self._batch(n)
+        shape = (s, self.local) if s else (self.local,)
+        images = torch.from_numpy(img.reshape(*shape, 32, 32, 3)).to(self.device, non_blocking=True)
+        labels = torch.from_numpy(lab.reshape(*shape)).to(self.device)
+        return {"images": images, "labels": labels,
+                "conditioning": torch.zeros(shape, dtype=torch.uint8, device=self.device)}
+
+    next = __next__
+
+
+def create_dataset(config, device, seed, rank=0, world=1):
+    """(train_iter, eval_iter) like ldm/dataset.py:65-246 for the supported datasets."""
+    name = config.data.dataset
+    tr = config.training
+    train = BatchStream(name, tr.batch_size_train, train=True, device=device, seed=seed, rank=rank, world=world,
+                        substeps=tr.substeps)
+    evl = BatchStream(name, tr.batch_size_eval, train=False, device=device, seed=seed + 1, rank=rank, world=world)
+    return train, evl
+
+
+def create_one_time_eval_dataset(config, batch_size, device, rank=0, world=1):
+    """Unshuffled single pass over the test split (ldm/dataset.py:379-410), sharded by rank."""
+    return BatchStream(config.data.dataset, batch_size * world, train=False, device=device, rank=rank, world=world,
+                       one_pass=True)

@@ -1,0 +1,230 @@
+"""Experiment harness on PyTorch-ROCm + libmulan_hip (mirror of ldm/experiment.py + ldm/experiment_vdm.py).
+
+Kept surface: Experiment(config) -> .train_step(base_rng, state, batch), .eval_step(base_rng, params,
+batch, eval_step), .loss_fn(params, inputs, step, rng, is_train), .get_model_and_params(rng),
+.train_and_evaluate(workdir), .evaluate(logdir, checkpoint_dir), .p_train_step / .p_eval_step.
+jax.pmap/lax.scan/lax.pmean become: one process per GPU (torchrun), a host loop over sub-steps, and a
+bucketed RCCL all-reduce of the flat gradient buffer overlapped with backward (mulan_amd.parallel).
+"""
+import abc
+import functools
+import logging
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import checkpoint as ckpt_lib
+from . import data as dataset
+from . import parallel
+from .model import VDMConfig, make_vdm, tree_leaves
+from .rng import PRNGKey
+from .train_state import TrainState, tree_leaves_in_layout
+
+log = logging.getLogger("mulan")
+
+
+def restore_partial(state, state_restore_dict):
+    """Key-wise overlay of a checkpoint onto the state (ldm/experiment.py:377-393)."""
+    state.load_state_dict(state_restore_dict, strict=False)
+    return state
+
+
+class Experiment(abc.ABC):
+    """Boilerplate for training and evaluating VDM models (ldm/experiment.py:42-104)."""
+
+    def __init__(self, config, device=None):
+        self.config = config
+        self.rank, self.world, local = parallel.init_distributed()
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("the MuLAN hot path needs an MI355X (no CPU fallback); no HIP device visible")
+            device = torch.device("cuda", local if self.world > 1 else torch.cuda.current_device())
+            torch.cuda.set_device(device)
+        self.device = device
+
+        # Set seed before initializing model (ldm/experiment.py:48-50).
+        self.rng = PRNGKey(config.training.seed)
+        self.rng, data_rng = self.rng.split()
+        self.train_iter, self.eval_iter = dataset.create_dataset(config, device, data_rng.v % (1 << 31), self.rank,
+                                                                 self.world)
+        self.rng, model_rng = self.rng.split()
+        self.model, params = self.get_model_and_params(model_rng)
+        n_params = sum(v.numel() for _, v in tree_leaves(params))
+        log.info("parameters: %.2f M", n_params / 1e6)
+
+        self.state = TrainState.create(apply_fn=self.model.apply, variables={"params": params}, device=device,
+                                       optimizer_args=dict(config.optimizer.args.items()))
+        self.lr_schedule = self.get_lr_schedule()
+
+        ckpt_restore_dir = self.config.get('ckpt_restore_dir', 'None')
+        if ckpt_restore_dir != 'None':
+            self.state = restore_partial(self.state, ckpt_lib.restore_dict(ckpt_restore_dir))
+
+        leaves = [(leaf, off, leaf.numel()) for (path, off, shape), (_, leaf) in
+                  zip(self.state.layout, tree_leaves_in_layout(self.state.params, self.state.layout))]
+        self.reducer = parallel.GradReducer(self.state.grad, leaves)
+
+        self.rng, train_rng = self.rng.split()
+        self._train_rng = train_rng
+        self.rng, eval_rng, sample_rng = self.rng.split(3)
+        self._eval_rng, self._sample_rng = eval_rng, sample_rng
+
+    # ---- schedules / optimiser ------------------------------------------------------------------
+    def get_lr_schedule(self):
+        """optax.linear_schedule warm-up (+ optional linear decay), ldm/experiment.py:106-129."""
+        lr = self.config.optimizer.learning_rate
+        tr = self.config.training
+        warm = tr.num_steps_lr_warmup
+        decay = bool(self.config.optimizer.lr_decay)
+        total = tr.num_steps_train
+
+        def schedule(step):
+            if step < warm or not decay:
+                return lr * min(max(step, 0), warm) / warm
+            return lr * max(0.0, 1.0 - (step - warm) / max(1, total - warm))
+        return schedule
+
+    @abc.abstractmethod
+    def get_model_and_params(self, rng):
+        ...
+
+    @abc.abstractmethod
+    def sample_fn(self, *, dummy_inputs, rng, params):
+        ...
+
+    @abc.abstractmethod
+    def loss_fn(self, params, inputs, step, rng, is_train):
+        ...
+
+    # ---- steps ----------------------------------------------------------------------------------
+    def train_step(self, base_rng, state, batch):
+        """Experiment.train_step (ldm/experiment.py:335-356): fold rank + step into the rng, value_and_grad,
+        gradient mean over ranks, lr schedule, AdamW+EMA, scalar mean over ranks."""
+        rng = base_rng.fold_in(self.rank).fold_in(state.step)
+        state.zero_grad()
+        self.reducer.prepare()
+        bpd, metrics = self.loss_fn(state.params, batch, step=state.step, rng=rng, is_train=True)
+        bpd.backward()
+        self.reducer.finish()
+        learning_rate = self.lr_schedule(state.step)
+        state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate, grad_scale=1.0 / self.world)
+        scalars = parallel.allreduce_mean_scalars(metrics['scalars'], self.device)
+        metrics['scalars'] = {'train_' + k: v for k, v in scalars.items()}
+        return state, metrics
+
+    def eval_step(self, base_rng, params, batch, eval_step=0):
+        """Experiment.eval_step (ldm/experiment.py:358-374)."""
+        rng = base_rng.fold_in(self.rank).fold_in(eval_step)
+        with torch.no_grad():
+            _, metrics = self.loss_fn(params, batch, eval_step, rng=rng, is_train=False)
+        scalars = parallel.allreduce_mean_scalars(metrics['scalars'], self.device)
+        metrics['scalars'] = {'eval_' + k: v for k, v in scalars.items()}
+        return metrics
+
+    def p_train_step(self, state, batch):
+        """pmap(scan(train_step)) analogue (ldm/experiment.py:88-91): `batch` leaves carry a leading
+        sub-step axis; returns the state and metrics stacked over sub-steps."""
+        substeps = batch['images'].shape[0]
+        stacked = {}
+        for s in range(substeps):
+            sub = {k: v[s] for k, v in batch.items()}
+            state, m = self.train_step(self._train_rng, state, sub)
+            for k, v in m['scalars'].items():
+                stacked.setdefault(k, []).append(v.detach() if torch.is_tensor(v) else torch.tensor(v))
+        return state, {'scalars': {k: torch.stack(v) for k, v in stacked.items()}}
+
+    def p_eval_step(self, params, batch, eval_step):
+        return self.eval_step(self._eval_rng, params, batch, eval_step)
+
+    # ---- loops ----------------------------------------------------------------------------------
+    def train_and_evaluate(self, workdir):
+        """Experiment.train_and_evaluate (ldm/experiment.py:199-294)."""
+        config = self.config.training
+        state = self.state
+        checkpoint_dir = os.path.join(workdir, 'checkpoints')
+        latest = ckpt_lib.latest_checkpoint(checkpoint_dir)
+        if latest:
+            state.load_state_dict(ckpt_lib.restore_dict(latest))
+        step = initial_step = int(state.step)
+        substeps = config.substeps
+        writer = ckpt_lib.ScalarWriter(workdir if self.rank == 0 else None)
+        if initial_step == 0:
+            writer.write_hparams(self.config.to_dict())
+        t_last, s_last = time.time(), step
+        while step < config.num_steps_train:
+            is_last_step = step + substeps >= config.num_steps_train
+            batch = next(self.train_iter)
+            state, _train_metrics = self.p_train_step(state, batch)
+            new_step = int(state.step)
+            assert new_step == step + substeps
+            step = new_step
+            if step % config.steps_per_logging == 0 or is_last_step:
+                metrics = {k: float(v.mean()) for k, v in _train_metrics['scalars'].items()}
+                now = time.time()
+                metrics['steps_per_sec'] = (step - s_last) / max(now - t_last, 1e-9)
+                t_last, s_last = now, step
+                writer.write_scalars(step, metrics)
+            if step % config.steps_per_eval == 0 or is_last_step or step == 1000:
+                eval_metrics = []
+                for eval_step in range(config.num_steps_eval):
+                    batch = self.eval_iter.next()
+                    metrics = self.p_eval_step(state.ema_params, batch, eval_step)
+                    eval_metrics.append({k: float(v) for k, v in metrics['scalars'].items()})
+                writer.write_scalars(step, {k: float(np.mean([m[k] for m in eval_metrics])) for k in eval_metrics[0]})
+            if step % config.steps_per_save == 0 or is_last_step:
+                if self.rank == 0:
+                    ckpt_lib.save(checkpoint_dir, state.state_dict(), max_to_keep=100)
+        writer.close()
+        return state
+
+    def evaluate(self, logdir, checkpoint_dir):
+        """Experiment.evaluate (ldm/experiment.py:296-332): num_steps_eval batches on the EMA parameters."""
+        sd = ckpt_lib.restore_dict(checkpoint_dir)
+        self.state.load_state_dict({"ema_params": sd["ema_params"], "step": sd.get("step", 0)}, strict=True)
+        step = int(sd.get("step", 0))
+        eval_metrics = []
+        for eval_step in range(self.config.training.num_steps_eval):
+            batch = self.eval_iter.next()
+            metrics = self.p_eval_step(self.state.ema_params, batch, eval_step)
+            eval_metrics.append({k: float(v) for k, v in metrics['scalars'].items()})
+        out = {k: float(np.mean([m[k] for m in eval_metrics])) for k in eval_metrics[0]}
+        writer = ckpt_lib.ScalarWriter(os.path.join(logdir, 'eval') if self.rank == 0 else None)
+        writer.write_scalars(step, out)
+        writer.close()
+        return out
+
+
+class Experiment_VDM(Experiment):
+    """Train and evaluate a VDM model (ldm/experiment_vdm.py:27-110)."""
+
+    def get_model_and_params(self, rng):
+        config = VDMConfig(**self.config.model.to_dict())
+        model = make_vdm(self.config.vdm_type, config)
+        rng1, _rng2 = rng.split()
+        return model, model.init(rng1)
+
+    def loss_fn(self, params, inputs, step, rng, is_train):
+        """Experiment_VDM.loss_fn (ldm/experiment_vdm.py:47-78)."""
+        rng, sample_rng = rng.split()
+        rngs = {'sample': sample_rng}
+        if is_train:
+            rng, dropout_rng = rng.split()
+            rngs['dropout'] = dropout_rng
+        outputs = self.state.apply_fn(params, inputs['images'], inputs.get('labels'), inputs.get('conditioning'),
+                                      step=step, rngs=rngs, deterministic=not is_train)
+        rescale_to_bpd = 1. / (float(np.prod(inputs['images'].shape[1:])) * math.log(2.))
+        bpd_latent = outputs.loss_klz.mean() * rescale_to_bpd
+        bpd_recon = outputs.loss_recon.mean() * rescale_to_bpd
+        bpd_diff = outputs.loss_diff.mean() * rescale_to_bpd
+        bpd = bpd_recon + bpd_latent + bpd_diff
+        scalar_dict = {'bpd': bpd.detach(), 'bpd_latent': bpd_latent.detach(), 'bpd_recon': bpd_recon.detach(),
+                       'bpd_diff': bpd_diff.detach(), 'var0': outputs.var_0.detach(), 'var': outputs.var_1.detach()}
+        metrics = {'scalars': scalar_dict, 'images': {'inputs': inputs['images']}}
+        return bpd, metrics
+
+    def sample_fn(self, *, dummy_inputs, rng, params):
+        raise NotImplementedError("ancestral sampler (ldm/experiment_vdm.py:80-110) is outside the round-1 hot path "
+                                  "(SURVEY 8f rank 3)")

@@ -1,0 +1,100 @@
+"""ctypes binding of libmulan_hip.so (the C ABI declared in include/mulan_hip.h).
+
+There is no CPU fallback: if the shared object is missing or a symbol cannot be resolved this
+module raises, and every call checks the returned hipError_t.  torch is used only for device
+memory and the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmulan_hip.so")
+
+P, I, F, Z, U, LL = c_void_p, c_int, c_float, c_size_t, c_ulonglong, c_longlong
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mulan_hip.h
+SIGNATURES = {
+    "mulan_conv3x3_fwd": [P, P, P, P, I, P, P, I, I, I, I, I, P],
+    "mulan_conv3x3_wflip": [P, P, I, I, P],
+    "mulan_conv3x3_wgrad_workspace": [I, I, I, I, I],
+    "mulan_conv3x3_wgrad": [P, P, P, P, I, I, I, I, I, I, P],
+    "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P],
+    "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P],
+    "mulan_groupnorm_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, I, P],
+    "mulan_act_fwd": [P, P, Z, I, F, P],
+    "mulan_act_bwd": [P, P, P, Z, I, P],
+    "mulan_colsum": [P, P, I, I, I, I, I, P],
+    "mulan_softmax_fwd": [P, P, Z, I, P],
+    "mulan_softmax_bwd": [P, P, P, Z, I, P],
+    "mulan_fourier_fwd": [P, P, Z, P],
+    "mulan_fourier_bwd": [P, P, P, Z, I, P],
+    "mulan_temb_fwd": [P, P, I, I, I, I, P],
+    "mulan_temb_bwd": [P, P, P, I, I, I, I, P],
+    "mulan_rowbcast": [P, P, Z, I, I, I, I, P],
+    "mulan_axpby": [P, P, Z, F, F, P],
+    "mulan_encode_u8": [P, P, Z, P],
+    "mulan_poly_gamma_fwd": [P, P, P, P, P, P, P, P, I, I, F, F, P],
+    "mulan_poly_gamma_bwd": [P, P, P, P, P, P, P, P, P, I, I, F, F, P],
+    "mulan_qsample_fwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
+    "mulan_qsample_bwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P],
+    "mulan_diffloss_fwd": [I, P, P, P, I, P, P, P, P, I, I, P],
+    "mulan_diffloss_bwd": [I, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
+    "mulan_topk_fwd": [P, P, P, P, P, P, I, I, I, F, P],
+    "mulan_topk_bwd": [P, P, P, P, P, P, I, I, P],
+    "mulan_adamw_ema_step": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P],
+    "mulan_randn": [P, Z, U, U, P],
+    "mulan_version": [],
+}
+_RESTYPES = {"mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_version": c_char_p}
+
+
+class MulanHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads the library (after torch, so the HIP runtime already in the process is reused)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (libamdhip64.so.7 must be resident first)
+    if not os.path.exists(LIB_PATH):
+        raise MulanHipError(
+            f"{LIB_PATH} not found: build it with `python -m mulan_amd.build` "
+            "(there is no CPU fallback for the MuLAN hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise MulanHipError("non-contiguous tensor passed to the HIP boundary")
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MulanHipError(f"{name} failed with hipError_t {rc}")
+
+
+def version():
+    return load().mulan_version().decode()

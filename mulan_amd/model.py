@@ -1,0 +1,493 @@
+"""MuLAN / VDM models over the HIP kernels (host-side mirror of the reference's Flax modules).
+
+Functional, Flax-like API: `VDM(config).init(rng)` returns a parameter tree whose names and shapes
+are the reference's (the only layout difference is conv_in, stored with a 16th
+zero input channel for aligned loads), `VDM.apply(params, images, labels, conditioning, step, rngs,
+deterministic)` returns a VDMOutput.  Mirrors:
+  VDMConfig / VDMOutput ............ ldm/model_vdm.py:33-92
+  ScoreUNet / ldm UNet / UnetEncoder  ldm/model_vdm.py:309-388, ldm/ldm_unet.py:64-142,
+                                     ldm/model_mulan_epsilon.py:101-154
+  ResnetBlock / AttnBlock .......... ldm/model_vdm.py:610-701, ldm/ldm_unet.py:10-61
+  NoiseSchedule_polynomial_fixedend  ldm/model_mulan_epsilon.py:481-613
+  NoiseSchedule_{Scalar,FixedLinear,NNet} (plain VDM) ldm/model_vdm.py:418-509
+  VDM.__call__ ...................... ldm/model_mulan_velocity.py:188-268,
+                                     ldm/model_mulan_epsilon.py:280-363, ldm/model_vdm.py:110-180
+All tensor math runs in libmulan_hip.so (mulan_amd.ops); there is no CPU path.
+"""
+import dataclasses
+import math
+from typing import Any, Optional
+
+import torch
+
+from . import ops
+from .rng import Key
+
+HW = 1024
+D = 3072
+
+
+# ----------------------------------------------------------------------------- config / output
+@dataclasses.dataclass(frozen=True)
+class VDMConfig:
+    """Same fields as the reference dataclass (ldm/model_vdm.py:33-82); unknown keys raise TypeError."""
+    vocab_size: int
+    sample_softmax: bool
+    antithetic_time_sampling: bool
+    with_fourier_features: bool
+    with_attention: bool
+    gamma_type: str
+    gamma_min: float
+    gamma_max: float
+    sm_n_timesteps: int
+    sm_n_embd: int
+    sm_n_layer: int
+    sm_pdrop: float
+    sm_kernel_init: Any = None
+    forward_n_layer: int = 4
+    forward_type: int = 1
+    sigma_type: str = 'learnable_scalar'
+    sigma_min: float = 0
+    sigma_max: float = 20.0
+    sm_mult: float = 1.0
+    sigma_prior: float = 1.0
+    blur_noise: bool = False
+    sigma_recons_type: str = 'sigmoid'
+    loss_type: str = 'recons'
+    reparam_type: str = 'noise'
+    nn_input: str = 'gamma'
+    condition: str = 'label'
+    latent_size: int = 10
+    epsilon: float = 0.0
+    encoder: str = 'cnn'
+    model_time: bool = False
+    monotone_layer: str = 'dense_monotone'
+    latent_type: str = 'gumbel'
+    z_conditioning: bool = False
+    importance_sampling: bool = False
+    velocity_from_epsilon: bool = False
+    unet_type: str = 'vdm'
+    topk_noise_type: str = 'gamma'
+    latent_k: int = 15
+    trace_matching: bool = False
+
+
+@dataclasses.dataclass
+class VDMOutput:
+    loss_recon: torch.Tensor   # [B]
+    loss_klz: torch.Tensor     # [B]
+    loss_diff: torch.Tensor    # [B]
+    var_0: torch.Tensor
+    var_1: torch.Tensor
+
+
+# ----------------------------------------------------------------------------- initialisers
+def _lecun_normal(gen, shape, fan_in):
+    """jax.nn.initializers.lecun_normal (flax Dense/Conv default): truncated normal, var = 1/fan_in"""
+    std = math.sqrt(1.0 / fan_in) / .87962566103423978
+    t = torch.empty(shape, dtype=torch.float32)
+    torch.nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2 * std, b=2 * std, generator=gen)
+    return t
+
+
+def _dense(gen, cin, cout, bias=True, zero=False):
+    p = {"kernel": torch.zeros(cin, cout) if zero else _lecun_normal(gen, (cin, cout), cin)}
+    if bias:
+        p["bias"] = torch.zeros(cout)
+    return p
+
+
+def _conv(gen, cin, cout, zero=False, pad_in=0):
+    k = torch.zeros(3, 3, cin, cout) if zero else _lecun_normal(gen, (3, 3, cin, cout), 9 * cin)
+    if pad_in:
+        k = torch.cat([k, torch.zeros(3, 3, pad_in, cout)], dim=2)
+    return {"kernel": k, "bias": torch.zeros(cout)}
+
+
+def _gn(C):
+    return {"scale": torch.ones(C), "bias": torch.zeros(C)}
+
+
+def _resblock_init(gen, cin, cout, cond_dim):
+    p = {"GroupNorm_0": _gn(cin), "conv1": _conv(gen, cin, cout), "cond_proj": _dense(gen, cond_dim, cout, False, True),
+         "GroupNorm_1": _gn(cout), "conv2": _conv(gen, cout, cout, zero=True)}
+    if cin != cout:
+        p["nin_shortcut"] = _dense(gen, cin, cout)
+    return p
+
+
+def _attn_init(gen, C):
+    return {"GroupNorm_0": _gn(C), "q": _dense(gen, C, C), "k": _dense(gen, C, C), "v": _dense(gen, C, C),
+            "proj_out": _dense(gen, C, C, zero=True)}
+
+
+def _unet_init(gen, E, n_layers, cond_in, out_ch, with_up):
+    p = {"dense0": _dense(gen, cond_in, 4 * E), "dense1": _dense(gen, 4 * E, 4 * E),
+         "conv_in": _conv(gen, 15, E, pad_in=1)}
+    for i in range(n_layers):
+        p[f"down.block_{i}"] = _resblock_init(gen, E, E, 4 * E)
+    p["mid.block_1"] = _resblock_init(gen, E, E, 4 * E)
+    p["mid.attn_1"] = _attn_init(gen, E)
+    p["mid.block_2"] = _resblock_init(gen, E, E, 4 * E)
+    if with_up:
+        for i in range(n_layers + 1):
+            p[f"up.block_{i}"] = _resblock_init(gen, 2 * E, E, 4 * E)
+    p["GroupNorm_0"] = _gn(E)
+    p["conv_out"] = _conv(gen, E, out_ch, zero=True)
+    return p
+
+
+# ----------------------------------------------------------------------------- blocks
+class _Drop:
+    """Per-apply dropout context: one Philox seed, a distinct counter window per dropout site."""
+
+    def __init__(self, key: Optional[Key], rate: float):
+        self.on = key is not None and rate > 0.0
+        self.keep = 1.0 - rate if self.on else 1.0
+        self.seed = key.v if key is not None else 0
+        self.site = 0
+
+    def next(self):
+        self.site += 1
+        return self.keep, self.seed, self.site << 34
+
+
+def resnet_block(p, x1, x2, cond, drop):
+    """ResnetBlock.__call__ (ldm/model_vdm.py:618-657 / ldm/ldm_unet.py:18-61) on [x1|x2]."""
+    h = ops.group_norm(x1, x2, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
+    cb = ops.linear(cond, p["cond_proj"]["kernel"])          # [B,E] or [B,1024,E]
+    h = ops.conv3x3(h, p["conv1"]["kernel"], p["conv1"]["bias"], cbias=cb)
+    keep, seed, off = drop.next()
+    h = ops.group_norm(h, None, p["GroupNorm_1"]["scale"], p["GroupNorm_1"]["bias"], act=True, keep=keep, seed=seed,
+                       offset=off)
+    if "nin_shortcut" in p:
+        if x2 is None:
+            res = ops.linear(x1, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
+        else:
+            res = ops.linear2(x1, x2, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
+    else:
+        res = x1
+    return ops.conv3x3(h, p["conv2"]["kernel"], p["conv2"]["bias"], res=res)
+
+
+def attn_block(p, x):
+    """AttnBlock.__call__ with num_heads = 1 (ldm/model_vdm.py:668-701)."""
+    h = ops.group_norm(x, None, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=False)
+    q = ops.linear(h, p["q"]["kernel"], p["q"]["bias"])
+    k = ops.linear(h, p["k"]["kernel"], p["k"]["bias"])
+    v = ops.linear(h, p["v"]["kernel"], p["v"]["bias"])
+    o = ops.attention(q, k, v)
+    return ops.linear(o, p["proj_out"]["kernel"], p["proj_out"]["bias"], res=x)
+
+
+def _unet_stem(p, z, t, conditioning, E, n_layers, per_pixel, with_attention, drop):
+    """conv_in .. mid.block_2 shared by ScoreUNet, ldm UNet and UnetEncoder."""
+    if per_pixel:
+        # ldm_unet.py:82-90: temb over t.reshape(-1) -> [B,32,32,3E]; dense0(concat[temb, c]) is evaluated as
+        # temb @ W[:3E] + broadcast(c @ W[3E:] + b) so the per-pixel concat is never materialised.
+        B = z.shape[0]
+        none = torch.empty((B * D, 0), device=z.device, dtype=torch.float32)
+        temb3 = ops.cond_input(t.reshape(-1), none, E).view(B * HW, 3 * E)
+        w0 = p["dense0"]["kernel"]
+        cs = ops.linear(conditioning, w0[3 * E:], p["dense0"]["bias"])
+        cond = ops.silu(ops.linear(temb3, w0[:3 * E], None, res=ops.row_broadcast(cs, HW)))
+    else:
+        cond = ops.silu(ops.linear(ops.cond_input(t, conditioning, E), p["dense0"]["kernel"], p["dense0"]["bias"]))
+    cond = ops.silu(ops.linear(cond, p["dense1"]["kernel"], p["dense1"]["bias"]))
+    if per_pixel:
+        cond = cond.view(z.shape[0], HW, -1)
+    h = ops.conv3x3(ops.fourier_features(z), p["conv_in"]["kernel"], p["conv_in"]["bias"])
+    hs = [h]
+    for i in range(n_layers):
+        h = resnet_block(p[f"down.block_{i}"], hs[-1], None, cond, drop)
+        if with_attention:
+            h = attn_block(p[f"down.attn_{i}"], h)
+        hs.append(h)
+    h = resnet_block(p["mid.block_1"], hs[-1], None, cond, drop)
+    h = attn_block(p["mid.attn_1"], h)
+    h = resnet_block(p["mid.block_2"], h, None, cond, drop)
+    return h, hs, cond
+
+
+def score_unet(p, cfg, z, g_t, conditioning, drop, time=False):
+    """ScoreUNet.__call__ (ldm/model_vdm.py:314-388) / ldm_unet.UNet.__call__ (ldm/ldm_unet.py:69-142).
+    z [B,1024,3]; g_t [B] (vdm) or [B,1024,3] (ldm); conditioning [B,K]."""
+    per_pixel = cfg.unet_type == 'ldm'
+    E, L = cfg.sm_n_embd, cfg.sm_n_layer
+    t = g_t if (time and not per_pixel) else (g_t - cfg.gamma_min) / (cfg.gamma_max - cfg.gamma_min)
+    h, hs, cond = _unet_stem(p, z, t, conditioning, E, L, per_pixel, cfg.with_attention, drop)
+    for i in range(L + 1):
+        h = resnet_block(p[f"up.block_{i}"], h, hs.pop(), cond, drop)
+        if cfg.with_attention:
+            h = attn_block(p[f"up.attn_{i}"], h)
+    assert not hs
+    h = ops.group_norm(h, None, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
+    return ops.conv3x3(h, p["conv_out"]["kernel"], p["conv_out"]["bias"], res=z)
+
+
+def unet_encoder(p, cfg, f, drop):
+    """UnetEncoder.__call__ (ldm/model_mulan_epsilon.py:101-154): f [B,1024,3] -> logits [B,latent_size]"""
+    B = f.shape[0]
+    E = cfg.sm_n_embd
+    t = torch.zeros(B, device=f.device)
+    conditioning = torch.zeros((B, 1), device=f.device)
+    h, _, _ = _unet_stem(p, f, t, conditioning, E, cfg.forward_n_layer, False, cfg.with_attention, drop)
+    h = ops.group_norm(h, None, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
+    h = ops.conv3x3(h, p["conv_out"]["kernel"], p["conv_out"]["bias"])          # [B,1024,1]
+    h = ops.silu(h.view(B, HW))
+    return ops.linear(h, p["dense_layer_final"]["kernel"], p["dense_layer_final"]["bias"])
+
+
+def poly_coefficients(p, emb):
+    """NoiseSchedule_polynomial_fixedend._compute_coefficients (ldm/model_mulan_epsilon.py:531-538)"""
+    h = ops.silu(ops.linear(emb, p["dense_1"]["kernel"], p["dense_1"]["bias"]))
+    h = ops.silu(ops.linear(h, p["dense_2"]["kernel"], p["dense_2"]["bias"]))
+    a = ops.linear(h, p["dense_out_a"]["kernel"], p["dense_out_a"]["bias"])
+    b = ops.linear(h, p["dense_out_b"]["kernel"], p["dense_out_b"]["bias"])
+    c = ops.softplus_shift(ops.linear(h, p["dense_out_c"]["kernel"], p["dense_out_c"]["bias"]), 1e-3)
+    return a, b, c
+
+
+def encode_images(images_u8):
+    """EncDec.encode (ldm/model_vdm.py:274-280) as a device tensor [B,1024,3] (exact in fp32)."""
+    return ops.encode_u8(images_u8.reshape(images_u8.shape[0], HW, 3))
+
+
+# ----------------------------------------------------------------------------- VDM variants
+class _VDMBase:
+    def __init__(self, config: VDMConfig):
+        self.config = config
+
+    def _noise(self, rngs, noise, B, device, need_gamma):
+        """Draw (t0, raw Gamma, eps_0, eps) in the reference's make_rng('sample') order
+        (ldm/model_mulan_velocity.py:195, :95-96 via :210, :223, :235) unless given explicitly."""
+        noise = dict(noise or {})
+        key = rngs.get("sample") if rngs else None
+        if any(k not in noise for k in ("t0", "eps_0", "eps")) or (need_gamma and "gamma_raw" not in noise):
+            if key is None:
+                raise ValueError("VDM.apply needs rngs={'sample': Key} or explicit noise")
+            k_t, k_g, k_0, k_e = key.split(4)
+            noise.setdefault("t0", k_t.uniform())
+            if need_gamma:
+                cfg = self.config
+                noise.setdefault("gamma_raw", k_g.gamma(1.0 / cfg.latent_k, (10, B, cfg.latent_size), device))
+            noise.setdefault("eps_0", k_0.normal((B, D), device))
+            noise.setdefault("eps", k_e.normal((B, D), device))
+        return noise
+
+    def _times(self, t0, B, device):
+        cfg = self.config
+        if not cfg.antithetic_time_sampling:
+            raise NotImplementedError("antithetic_time_sampling=False")
+        # t = mod(t0 + arange(0, 1, 1/B), 1)  (ldm/model_mulan_velocity.py:196-198), built in fp32 like jnp
+        t = torch.remainder(torch.tensor(float(t0), dtype=torch.float32) + torch.arange(B, dtype=torch.float32)
+                            * torch.tensor(1.0 / B, dtype=torch.float32), 1.0)
+        T = cfg.sm_n_timesteps
+        if T > 0:
+            t = torch.ceil(t * T) / T
+        return t.to(device)
+
+    def __call__(self, params, *a, **kw):
+        return self.apply(params, *a, **kw)
+
+
+class MulanVDM(_VDMBase):
+    """model_mulan_velocity.VDM / model_mulan_epsilon.VDM selected by `parameterization`."""
+
+    def __init__(self, config: VDMConfig, parameterization: str):
+        super().__init__(config)
+        assert parameterization in ("velocity", "epsilon")
+        self.parameterization = parameterization
+        c = config
+        if c.latent_type != 'topk' or c.encoder != 'unet' or c.gamma_type != 'poly_fixedend':
+            raise NotImplementedError(
+                "hot path covers latent_type=topk, encoder=unet, gamma_type=poly_fixedend (the shipped configs); "
+                f"got {c.latent_type}/{c.encoder}/{c.gamma_type}")
+        if c.topk_noise_type != 'gamma':
+            raise NotImplementedError("topk_noise_type=gumbel")
+        if parameterization == "velocity" and c.sm_n_timesteps != 0:
+            raise AssertionError("model_mulan_velocity asserts T == 0 (ldm/model_mulan_velocity.py:255)")
+
+    def init(self, rng: Key):
+        c = self.config
+        gen = torch.Generator().manual_seed(rng.v & ((1 << 63) - 1))
+        E = c.sm_n_embd
+        K = c.latent_size if c.z_conditioning else 1
+        temb = 3 * E if c.unet_type == 'ldm' else E
+        score = _unet_init(gen, E, c.sm_n_layer, temb + K, 3, True)
+        enc = _unet_init(gen, E, c.forward_n_layer, E + 1, 1, False)
+        enc["dense_layer_final"] = _dense(gen, HW, c.latent_size)
+        lat = c.latent_size if c.reparam_type == 'true' else 10
+        gamma = {"dense_1": _dense(gen, lat, D), "dense_2": _dense(gen, D, D),
+                 "dense_out_a": _dense(gen, D, D, zero=True), "dense_out_b": _dense(gen, D, D),
+                 "dense_out_c": _dense(gen, D, D)}
+        return {"score_model": score, "encoder_model": enc, "gamma": gamma}
+
+    def apply(self, params, images, labels=None, conditioning=None, step=0, rngs=None, deterministic=True,
+              noise=None, return_aux=False):
+        cfg = self.config
+        dev = images.device
+        x = images.reshape(-1, D).contiguous()
+        if x.dtype != torch.uint8:
+            x = torch.round(x).to(torch.uint8)
+        B = x.shape[0]
+        noise = self._noise(rngs, noise, B, dev, cfg.reparam_type == 'true')
+        t = self._times(noise["t0"], B, dev)
+        f = encode_images(x)
+        drop_key = None if deterministic else (rngs or {}).get("dropout")
+        if not deterministic and drop_key is None:
+            raise ValueError("training mode needs rngs['dropout']")
+        k_enc, k_score = drop_key.split(2) if drop_key is not None else (None, None)
+        if cfg.reparam_type == 'true':
+            logits = unet_encoder(params["encoder_model"], cfg, f, _Drop(k_enc, cfg.sm_pdrop))
+            emb, kl_z = ops.topk_embedding(logits, noise["gamma_raw"], cfg.latent_k)
+        else:   # ldm/model_mulan_velocity.py:212-214
+            emb = torch.nn.functional.one_hot(labels.long(), 10).to(torch.float32)
+            kl_z = torch.zeros(B, device=dev)
+        a, b, c = poly_coefficients(params["gamma"], emb)
+        g0, g1, gt, gp = ops.poly_gamma(a, b, c, t, cfg.gamma_min, cfg.gamma_max)
+        zt, gbar, loss_recon, loss_klz, v0, v1 = ops.qsample(x, g0, g1, gt, noise["eps_0"], noise["eps"])
+        if cfg.z_conditioning:
+            cond = emb
+        else:
+            cond = conditioning.reshape(B, 1).to(torch.float32)
+        g_in = gt.view(B, HW, 3) if cfg.unet_type == 'ldm' else gbar
+        net = score_unet(params["score_model"], cfg, zt.view(B, HW, 3), g_in, cond, _Drop(k_score, cfg.sm_pdrop))
+        net = net.reshape(B, D)
+        T = cfg.sm_n_timesteps
+        if self.parameterization == "velocity":
+            mode = 1 if cfg.velocity_from_epsilon else 0
+            loss_diff = ops.diffusion_loss(mode, x, gt, gp, noise["eps"], zt, net)
+        elif T == 0:
+            loss_diff = ops.diffusion_loss(2, x, gt, gp, noise["eps"], zt, net)
+        else:
+            raise NotImplementedError("mulan_epsilon with sm_n_timesteps > 0 (ldm/model_mulan_epsilon.py:348-355)")
+        out = VDMOutput(loss_recon=loss_recon, loss_klz=kl_z + loss_klz, loss_diff=loss_diff, var_0=v0.mean(),
+                        var_1=v1.mean())
+        if return_aux:
+            return out, dict(emb=emb, zt=zt, net=net, gt=gt, gp=gp, t=t, logits=logits if cfg.reparam_type == 'true' else None)
+        return out
+
+
+class PlainVDM(_VDMBase):
+    """model_vdm.VDM (ldm/model_vdm.py:95-180): scalar noise schedule, epsilon prediction, T = 0 or T > 0
+    with reparam_type 'noise'.  gamma_type in {'fixed', 'learnable_scalar'}."""
+
+    def __init__(self, config: VDMConfig):
+        super().__init__(config)
+        if config.gamma_type not in ('fixed', 'learnable_scalar'):
+            raise NotImplementedError(f"model_vdm.VDM gamma_type={config.gamma_type} "
+                                      "(supported: fixed, learnable_scalar; reference raises on poly_fixedend, "
+                                      "ldm/model_vdm.py:101-108)")
+        if config.unet_type != 'vdm':
+            raise NotImplementedError("model_vdm.VDM always uses ScoreUNet")
+
+    def init(self, rng: Key):
+        c = self.config
+        gen = torch.Generator().manual_seed(rng.v & ((1 << 63) - 1))
+        E = c.sm_n_embd
+        p = {"score_model": _unet_init(gen, E, c.sm_n_layer, E + 1, 3, True)}
+        if c.gamma_type == 'learnable_scalar':   # NoiseSchedule_Scalar, ldm/model_vdm.py:418-431
+            p["gamma"] = {"w": torch.tensor([c.gamma_max - c.gamma_min], dtype=torch.float32),
+                          "b": torch.tensor([c.gamma_min], dtype=torch.float32)}
+        return p
+
+    def _gamma(self, params, t):
+        c = self.config
+        if c.gamma_type == 'fixed':
+            return c.gamma_min + (c.gamma_max - c.gamma_min) * t, torch.full_like(t, c.gamma_max - c.gamma_min)
+        w, b = params["gamma"]["w"], params["gamma"]["b"]
+        aw = torch.abs(w)     # tiny [1]-element host-side autograd glue for the 2 schedule scalars
+        return b + aw * t, aw.expand_as(t)
+
+    def apply(self, params, images, labels=None, conditioning=None, step=0, rngs=None, deterministic=True,
+              noise=None, return_aux=False):
+        cfg = self.config
+        dev = images.device
+        x = images.reshape(-1, D).contiguous()
+        if x.dtype != torch.uint8:
+            x = torch.round(x).to(torch.uint8)
+        B = x.shape[0]
+        noise = self._noise(rngs, noise, B, dev, False)
+        t = self._times(noise["t0"], B, dev)
+        ones = torch.ones(B, device=dev)
+        g0, _ = self._gamma(params, 0.0 * ones)
+        g1, _ = self._gamma(params, ones)
+        gt, gp = self._gamma(params, t)
+        T = cfg.sm_n_timesteps
+        if T > 0:   # ldm/model_vdm.py:162-170 ('noise' reparameterisation)
+            gs, _ = self._gamma(params, t - 1.0 / T)
+            gp = T * torch.expm1(gt - gs)
+        zt, gbar, loss_recon, loss_klz, v0, v1 = ops.qsample(x, g0.contiguous(), g1.contiguous(), gt.contiguous(),
+                                                             noise["eps_0"], noise["eps"])
+        drop_key = None if deterministic else (rngs or {}).get("dropout")
+        if not deterministic and drop_key is None:
+            raise ValueError("training mode needs rngs['dropout']")
+        cond = conditioning.reshape(B, 1).to(torch.float32)
+        net = score_unet(params["score_model"], cfg, zt.view(B, HW, 3), gt, cond, _Drop(drop_key, cfg.sm_pdrop))
+        loss_diff = ops.diffusion_loss(2, x, gt.contiguous(), gp.contiguous(), noise["eps"], zt, net.reshape(B, D))
+        out = VDMOutput(loss_recon=loss_recon, loss_klz=loss_klz, loss_diff=loss_diff, var_0=v0.mean(), var_1=v1.mean())
+        if return_aux:
+            return out, dict(zt=zt, net=net, gt=gt, gp=gp, t=t)
+        return out
+
+
+def make_vdm(vdm_type: str, config: VDMConfig):
+    """Experiment_VDM.get_model_and_params dispatch (ldm/experiment_vdm.py:32-38)."""
+    if vdm_type == 'mulan_velocity':
+        return MulanVDM(config, "velocity")
+    if vdm_type == 'mulan_epsilon':
+        return MulanVDM(config, "epsilon")
+    if vdm_type == 'vdm':
+        return PlainVDM(config)
+    raise KeyError(vdm_type)
+
+
+# ----------------------------------------------------------------------------- tree utilities
+def tree_leaves(tree, prefix=()):
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            yield from tree_leaves(v, prefix + (k,))
+        else:
+            yield prefix + (k,), v
+
+
+def tree_map(fn, tree):
+    return {k: tree_map(fn, v) if isinstance(v, dict) else fn(v) for k, v in tree.items()}
+
+
+def tree_set(tree, path, value):
+    for k in path[:-1]:
+        tree = tree[k]
+    tree[path[-1]] = value
+
+
+def to_flax_layout(tree):
+    """Product tree -> reference (Flax) layout: drops the zero 16th input channel of conv_in."""
+    def fix(path, v):
+        if path[-2:] == ("conv_in", "kernel") and v.shape[2] == 16:
+            return v[:, :, :15, :]
+        return v
+    out = {}
+    for path, v in tree_leaves(tree):
+        d = out
+        for k in path[:-1]:
+            d = d.setdefault(k, {})
+        d[path[-1]] = fix(path, v)
+    return out
+
+
+def from_flax_layout(flax_tree, like):
+    """Copies a reference-layout tree into the leaves of `like` (in place, under no_grad)."""
+    with torch.no_grad():
+        for path, dst in tree_leaves(like):
+            src = flax_tree
+            for k in path:
+                src = src[k]
+            src = torch.as_tensor(src, dtype=torch.float32)
+            if path[-2:] == ("conv_in", "kernel") and src.shape[2] == 15:
+                src = torch.cat([src, torch.zeros(3, 3, 1, src.shape[3])], dim=2)
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"shape mismatch at {'/'.join(path)}: {tuple(src.shape)} vs {tuple(dst.shape)}")
+            dst.copy_(src.to(dst.device))
+    return like

@@ -1,0 +1,557 @@
+"""torch.autograd wiring over the C ABI (include/mulan_hip.h).
+
+Each Function's forward and backward are launches of hand-written HIP kernels through
+`mulan_amd.lib`; torch supplies device buffers, the current stream and the autograd tape only.
+Shapes: images are [B, 1024, C] (NHWC with H = W = 32 flattened), matrices row-major, all fp32.
+"""
+import math
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import lib
+from .lib import call, ptr, stream
+
+H = W = 32
+HW = H * W
+D = HW * 3
+
+
+def _c(t):
+    return t if (t is None or t.is_contiguous()) else t.contiguous()
+
+
+def _chk(t, name="tensor"):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise lib.MulanHipError(f"{name}: expected a float32 CUDA(HIP) tensor, got {t.dtype} on {t.device}")
+
+
+# ----------------------------------------------------------------------------- raw launches
+def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
+    """x [B,1024,C], w [3,3,C,N] -> [B,1024,N]"""
+    _chk(x, "conv input")
+    B, C, N = x.shape[0], x.shape[-1], w.shape[-1]
+    assert w.shape[:3] == (3, 3, C), (w.shape, C)
+    y = torch.empty((B, HW, N), device=x.device, dtype=torch.float32)
+    mode = 0
+    if cbias is not None:
+        mode = 1 if cbias.dim() == 2 else 2
+    call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N, stream())
+    return y
+
+
+def conv3x3_dgrad_raw(dy, w):
+    C, N = w.shape[2], w.shape[3]
+    wT = torch.empty((3, 3, N, C), device=w.device, dtype=torch.float32)
+    call("mulan_conv3x3_wflip", ptr(w), ptr(wT), C, N, stream())
+    return conv3x3_raw(dy, wT)
+
+
+def conv3x3_wgrad_raw(x, dy):
+    B, C, N = x.shape[0], x.shape[-1], dy.shape[-1]
+    nbytes = lib.load().mulan_conv3x3_wgrad_workspace(B, H, W, C, N)
+    ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
+    dw = torch.empty((3, 3, C, N), device=x.device, dtype=torch.float32)
+    call("mulan_conv3x3_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
+    return dw
+
+
+def gemm_raw(A, Bm, M, N, K, *, bias=None, R=None, transA=False, transB=False, alpha=1.0, beta=1.0,
+             lda=None, ldb=None, batch=1, sA=0, sB=0, out=None):
+    """C = alpha * op(A) op(B) + bias + beta * R.  Returns [batch, M, N] (or [M, N] when batch == 1)."""
+    lda = lda if lda is not None else (M if transA else K)
+    ldb = ldb if ldb is not None else (K if transB else N)
+    if out is None:
+        out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=A.device, dtype=torch.float32)
+    call("mulan_gemm", ptr(A), ptr(Bm), ptr(out), ptr(bias), ptr(R), M, N, K, lda, ldb, N, N, int(transA),
+         int(transB), batch, sA, sB, M * N, M * N, float(alpha), float(beta), stream())
+    return out
+
+
+def colsum_raw(x2d, nseg, seg, C):
+    out = torch.empty((nseg, C), device=x2d.device, dtype=torch.float32)
+    call("mulan_colsum", ptr(x2d), ptr(out), nseg, seg, C, C, 0, stream())
+    return out
+
+
+def randn(shape, seed, offset, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("mulan_randn", ptr(out), out.numel(), int(seed) & (2**64 - 1), int(offset), stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- conv
+class Conv3x3Fn(torch.autograd.Function):
+    """y = conv3x3(x, w) + bias + cbias + res   (ldm/model_vdm.py:633-656)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cbias, res):
+        x, w = _c(x), _c(w)
+        y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res))
+        ctx.save_for_backward(x, w)
+        ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        has_bias, cb_dim, has_res = ctx.has
+        B, N = dy.shape[0], dy.shape[-1]
+        dx = conv3x3_dgrad_raw(dy, w) if ctx.needs_input_grad[0] else None
+        dw = conv3x3_wgrad_raw(x, dy) if ctx.needs_input_grad[1] else None
+        dbias = dcb = None
+        per_sample = None
+        if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):
+            per_sample = colsum_raw(dy, B, HW, N)          # [B,N]
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = colsum_raw(per_sample, 1, B, N).view(N)
+        if cb_dim is not None and ctx.needs_input_grad[3]:
+            dcb = per_sample if cb_dim == 2 else dy
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        return dx, dw, dbias, dcb, dres
+
+
+def conv3x3(x, w, bias=None, cbias=None, res=None):
+    return Conv3x3Fn.apply(x, w, bias, cbias, res)
+
+
+# ----------------------------------------------------------------------------- dense
+class LinearFn(torch.autograd.Function):
+    """y[M,N] = x[M,K] @ w[K,N] + bias + res   (flax nn.Dense: y = x @ kernel + bias)"""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res):
+        x, w = _c(x), _c(w)
+        K, N = w.shape
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        y = gemm_raw(x2, w, M, N, K, bias=_c(bias), R=None if res is None else _c(res).reshape(M, N))
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, bias is not None, res is not None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xshape, has_bias, has_res = ctx.meta
+        K, N = w.shape
+        M = x2.shape[0]
+        dy2 = _c(dy).reshape(M, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_raw(dy2, w, M, K, N, transB=True).view(xshape)
+        if ctx.needs_input_grad[1]:
+            dw = gemm_raw(x2, dy2, K, N, M, transA=True)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum_raw(dy2, 1, M, N).view(N)
+        dres = dy if (has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres
+
+
+def linear(x, w, bias=None, res=None):
+    return LinearFn.apply(x, w, bias, res)
+
+
+class Linear2Fn(torch.autograd.Function):
+    """y = [x1 | x2] @ w + bias over a virtual channel concat (nin_shortcut on concat[h, skip],
+    ldm/model_vdm.py:369,652-653) without materialising the concat."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, bias):
+        x1, x2, w = _c(x1), _c(x2), _c(w)
+        K1, K2, N = x1.shape[-1], x2.shape[-1], w.shape[1]
+        a1, a2 = x1.reshape(-1, K1), x2.reshape(-1, K2)
+        M = a1.shape[0]
+        y = gemm_raw(a1, w[:K1], M, N, K1, bias=_c(bias))
+        y = gemm_raw(a2, w[K1:], M, N, K2, R=y, out=torch.empty_like(y))
+        ctx.save_for_backward(a1, a2, w)
+        ctx.shape = x1.shape[:-1]
+        return y.view(*x1.shape[:-1], N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        a1, a2, w = ctx.saved_tensors
+        K1, K2, N = a1.shape[1], a2.shape[1], w.shape[1]
+        M = a1.shape[0]
+        dy2 = _c(dy).reshape(M, N)
+        dx1 = gemm_raw(dy2, w[:K1], M, K1, N, transB=True).view(*ctx.shape, K1) if ctx.needs_input_grad[0] else None
+        dx2 = gemm_raw(dy2, w[K1:], M, K2, N, transB=True).view(*ctx.shape, K2) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w)
+            gemm_raw(a1, dy2, K1, N, M, transA=True, out=dw[:K1])
+            gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])
+        db = colsum_raw(dy2, 1, M, N).view(N) if ctx.needs_input_grad[3] else None
+        return dx1, dx2, dw, db
+
+
+def linear2(x1, x2, w, bias):
+    return Linear2Fn.apply(x1, x2, w, bias)
+
+
+# ----------------------------------------------------------------------------- activations
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind, shift):
+        x = _c(x)
+        y = torch.empty_like(x)
+        call("mulan_act_fwd", ptr(x), ptr(y), x.numel(), kind, float(shift), stream())
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        call("mulan_act_bwd", ptr(x), ptr(dy), ptr(dx), x.numel(), ctx.kind, stream())
+        return dx, None, None
+
+
+def silu(x):
+    return ActFn.apply(x, 1, 0.0)
+
+
+def softplus_shift(x, shift):
+    return ActFn.apply(x, 2, shift)
+
+
+# ----------------------------------------------------------------------------- group norm
+class GroupNormFn(torch.autograd.Function):
+    """y = dropout(act(GroupNorm([x1|x2])))  -> [B,1024,C1+C2]"""
+
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
+        x1, x2 = _c(x1), _c(x2)
+        B, C1 = x1.shape[0], x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        y = torch.empty((B, HW, C1 + C2), device=x1.device, dtype=torch.float32)
+        mean = torch.empty((B, groups), device=x1.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B,
+             HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), stream())
+        ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
+        ctx.meta = (groups, int(act), float(keep), int(seed), int(offset))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x1, x2, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, act, keep, seed, offset = ctx.meta
+        dy = _c(dy)
+        B, C1 = x1.shape[0], x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Ct = C1 + C2
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        dgp = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
+        dbp = torch.empty_like(dgp)
+        call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+             ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, stream())
+        dgamma = colsum_raw(dgp, 1, B, Ct).view(Ct)
+        dbeta = colsum_raw(dbp, 1, B, Ct).view(Ct)
+        return dx1, dx2, dgamma, dbeta, None, None, None, None, None, None
+
+
+def group_norm(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=1.0, seed=0, offset=0):
+    return GroupNormFn.apply(x1, x2, gamma, beta, groups, eps, int(act), keep, seed, offset)
+
+
+# ----------------------------------------------------------------------------- attention core
+class AttentionFn(torch.autograd.Function):
+    """softmax((q / sqrt(C)) k^T) v for one head over 1024 positions (ldm/model_vdm.py:679-683,704-802)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, S, C = q.shape
+        alpha = 1.0 / math.sqrt(C)
+        s = gemm_raw(q, k, S, S, C, transB=True, alpha=alpha, batch=B, sA=S * C, sB=S * C)
+        p = torch.empty_like(s)
+        call("mulan_softmax_fwd", ptr(s), ptr(p), B * S, S, stream())
+        del s
+        o = gemm_raw(p, v, S, C, S, batch=B, sA=S * S, sB=S * C)
+        ctx.save_for_backward(q, k, v, p)
+        return o.view(B, S, C)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, do):
+        q, k, v, p = ctx.saved_tensors
+        do = _c(do)
+        B, S, C = q.shape
+        alpha = 1.0 / math.sqrt(C)
+        dv = gemm_raw(p, do, S, C, S, transA=True, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+        dp = gemm_raw(do, v, S, S, C, transB=True, batch=B, sA=S * C, sB=S * C)
+        ds = torch.empty_like(dp)
+        call("mulan_softmax_bwd", ptr(p), ptr(dp), ptr(ds), B * S, S, stream())
+        del dp
+        dq = gemm_raw(ds, k, S, C, S, alpha=alpha, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+        dk = gemm_raw(ds, q, S, C, S, transA=True, alpha=alpha, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+        return dq, dk, dv
+
+
+def attention(q, k, v):
+    return AttentionFn.apply(q, k, v)
+
+
+# ----------------------------------------------------------------------------- embeddings
+class FourierFn(torch.autograd.Function):
+    """[z, sin(2^{6,7} 2pi z), cos(...), 0] -> 16 channels (ldm/model_vdm.py:341-343,812-829)"""
+
+    @staticmethod
+    def forward(ctx, z):
+        z = _c(z)
+        B = z.shape[0]
+        out = torch.empty((B, HW, 16), device=z.device, dtype=torch.float32)
+        call("mulan_fourier_fwd", ptr(z), ptr(out), B * HW, stream())
+        ctx.save_for_backward(z)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (z,) = ctx.saved_tensors
+        dout = _c(dout)
+        dz = torch.empty_like(z)
+        call("mulan_fourier_bwd", ptr(z), ptr(dout), ptr(dz), z.shape[0] * HW, 0, stream())
+        return dz
+
+
+def fourier_features(z):
+    return FourierFn.apply(z)
+
+
+class CondInputFn(torch.autograd.Function):
+    """concat([timestep_embedding(t, E), conditioning]) -> [n, E + K]  (ldm/model_vdm.py:335-336).
+    With rep > 1 the conditioning rows are broadcast `rep` times (ldm/ldm_unet.py:82-88)."""
+
+    @staticmethod
+    def forward(ctx, t, cond, E, rep):
+        t, cond = _c(t), _c(cond)
+        n, K = t.numel(), cond.shape[-1]
+        out = torch.empty((n, E + K), device=t.device, dtype=torch.float32)
+        call("mulan_temb_fwd", ptr(t), ptr(out), n, E, E + K, 0, stream())
+        call("mulan_rowbcast", ptr(cond), ptr(out), n, K, rep, E + K, E, stream())
+        ctx.save_for_backward(t)
+        ctx.meta = (E, K, rep, cond.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        (t,) = ctx.saved_tensors
+        E, K, rep, cshape = ctx.meta
+        dout = _c(dout)
+        n = t.numel()
+        dt = dc = None
+        if ctx.needs_input_grad[0]:
+            dt = torch.empty_like(t)
+            call("mulan_temb_bwd", ptr(t), ptr(dout), ptr(dt), n, E, E + K, 0, stream())
+        if ctx.needs_input_grad[1]:
+            dcr = dout[:, E:].contiguous()               # [n, K]
+            dc = dcr if rep == 1 else colsum_raw(dcr, n // rep, rep, K)
+            dc = dc.view(cshape)
+        return dt, dc, None, None
+
+
+def cond_input(t, cond, E, rep=1):
+    return CondInputFn.apply(t, cond, E, rep)
+
+
+class RowBcastFn(torch.autograd.Function):
+    """y[r] = x[r // rep]: per-pixel broadcast of a per-sample vector (ldm/ldm_unet.py:85-87)"""
+
+    @staticmethod
+    def forward(ctx, x, rep):
+        x = _c(x)
+        n, K = x.shape
+        y = torch.empty((n * rep, K), device=x.device, dtype=torch.float32)
+        call("mulan_rowbcast", ptr(x), ptr(y), n * rep, K, rep, K, 0, stream())
+        ctx.meta = (n, K, rep)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, K, rep = ctx.meta
+        return colsum_raw(_c(dy), n, rep, K), None
+
+
+def row_broadcast(x, rep):
+    return RowBcastFn.apply(x, rep)
+
+
+def encode_u8(x_u8):
+    """EncDec.encode (ldm/model_vdm.py:274-280): uint8 [B, ...] -> fp32 in (-1, 1), same shape"""
+    x_u8 = _c(x_u8)
+    f = torch.empty(x_u8.shape, device=x_u8.device, dtype=torch.float32)
+    call("mulan_encode_u8", ptr(x_u8), ptr(f), x_u8.numel(), stream())
+    return f
+
+
+# ----------------------------------------------------------------------------- MuLAN closed forms
+class PolyGammaFn(torch.autograd.Function):
+    """gamma_0, gamma_1, gamma_t, gamma'_t of NoiseSchedule_polynomial_fixedend
+    (ldm/model_mulan_epsilon.py:514-555); gradients flow into (a, b, c) through gamma_t and gamma'_t."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, t, gmin, gmax):
+        a, b, c, t = _c(a), _c(b), _c(c), _c(t)
+        B = a.shape[0]
+        g0, g1, gt, gp = (torch.empty_like(a) for _ in range(4))
+        call("mulan_poly_gamma_fwd", ptr(a), ptr(b), ptr(c), ptr(t), ptr(g0), ptr(g1), ptr(gt), ptr(gp), B, D,
+             float(gmin), float(gmax), stream())
+        ctx.save_for_backward(a, b, c, t)
+        ctx.lim = (float(gmin), float(gmax))
+        ctx.mark_non_differentiable(g0, g1)
+        return g0, g1, gt, gp
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, _d0, _d1, dgt, dgp):
+        a, b, c, t = ctx.saved_tensors
+        B = a.shape[0]
+        da, db, dc = (torch.empty_like(a) for _ in range(3))
+        call("mulan_poly_gamma_bwd", ptr(a), ptr(b), ptr(c), ptr(t), ptr(_c(dgt)) if dgt is not None else None,
+             ptr(_c(dgp)) if dgp is not None else None, ptr(da), ptr(db), ptr(dc), B, D, ctx.lim[0], ctx.lim[1],
+             stream())
+        return da, db, dc, None, None, None
+
+
+def poly_gamma(a, b, c, t, gmin, gmax):
+    return PolyGammaFn.apply(a, b, c, t, gmin, gmax)
+
+
+class QSampleFn(torch.autograd.Function):
+    """(z_t, mean gamma_t, loss_recon, loss_klz, var0, var1) from (x, gamma_0, gamma_1, gamma_t, eps0, eps)
+    (ldm/model_mulan_velocity.py:208-236; ldm/model_vdm.py:119-151,274-303)."""
+
+    @staticmethod
+    def forward(ctx, x_u8, g0, g1, gt, eps0, eps):
+        g0, g1, gt = _c(g0), _c(g1), _c(gt)
+        B = x_u8.shape[0]
+        per_elem = int(gt.numel() == B * D)
+        dev = x_u8.device
+        zt = torch.empty((B, D), device=dev, dtype=torch.float32)
+        gbar, recon, klz, v0, v1 = (torch.empty(B, device=dev, dtype=torch.float32) for _ in range(5))
+        call("mulan_qsample_fwd", ptr(x_u8), ptr(g0), ptr(g1), ptr(gt), per_elem, ptr(eps0), ptr(eps), ptr(zt),
+             ptr(gbar), ptr(recon), ptr(klz), ptr(v0), ptr(v1), B, D, stream())
+        ctx.save_for_backward(x_u8, g0, g1, gt, eps0, eps)
+        ctx.per_elem = per_elem
+        ctx.mark_non_differentiable(v0, v1)
+        return zt, gbar, recon, klz, v0, v1
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dzt, dgbar, drecon, dklz, _dv0, _dv1):
+        x, g0, g1, gt, eps0, eps = ctx.saved_tensors
+        B = x.shape[0]
+        dev = x.device
+        need0, need1 = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dzt = _c(dzt) if dzt is not None else torch.zeros((B, D), device=dev)
+        dgt = torch.empty((B, D), device=dev, dtype=torch.float32)
+        dg0 = torch.empty((B, D), device=dev, dtype=torch.float32) if need0 else None
+        dg1 = torch.empty((B, D), device=dev, dtype=torch.float32) if need1 else None
+        zero = None
+        if (need0 and drecon is None) or (need1 and dklz is None):
+            zero = torch.zeros(B, device=dev)
+        call("mulan_qsample_bwd", ptr(x), ptr(g0), ptr(g1), ptr(gt), ctx.per_elem, ptr(eps0), ptr(eps), ptr(dzt),
+             ptr(_c(dgbar)) if dgbar is not None else None,
+             ptr(_c(drecon) if drecon is not None else zero) if need0 else None,
+             ptr(_c(dklz) if dklz is not None else zero) if need1 else None,
+             ptr(dgt), ptr(dg0), ptr(dg1), B, D, stream())
+        if not ctx.per_elem:   # scalar schedule: reduce the per-element gradients to per-sample
+            dgt = colsum_raw(dgt.view(B, D, 1), B, D, 1).view(gt.shape)
+            dg0 = colsum_raw(dg0.view(B, D, 1), B, D, 1).view(g0.shape) if need0 else None
+            dg1 = colsum_raw(dg1.view(B, D, 1), B, D, 1).view(g1.shape) if need1 else None
+        else:
+            dgt = dgt.view(gt.shape)
+        return None, dg0, dg1, dgt, None, None
+
+
+def qsample(x_u8, g0, g1, gt, eps0, eps):
+    return QSampleFn.apply(x_u8, g0, g1, gt, eps0, eps)
+
+
+class DiffLossFn(torch.autograd.Function):
+    """loss_diff[B].  mode 0 velocity, 1 velocity_from_epsilon, 2 epsilon
+    (ldm/model_mulan_velocity.py:246-260; ldm/model_mulan_epsilon.py:338-355; ldm/model_vdm.py:156-170)."""
+
+    @staticmethod
+    def forward(ctx, mode, x_u8, gt, gp, eps, zt, net):
+        gt, gp, zt, net = _c(gt), _c(gp), _c(zt), _c(net)
+        B = x_u8.shape[0]
+        per_elem = int(gt.numel() == B * D)
+        loss = torch.empty(B, device=x_u8.device, dtype=torch.float32)
+        call("mulan_diffloss_fwd", mode, ptr(x_u8), ptr(gt), ptr(gp), per_elem, ptr(eps), ptr(zt), ptr(net),
+             ptr(loss), B, D, stream())
+        ctx.save_for_backward(x_u8, gt, gp, eps, zt, net)
+        ctx.meta = (mode, per_elem)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dloss):
+        x, gt, gp, eps, zt, net = ctx.saved_tensors
+        mode, per_elem = ctx.meta
+        B = x.shape[0]
+        dev = x.device
+        dnet, dgt, dgp = (torch.empty((B, D), device=dev, dtype=torch.float32) for _ in range(3))
+        dzt = torch.empty((B, D), device=dev, dtype=torch.float32) if mode == 1 else None
+        call("mulan_diffloss_bwd", mode, ptr(x), ptr(gt), ptr(gp), per_elem, ptr(eps), ptr(zt), ptr(net),
+             ptr(_c(dloss)), ptr(dnet), ptr(dgt), ptr(dgp), ptr(dzt), B, D, stream())
+        if not per_elem:
+            dgt = colsum_raw(dgt.view(B, D, 1), B, D, 1).view(gt.shape)
+            dgp = colsum_raw(dgp.view(B, D, 1), B, D, 1).view(gp.shape)
+        else:
+            dgt, dgp = dgt.view(gt.shape), dgp.view(gp.shape)
+        return None, None, dgt, dgp, None, (dzt.view(zt.shape) if dzt is not None else None), dnet.view(net.shape)
+
+
+def diffusion_loss(mode, x_u8, gt, gp, eps, zt, net):
+    return DiffLossFn.apply(mode, x_u8, gt, gp, eps, zt, net)
+
+
+class TopKFn(torch.autograd.Function):
+    """(embedding, kl_z) = relaxed top-k straight-through latent (ldm/model_mulan_velocity.py:78-120)."""
+
+    @staticmethod
+    def forward(ctx, logits, gnoise, k, tau):
+        logits, gnoise = _c(logits), _c(gnoise)
+        B, L = logits.shape
+        emb, soft = torch.empty_like(logits), torch.empty_like(logits)
+        kl = torch.empty(B, device=logits.device, dtype=torch.float32)
+        nrm = torch.empty_like(kl)
+        call("mulan_topk_fwd", ptr(logits), ptr(gnoise), ptr(emb), ptr(kl), ptr(soft), ptr(nrm), B, L, int(k),
+             float(tau), stream())
+        ctx.save_for_backward(logits, soft, nrm)
+        return emb, kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, demb, dkl):
+        logits, soft, nrm = ctx.saved_tensors
+        B, L = logits.shape
+        demb = _c(demb) if demb is not None else torch.zeros_like(logits)
+        dkl = _c(dkl) if dkl is not None else torch.zeros(B, device=logits.device)
+        dl = torch.empty_like(logits)
+        call("mulan_topk_bwd", ptr(logits), ptr(soft), ptr(nrm), ptr(demb), ptr(dkl), ptr(dl), B, L, stream())
+        return dl, None, None, None
+
+
+def topk_embedding(logits, gnoise, k, tau=10.0):
+    return TopKFn.apply(logits, gnoise, k, tau)
+
+
+# ----------------------------------------------------------------------------- optimiser
+def adamw_ema_step(p, g, m, v, ema, n_decay, lr, b1, b2, eps, wd, step, ema_rate, grad_scale=1.0):
+    call("mulan_adamw_ema_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(lr),
+         float(b1), float(b2), float(eps), float(wd), int(step), float(ema_rate), float(grad_scale), stream())

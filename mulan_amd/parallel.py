@@ -1,0 +1,130 @@
+"""Data-parallel plumbing: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+Replaces jax.pmap + lax.pmean of the reference (ldm/experiment.py:89-95,341,347,365): parameters are
+replicated, the batch is sharded by rank, and the only data-path collective is the all-reduce of the
+flat gradient buffer.  The buffer is cut into buckets in the order gradients become ready during
+backward; each bucket is all-reduced on a side HIP stream as soon as its last gradient has landed, so
+the exchange overlaps the rest of the U-Net backward.  The 1/world_size factor is folded into the
+optimizer kernel (grad_scale).  Works unchanged with backend "gloo" on CPU tensors (tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialises torch.distributed from the torchrun environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class GradReducer:
+    """Bucketed, backward-overlapped sum all-reduce of a flat gradient buffer.
+
+    `leaves` is a list of (tensor, offset, numel) views of `flat_grad` (the tensors whose .grad are
+    those views).  Buckets are contiguous [lo, hi) ranges of the flat buffer; a bucket is launched
+    when all of its leaves have reported ready through their post-accumulate hook.
+    """
+
+    def __init__(self, flat_grad, leaves, bucket_bytes=64 << 20, process_group=None):
+        self.flat = flat_grad
+        self.pg = process_group
+        self.world = world_size()
+        self.enabled = self.world > 1
+        self.cuda = flat_grad.is_cuda
+        self.side = torch.cuda.Stream() if (self.cuda and self.enabled) else None
+        order = sorted(leaves, key=lambda l: l[1])
+        cap = max(1, bucket_bytes // 4)
+        self.buckets = []          # [lo, hi, n_leaves]
+        self.leaf_bucket = {}
+        lo = hi = None
+        cnt = 0
+        for t, off, n in order:
+            if lo is None:
+                lo, hi, cnt = off, off + n, 0
+            if off + n - lo > cap and cnt > 0:
+                self.buckets.append([lo, hi, cnt])
+                lo, hi, cnt = off, off + n, 0
+            hi = max(hi, off + n)
+            cnt += 1
+            self.leaf_bucket[id(t)] = len(self.buckets)
+        if lo is not None:
+            self.buckets.append([lo, hi, cnt])
+        # pad bucket ranges so they tile the whole flat buffer (alignment padding between leaves)
+        for i, b in enumerate(self.buckets):
+            b[1] = self.buckets[i + 1][0] if i + 1 < len(self.buckets) else flat_grad.numel()
+        if self.buckets:
+            self.buckets[0][0] = 0
+        self.pending = [0] * len(self.buckets)
+        self.works = []
+        self.launched = [False] * len(self.buckets)
+        if self.enabled:
+            for t, off, n in order:
+                t.register_post_accumulate_grad_hook(self._hook)
+
+    def prepare(self):
+        """Call before each backward."""
+        self.pending = [b[2] for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.works = []
+
+    def _launch(self, bi):
+        lo, hi, _ = self.buckets[bi]
+        view = self.flat[lo:hi]
+        self.launched[bi] = True
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _hook(self, t):
+        bi = self.leaf_bucket[id(t)]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0 and not self.launched[bi]:
+            self._launch(bi)
+
+    def finish(self):
+        """Launch whatever did not fire (unused leaves), then make the compute stream wait for all buckets."""
+        if not self.enabled:
+            return
+        for bi in range(len(self.buckets)):
+            if not self.launched[bi]:
+                self._launch(bi)
+        for w in self.works:
+            w.wait()
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.works = []
+
+
+def allreduce_mean_scalars(values, device):
+    """lax.pmean over a dict of python/0-d scalars (ldm/experiment.py:347-348,365-366)."""
+    if world_size() == 1:
+        return values
+    keys = sorted(values)
+    t = torch.stack([torch.as_tensor(values[k], dtype=torch.float32, device=device).reshape(()) for k in keys])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = t / world_size()
+    return {k: t[i] for i, k in enumerate(keys)}

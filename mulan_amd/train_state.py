@@ -1,0 +1,140 @@
+"""TrainState on flat fp32 device buffers (mirror of ldm/train_state.py:33-119).
+
+State = {step, params, ema_params, opt_state(mu, nu)}: every parameter leaf is a view into one
+contiguous buffer (weight-decayed leaves first, `bias` leaves last -- the reference's decay mask,
+ldm/experiment.py:139-146), so AdamW+EMA is one kernel launch (mulan_adamw_ema_step) and the
+data-parallel gradient exchange is a few large all-reduces over slices of one flat gradient buffer.
+"""
+import torch
+
+from . import ops
+from .model import tree_leaves, tree_set
+
+
+def _is_decayed(path):
+    """decay_mask_fn of ldm/experiment.py:139-146: everything except leaves named 'bias' (and the
+    never-occurring ('layer_norm'|'final_layer_norm', 'scale')) -- GroupNorm scales ARE decayed."""
+    return path[-1] != 'bias' and tuple(path[-2:]) not in (('layer_norm', 'scale'), ('final_layer_norm', 'scale'))
+
+
+class TrainState:
+    def __init__(self, apply_fn, template, device, optimizer_args=None):
+        self.apply_fn = apply_fn
+        leaves = list(tree_leaves(template))
+        for path, _ in leaves:   # same assertion as ldm/experiment.py:165,168
+            assert path[0] in {'encoder_model', 'score_model', 'gamma'}, path
+        decayed = [(p, v) for p, v in leaves if _is_decayed(p)]
+        plain = [(p, v) for p, v in leaves if not _is_decayed(p)]
+        self.layout = []   # (path, offset, shape)
+        off = 0
+        self.n_decay = 0
+        for i, (path, v) in enumerate(decayed + plain):
+            n = v.numel()
+            self.layout.append((path, off, tuple(v.shape)))
+            off += (n + 3) // 4 * 4          # 16-byte aligned leaves
+            if i == len(decayed) - 1:
+                self.n_decay = off
+        self.numel = off
+        self.device = device
+        self.flat = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros_like(self.flat)
+        self.ema = torch.zeros_like(self.flat)
+        self.mu = torch.zeros_like(self.flat)
+        self.nu = torch.zeros_like(self.flat)
+        self.step = 0
+        self.opt = dict(b1=0.9, b2=0.99, eps=1e-8, weight_decay=0.01)
+        if optimizer_args:
+            self.opt.update(optimizer_args)
+        self.params = self._views(self.flat, requires_grad=True)
+        with torch.no_grad():
+            for path, off_, shape in self.layout:
+                src = template
+                for k in path:
+                    src = src[k]
+                self.flat[off_:off_ + src.numel()].copy_(src.reshape(-1).to(device))
+        self.ema.copy_(self.flat)            # ema_params = deepcopy(params), ldm/train_state.py:110
+        self.ema_params = self._views(self.ema, requires_grad=False)
+        for (path, off_, shape), (_, leaf) in zip(self.layout, tree_leaves_in_layout(self.params, self.layout)):
+            n = leaf.numel()
+            leaf.grad = self.grad[off_:off_ + n].view(shape)
+
+    @classmethod
+    def create(cls, *, apply_fn, variables, device, optimizer_args=None):
+        return cls(apply_fn, variables["params"] if "params" in variables else variables, device, optimizer_args)
+
+    def _views(self, flat, requires_grad):
+        tree = {}
+        for path, off, shape in self.layout:
+            n = 1
+            for s in shape:
+                n *= s
+            v = flat[off:off + n].view(shape)
+            if requires_grad:
+                v = v.detach().requires_grad_(True)
+            d = tree
+            for k in path[:-1]:
+                d = d.setdefault(k, {})
+            d[path[-1]] = v
+        return tree
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0):
+        """TrainState.apply_gradients (ldm/train_state.py:70-102) on the flat gradient buffer."""
+        self.step += 1
+        o = self.opt
+        ops.adamw_ema_step(self.flat, self.grad, self.mu, self.nu, self.ema, self.n_decay, lr, o["b1"], o["b2"],
+                           o["eps"], o["weight_decay"], self.step, ema_rate, grad_scale)
+        return self
+
+    # -- checkpoint form: {step, params, ema_params, opt_state} (ldm/train_state.py:62-68)
+    def state_dict(self):
+        def tree_of(flat):
+            out = {}
+            for path, off, shape in self.layout:
+                n = 1
+                for s in shape:
+                    n *= s
+                d = out
+                for k in path[:-1]:
+                    d = d.setdefault(k, {})
+                d[path[-1]] = flat[off:off + n].view(shape).detach().cpu().clone()
+            return out
+        return {"step": self.step, "params": tree_of(self.flat), "ema_params": tree_of(self.ema),
+                "opt_state": {"mu": tree_of(self.mu), "nu": tree_of(self.nu)}}
+
+    def load_state_dict(self, sd, strict=True):
+        def load(flat, tree):
+            for path, off, shape in self.layout:
+                src = tree
+                try:
+                    for k in path:
+                        src = src[k]
+                except (KeyError, TypeError):
+                    if strict:
+                        raise KeyError("/".join(path))
+                    continue
+                src = torch.as_tensor(src, dtype=torch.float32)
+                if path[-2:] == ("conv_in", "kernel") and src.shape[2] == 15:
+                    src = torch.cat([src, torch.zeros(3, 3, 1, src.shape[3])], dim=2)
+                flat[off:off + src.numel()].copy_(src.reshape(-1).to(flat.device))
+        with torch.no_grad():
+            if "params" in sd:
+                load(self.flat, sd["params"])
+            if "ema_params" in sd:
+                load(self.ema, sd["ema_params"])
+            opt = sd.get("opt_state")
+            if isinstance(opt, dict) and "mu" in opt:
+                load(self.mu, opt["mu"])
+                load(self.nu, opt["nu"])
+            if "step" in sd:
+                self.step = int(sd["step"])
+
+
+def tree_leaves_in_layout(tree, layout):
+    for path, _, _ in layout:
+        v = tree
+        for k in path:
+            v = v[k]
+        yield path, v

@@ -1,0 +1,313 @@
+"""CPU ORACLE (test infrastructure only) -- torch restatement of the same path as oracle/mulan_np.py.
+
+PARITY UNPINNED (see oracle/mulan_np.py header).  Purpose: (1) float64 autograd gradients to check the
+hand-written HIP backward kernels, (2) the fp32 multi-threaded CPU "port" timed as `cpu_baseline` by
+bench.py.  Only tests/, __graft_entry__.smoke() and bench.py may import it; the product never does.
+
+Parameters are a Flax-layout tree: {'score_model': {...}, 'encoder_model': {...}, 'gamma': {...}} with
+leaves {'kernel': [..in, out], 'bias': [out]} / {'scale','bias'} exactly as the reference checkpoint stores
+them (ldm/experiment.py:165-168).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+GAMMA_MIN, GAMMA_MAX = -13.3, 5.0
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def dense(x, p):
+    y = x @ p["kernel"]
+    return y + p["bias"] if "bias" in p else y
+
+
+def conv3x3(x, p):
+    """flax nn.Conv((3,3)) SAME NHWC/HWIO (ldm/model_vdm.py:633-634)"""
+    w = p["kernel"].permute(3, 2, 0, 1)   # HWIO -> OIHW
+    y = F.conv2d(x.permute(0, 3, 1, 2), w, p.get("bias"), padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+def group_norm(x, p, groups=32, eps=1e-6):
+    """flax nn.GroupNorm() (ldm/model_vdm.py:622): fast variance, eps 1e-6"""
+    B, H, W, C = x.shape
+    xg = x.reshape(B, H * W, groups, C // groups)
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = torch.clamp((xg * xg).mean(dim=(1, 3), keepdim=True) - mean * mean, min=0.)
+    y = (xg - mean) * torch.rsqrt(var + eps)
+    return y.reshape(B, H, W, C) * p["scale"] + p["bias"]
+
+
+def timestep_embedding(t, dim):
+    """ldm/model_vdm.py:391-413"""
+    half = dim // 2
+    w = torch.exp(torch.arange(half, dtype=t.dtype) * (-(math.log(10000) / (half - 1))))
+    e = (t * 1000.)[:, None] * w[None, :]
+    return torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+
+
+def fourier_features(z):
+    """ldm/model_vdm.py:812-829 (start=6, stop=8)"""
+    w = (2. ** torch.tensor([6., 7.], dtype=z.dtype)) * 2 * math.pi
+    w = w.repeat(z.shape[-1])
+    h = torch.repeat_interleave(z, 2, dim=-1) * w
+    return torch.cat([torch.sin(h), torch.cos(h)], dim=-1)
+
+
+def attn_block(x, p):
+    """ldm/model_vdm.py:660-701"""
+    B, H, W, C = x.shape
+    h = group_norm(x, p["GroupNorm_0"])
+    q, k, v = (dense(h, p[n]).reshape(B, H * W, C) for n in ("q", "k", "v"))
+    wgt = torch.softmax(torch.einsum("bqc,bkc->bqk", q / math.sqrt(C), k), dim=-1)
+    o = torch.einsum("bqk,bkc->bqc", wgt, v).reshape(B, H, W, C)
+    return x + dense(o, p["proj_out"])
+
+
+def resnet_block(x, cond, p, keep_mask=None, keep=1.0):
+    """ldm/model_vdm.py:610-657; ldm/ldm_unet.py:10-61"""
+    h = conv3x3(swish(group_norm(x, p["GroupNorm_0"])), p["conv1"])
+    cb = cond @ p["cond_proj"]["kernel"]
+    h = h + (cb[:, None, None, :] if cb.dim() == 2 else cb)
+    h = swish(group_norm(h, p["GroupNorm_1"]))
+    if keep_mask is not None:
+        h = torch.where(keep_mask, h / keep, torch.zeros_like(h))
+    h = conv3x3(h, p["conv2"])
+    if "nin_shortcut" in p:
+        x = dense(x, p["nin_shortcut"])
+    return x + h
+
+
+def unet_stem(z, t, conditioning, p, n_embd, n_layers, per_pixel=False, masks=None, keep=1.0):
+    B = z.shape[0]
+    masks = masks or {}
+    if per_pixel:
+        temb = timestep_embedding(t.reshape(-1), n_embd).reshape(B, 32, 32, 3 * n_embd)
+        cnd = conditioning[:, None, None, :].expand(B, 32, 32, conditioning.shape[1])
+        cond = torch.cat([temb, cnd], dim=-1)
+    else:
+        cond = torch.cat([timestep_embedding(t, n_embd), conditioning], dim=1)
+    cond = swish(dense(cond, p["dense0"]))
+    cond = swish(dense(cond, p["dense1"]))
+    h = conv3x3(torch.cat([z, fourier_features(z)], dim=-1), p["conv_in"])
+    hs = [h]
+    for i in range(n_layers):
+        n = f"down.block_{i}"
+        h = resnet_block(hs[-1], cond, p[n], masks.get(n), keep)
+        hs.append(h)
+    h = resnet_block(hs[-1], cond, p["mid.block_1"], masks.get("mid.block_1"), keep)
+    h = attn_block(h, p["mid.attn_1"])
+    h = resnet_block(h, cond, p["mid.block_2"], masks.get("mid.block_2"), keep)
+    return h, hs, cond
+
+
+def score_unet(z, g_t, conditioning, p, n_embd, n_layers, per_pixel=False, gmin=GAMMA_MIN, gmax=GAMMA_MAX,
+               masks=None, keep=1.0):
+    """ldm/model_vdm.py:314-388; ldm/ldm_unet.py:69-142"""
+    masks = masks or {}
+    t = (g_t - gmin) / (gmax - gmin)
+    h, hs, cond = unet_stem(z, t, conditioning, p, n_embd, n_layers, per_pixel, masks, keep)
+    for i in range(n_layers + 1):
+        n = f"up.block_{i}"
+        h = resnet_block(torch.cat([h, hs.pop()], dim=-1), cond, p[n], masks.get(n), keep)
+    h = swish(group_norm(h, p["GroupNorm_0"]))
+    return conv3x3(h, p["conv_out"]) + z
+
+
+def unet_encoder(f, p, n_embd, n_layers, masks=None, keep=1.0):
+    """ldm/model_mulan_epsilon.py:101-154"""
+    B = f.shape[0]
+    h, _, _ = unet_stem(f, torch.zeros(B, dtype=f.dtype), torch.zeros(B, 1, dtype=f.dtype), p, n_embd, n_layers,
+                        False, masks, keep)
+    h = conv3x3(swish(group_norm(h, p["GroupNorm_0"])), p["conv_out"])
+    return dense(swish(h.reshape(B, -1)), p["dense_layer_final"])
+
+
+def encode(x):
+    """ldm/model_vdm.py:274-280"""
+    return 2 * ((torch.round(x) + .5) / 256) - 1
+
+
+def logprob(x_int, z, g_0):
+    """ldm/model_vdm.py:282-303"""
+    vals = encode(torch.arange(256, dtype=z.dtype))
+    logits = -0.5 * torch.square((z[..., None] - vals) * torch.exp(-0.5 * g_0)[..., None])
+    lp = torch.log_softmax(logits, dim=-1)
+    sel = torch.gather(lp, -1, x_int[..., None].long())[..., 0]
+    return sel.reshape(sel.shape[0], -1).sum(dim=1)
+
+
+def poly_coefficients(emb, p):
+    """ldm/model_mulan_epsilon.py:531-538"""
+    h = swish(dense(emb, p["dense_1"]))
+    h = swish(dense(h, p["dense_2"]))
+    return dense(h, p["dense_out_a"]), dense(h, p["dense_out_b"]), 1e-3 + F.softplus(dense(h, p["dense_out_c"]))
+
+
+def poly_gamma(a, b, c, t, gmin=GAMMA_MIN, gmax=GAMMA_MAX):
+    """ldm/model_mulan_epsilon.py:514-529"""
+    t = t.reshape(-1, 1)
+    poly = (a ** 2) * t ** 5 / 5.0 + (b ** 2 + 2 * a * c) * t ** 3 / 3.0 + a * b * t ** 4 / 2.0 + b * c * t ** 2 + c ** 2 * t
+    scale = (a ** 2) / 5.0 + (b ** 2 + 2 * a * c) / 3.0 + a * b / 2.0 + b * c + c ** 2
+    return gmin + (gmax - gmin) * poly / scale
+
+
+def poly_gamma_grad_t(a, b, c, t, gmin=GAMMA_MIN, gmax=GAMMA_MAX):
+    """ldm/model_mulan_epsilon.py:540-555"""
+    t = t.reshape(-1, 1)
+    poly = (a ** 2) * t ** 4 + (b ** 2 + 2 * a * c) * t ** 2 + a * b * t ** 3 * 2.0 + b * c * t * 2 + c ** 2
+    scale = (a ** 2) / 5.0 + (b ** 2 + 2 * a * c) / 3.0 + a * b / 2.0 + b * c + c ** 2
+    return (gmax - gmin) * poly / scale
+
+
+def topk_embedding_and_loss(logits, raw_gamma, k, tau=10.0):
+    """ldm/model_mulan_velocity.py:78-120"""
+    L = logits.shape[1]
+    q = torch.softmax(logits, dim=1)
+    kl = torch.sum(q * (torch.log_softmax(logits, dim=1) - math.log(1.0 / L)), dim=1)
+    beta = k / torch.arange(1., 11., dtype=logits.dtype)
+    s = (raw_gamma / beta[:, None, None]).sum(dim=0) - math.log(10.0)
+    l = logits + tau * (s / k)
+    l = l - l.mean(dim=1, keepdim=True)
+    soft = l / torch.linalg.norm(l, dim=1, keepdim=True)
+    thr = torch.topk(l, k, dim=1).values[:, -1]
+    hard = (l >= thr[:, None]).to(l.dtype)
+    return (hard - soft).detach() + soft, kl
+
+
+def mulan_forward(params, cfg, x_u8, t0, raw_gamma, eps_0, eps, enc_masks=None, score_masks=None, keep=1.0,
+                  dtype=torch.float64):
+    """VDM.__call__ (ldm/model_mulan_velocity.py:188-268, ldm/model_mulan_epsilon.py:280-363, T = 0) +
+    Experiment_VDM.loss_fn BPD (ldm/experiment_vdm.py:62-66)."""
+    B = x_u8.shape[0]
+    x = x_u8.reshape(B, 32, 32, 3)
+    t = torch.remainder(t0 + torch.arange(B, dtype=dtype) / B, 1.)
+    f = encode(x.to(dtype))
+    logits = unet_encoder(f, params["encoder_model"], cfg["n_embd"], cfg["forward_n_layer"], enc_masks, keep)
+    emb, kl_z = topk_embedding_and_loss(logits, raw_gamma, cfg["latent_k"])
+    a, b, c = poly_coefficients(emb, params["gamma"])
+    shp = f.shape
+    g_0 = poly_gamma(a, b, c, torch.zeros(B, dtype=dtype)).reshape(shp)
+    g_1 = poly_gamma(a, b, c, torch.ones(B, dtype=dtype)).reshape(shp)
+    g_t = poly_gamma(a, b, c, t).reshape(shp)
+    g_p = poly_gamma_grad_t(a, b, c, t).reshape(shp)
+    var_t, var_0, var_1 = torch.sigmoid(g_t), torch.sigmoid(g_0), torch.sigmoid(g_1)
+    z_0 = f + torch.exp(0.5 * g_0) * eps_0
+    loss_recon = -logprob(x, z_0, g_0)
+    loss_klz = 0.5 * ((1. - var_1) * f * f + var_1 - torch.log(var_1) - 1.).reshape(B, -1).sum(dim=1)
+    z_t = torch.sqrt(1. - var_t) * f + torch.sqrt(var_t) * eps
+    per_pixel = cfg.get("unet_type", "vdm") == "ldm"
+    g_in = g_t if per_pixel else g_t.reshape(B, -1).mean(dim=1)
+    net = score_unet(z_t, g_in, emb, params["score_model"], cfg["n_embd"], cfg["n_layer"], per_pixel,
+                     masks=score_masks, keep=keep)
+    if cfg["vdm_type"] == "mulan_velocity":
+        v_hat = net
+        if cfg.get("velocity_from_epsilon", False):
+            v_hat = -torch.exp(0.5 * g_t) * z_t + torch.sqrt(1 + torch.exp(g_t)) * net
+        v_target = torch.sqrt(1. - var_t) * eps - torch.sqrt(var_t) * f
+        loss_diff = .5 * ((1 - var_t) * g_p * (v_target - v_hat) ** 2).reshape(B, -1).sum(dim=1)
+    else:
+        loss_diff = .5 * (g_p * (eps - net) ** 2).reshape(B, -1).sum(dim=1)
+    klz = kl_z + loss_klz
+    r = 1. / (3072 * math.log(2.))
+    return dict(loss_recon=loss_recon, loss_klz=klz, loss_diff=loss_diff, var_0=var_0.mean(), var_1=var_1.mean(),
+                bpd=(loss_recon.mean() + klz.mean() + loss_diff.mean()) * r,
+                aux=dict(logits=logits, emb=emb, z_t=z_t, net=net, g_t=g_t, g_p=g_p))
+
+
+# ------------------------------------------------------------------------------ parameter trees
+def tree_map(fn, tree):
+    return {k: tree_map(fn, v) if isinstance(v, dict) else fn(v) for k, v in tree.items()}
+
+
+def tree_leaves(tree, prefix=()):
+    for k, v in tree.items():
+        if isinstance(v, dict):
+            yield from tree_leaves(v, prefix + (k,))
+        else:
+            yield prefix + (k,), v
+
+
+def to_np_tuples(tree):
+    """Flax-layout tree -> the tuple layout oracle/mulan_np.py consumes."""
+    import numpy as np
+    out = {}
+    for k, v in tree.items():
+        if isinstance(v, dict) and all(not isinstance(x, dict) for x in v.values()):
+            g = lambda a: np.asarray(a.detach().cpu().double().numpy() if torch.is_tensor(a) else a, dtype=np.float64)
+            if "scale" in v:
+                out[k] = (g(v["scale"]), g(v["bias"]))
+            else:
+                out[k] = (g(v["kernel"]), g(v["bias"]) if "bias" in v else 0.0)
+        else:
+            out[k] = to_np_tuples(v)
+    return out
+
+
+def init_params(cfg, seed=0, dtype=torch.float64, zero_init=False, latent=50):
+    """Random Flax-layout parameter tree for a (small) config.  With zero_init=False the tensors the
+    reference zero-initialises (conv2, cond_proj, proj_out, conv_out, dense_out_a) get small random
+    values instead, so every gradient path is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    E = cfg["n_embd"]
+
+    def rnd(*shape, scale=None):
+        fan_in = shape[-2] if len(shape) > 1 else shape[0]
+        if len(shape) == 4:
+            fan_in = shape[0] * shape[1] * shape[2]
+        s = scale if scale is not None else 1.0 / math.sqrt(fan_in)
+        return (torch.randn(*shape, generator=g, dtype=torch.float64) * s).to(dtype)
+
+    def z_or_r(*shape, scale=None):
+        return torch.zeros(*shape, dtype=dtype) if zero_init else rnd(*shape, scale=scale)
+
+    def gn(C):
+        return {"scale": (1.0 + 0.1 * torch.randn(C, generator=g, dtype=torch.float64)).to(dtype),
+                "bias": rnd(C, scale=0.1)}
+
+    def block(cin, cout, cond_dim):
+        p = {"GroupNorm_0": gn(cin), "conv1": {"kernel": rnd(3, 3, cin, cout), "bias": rnd(cout, scale=0.1)},
+             "cond_proj": {"kernel": z_or_r(cond_dim, cout)}, "GroupNorm_1": gn(cout),
+             "conv2": {"kernel": z_or_r(3, 3, cout, cout), "bias": rnd(cout, scale=0.1)}}
+        if cin != cout:
+            p["nin_shortcut"] = {"kernel": rnd(cin, cout), "bias": rnd(cout, scale=0.1)}
+        return p
+
+    def attn(C):
+        p = {"GroupNorm_0": gn(C)}
+        for n in ("q", "k", "v"):
+            p[n] = {"kernel": rnd(C, C), "bias": rnd(C, scale=0.1)}
+        p["proj_out"] = {"kernel": z_or_r(C, C), "bias": rnd(C, scale=0.1)}
+        return p
+
+    def unet(n_layers, K, out_ch, with_up, temb_dim):
+        p = {"dense0": {"kernel": rnd(temb_dim + K, 4 * E), "bias": rnd(4 * E, scale=0.1)},
+             "dense1": {"kernel": rnd(4 * E, 4 * E), "bias": rnd(4 * E, scale=0.1)},
+             "conv_in": {"kernel": rnd(3, 3, 15, E), "bias": rnd(E, scale=0.1)}}
+        for i in range(n_layers):
+            p[f"down.block_{i}"] = block(E, E, 4 * E)
+        p["mid.block_1"] = block(E, E, 4 * E)
+        p["mid.attn_1"] = attn(E)
+        p["mid.block_2"] = block(E, E, 4 * E)
+        if with_up:
+            for i in range(n_layers + 1):
+                p[f"up.block_{i}"] = block(2 * E, E, 4 * E)
+        p["GroupNorm_0"] = gn(E)
+        p["conv_out"] = {"kernel": z_or_r(3, 3, E, out_ch), "bias": rnd(out_ch, scale=0.1)}
+        return p
+
+    per_pixel = cfg.get("unet_type", "vdm") == "ldm"
+    score = unet(cfg["n_layer"], latent, 3, True, 3 * E if per_pixel else E)
+    enc = unet(cfg["forward_n_layer"], 1, 1, False, E)
+    enc["dense_layer_final"] = {"kernel": rnd(1024, latent), "bias": rnd(latent, scale=0.1)}
+    Dm = 3072
+    gamma = {"dense_1": {"kernel": rnd(latent, Dm), "bias": rnd(Dm, scale=0.1)},
+             "dense_2": {"kernel": rnd(Dm, Dm), "bias": rnd(Dm, scale=0.1)},
+             "dense_out_a": {"kernel": z_or_r(Dm, Dm), "bias": z_or_r(Dm, scale=0.1)},
+             "dense_out_b": {"kernel": rnd(Dm, Dm), "bias": rnd(Dm, scale=0.1)},
+             "dense_out_c": {"kernel": rnd(Dm, Dm), "bias": rnd(Dm, scale=0.1)}}
+    return {"score_model": score, "encoder_model": enc, "gamma": gamma}

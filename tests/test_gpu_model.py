@@ -1,0 +1,165 @@
+"""End-to-end parity of the HIP model (through mulan_amd.model / the C ABI) with the float64 oracle:
+forward ELBO terms and every parameter gradient of one MuLAN step, with identical explicit noise and
+the oracle reproducing the kernel's Philox dropout masks."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mulan_np as onp
+from oracle import torch_ref as tr
+
+
+def make_cfg(vdm_type="mulan_velocity", unet_type="vdm", vfe=False, n_layer=1, fwd_layers=1, E=128):
+    from mulan_amd.model import VDMConfig
+    return VDMConfig(vocab_size=256, sample_softmax=False, antithetic_time_sampling=True, with_fourier_features=True,
+                     with_attention=False, gamma_type='poly_fixedend', gamma_min=-13.3, gamma_max=5.0,
+                     sm_n_timesteps=0, sm_n_embd=E, sm_n_layer=n_layer, sm_pdrop=0.1, forward_n_layer=fwd_layers,
+                     latent_size=50, latent_k=15, encoder='unet', latent_type='topk', z_conditioning=True,
+                     reparam_type='true', unet_type=unet_type, velocity_from_epsilon=vfe, condition='input',
+                     sigma_type='no_blur', sigma_prior=1.0), dict(
+        vdm_type=vdm_type, n_embd=E, n_layer=n_layer, forward_n_layer=fwd_layers, latent_k=15, unet_type=unet_type,
+        velocity_from_epsilon=vfe)
+
+
+def oracle_masks(names, key, B, C, keep):
+    masks = {}
+    for site, name in enumerate(names, start=1):
+        masks[name] = torch.tensor(onp.dropout_mask((B, 32, 32, C), keep, key.v, site << 34))
+    return masks
+
+
+def block_names(n_down, with_up):
+    names = [f"down.block_{i}" for i in range(n_down)] + ["mid.block_1", "mid.block_2"]
+    if with_up:
+        names += [f"up.block_{i}" for i in range(n_down + 1)]
+    return names
+
+
+def to_device_tree(flax_tree, like):
+    from mulan_amd import model as M
+    return M.from_flax_layout(flax_tree, like)
+
+
+def run_case(vdm_type, unet_type, vfe, train):
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe)
+    B = 4
+    rng = np.random.default_rng(17)
+    ref_params = tr.init_params(ocfg, seed=3, dtype=torch.float64)
+    for _, leaf in tr.tree_leaves(ref_params):
+        leaf.requires_grad_(True)
+    vdm = M.make_vdm(vdm_type, cfg)
+    tmpl = vdm.init(PRNGKey(0))
+    params = M.tree_map(lambda t: t.cuda(), tmpl)
+    to_device_tree(M.tree_map(lambda t: t.detach().float(), ref_params), params)
+    for _, leaf in M.tree_leaves(params):
+        leaf.requires_grad_(True)
+
+    x = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    raw = rng.gamma(1.0 / 15, size=(10, B, 50))
+    e0, e = rng.standard_normal((B, 3072)), rng.standard_normal((B, 3072))
+    t0 = 0.37
+    noise = dict(t0=t0, gamma_raw=torch.tensor(raw, dtype=torch.float32).cuda(),
+                 eps_0=torch.tensor(e0, dtype=torch.float32).cuda(), eps=torch.tensor(e, dtype=torch.float32).cuda())
+    keep = 1.0
+    enc_masks = score_masks = None
+    rngs = None
+    if train:
+        keep = float(np.float32(0.9))
+        dkey = PRNGKey(99)
+        k_enc, k_score = dkey.split(2)
+        enc_masks = oracle_masks(block_names(1, False), k_enc, B, 128, 0.9)
+        score_masks = oracle_masks(block_names(1, True), k_score, B, 128, 0.9)
+        rngs = {"dropout": dkey}
+    ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), t0, torch.tensor(raw),
+                           torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3),
+                           enc_masks=enc_masks, score_masks=score_masks, keep=keep)
+    out, aux = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs=rngs, deterministic=not train,
+                         noise=noise, return_aux=True)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+    # same hard top-k latent, same z_t
+    assert np.array_equal(np.round(aux["emb"].detach().cpu().numpy()), np.round(ref["aux"]["emb"].detach().numpy()))
+    assert rel(aux["zt"].detach().cpu().numpy(), ref["aux"]["z_t"].detach().numpy().reshape(B, -1)) < 1e-5
+    assert rel(aux["net"].detach().cpu().numpy(), ref["aux"]["net"].detach().numpy().reshape(B, -1)) < 2e-4
+    assert rel(out.loss_recon.detach().cpu().numpy(), ref["loss_recon"].detach().numpy()) < 1e-5
+    assert rel(out.loss_klz.detach().cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-5
+    assert rel(out.loss_diff.detach().cpu().numpy(), ref["loss_diff"].detach().numpy()) < 5e-4
+    r = 1.0 / (3072 * np.log(2.0))
+    bpd = (out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) * r
+    # BPD tolerance: 1e-3 relative here (the north-star bar is +-0.005 absolute on BPD ~ 2.5-3.7)
+    assert abs(float(bpd) - float(ref["bpd"])) < 1e-3 * abs(float(ref["bpd"]))
+    if not train:
+        return
+    ref["bpd"].backward()
+    bpd.backward()
+    flax_grads = M.to_flax_layout(M.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), params))
+    worst = []
+    for path, leaf in tr.tree_leaves(ref_params):
+        g = flax_grads
+        for k in path:
+            g = g[k]
+        rg = leaf.grad.numpy() if leaf.grad is not None else np.zeros(tuple(leaf.shape))
+        scale = np.abs(rg).max()
+        err = np.abs(g.cpu().double().numpy() - rg).max()
+        worst.append((err / (scale + 1e-12) if scale > 1e-12 else err, "/".join(path)))
+    worst.sort(reverse=True)
+    # fp32 end-to-end through ~40 kernels vs float64: 2e-3 of each leaf's gradient scale
+    assert worst[0][0] < 2e-3, worst[:8]
+
+
+@pytest.mark.parametrize("vdm_type,unet_type,vfe", [("mulan_velocity", "vdm", False), ("mulan_velocity", "vdm", True),
+                                                    ("mulan_epsilon", "vdm", False), ("mulan_velocity", "ldm", False)])
+def test_mulan_forward_eval(vdm_type, unet_type, vfe):
+    run_case(vdm_type, unet_type, vfe, train=False)
+
+
+@pytest.mark.parametrize("vdm_type,unet_type,vfe", [("mulan_velocity", "vdm", False), ("mulan_epsilon", "vdm", False),
+                                                    ("mulan_velocity", "vdm", True), ("mulan_velocity", "ldm", False)])
+def test_mulan_train_gradients(vdm_type, unet_type, vfe):
+    run_case(vdm_type, unet_type, vfe, train=True)
+
+
+def test_zero_init_network_is_identity():
+    """with the reference's zero-initialised conv2/cond_proj/proj_out/conv_out the score model
+    returns z exactly (ldm/model_vdm.py:378-386)."""
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, _ = make_cfg()
+    vdm = M.make_vdm("mulan_velocity", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(1)))
+    z = torch.randn(2, 1024, 3).cuda()
+    out = M.score_unet(params["score_model"], cfg, z, torch.tensor([0.5, -3.0]).cuda(), torch.randn(2, 50).cuda(),
+                       M._Drop(None, 0.0))
+    assert torch.equal(out, z)
+
+
+def test_train_steps_reduce_loss_and_ema():
+    """3 optimiser steps through Experiment_VDM.train_step on a fixed synthetic batch: finite loss that goes
+    down, step counter, EMA lagging the parameters."""
+    import os
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+    config.data.dataset = 'synthetic'
+    config.model.sm_n_layer = 1
+    config.model.forward_n_layer = 1
+    config.training.batch_size_train = 4
+    config.training.batch_size_eval = 4
+    config.training.substeps = 1
+    config.training.num_steps_lr_warmup = 1
+    exp = Experiment_VDM(config)
+    batch = next(exp.train_iter)
+    sub = {k: v[0] for k, v in batch.items()}
+    losses = []
+    for _ in range(3):
+        exp.state, m = exp.train_step(exp._train_rng.fold_in(0), exp.state, sub)
+        losses.append(float(m['scalars']['train_bpd']))
+    assert all(np.isfinite(losses)), losses
+    assert exp.state.step == 3
+    assert not torch.equal(exp.state.flat, exp.state.ema)
+    m = exp.eval_step(exp._eval_rng, exp.state.ema_params, sub, 0)
+    assert np.isfinite(float(m['scalars']['eval_bpd']))
