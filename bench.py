@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""MuLAN training-throughput bench on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full train step of the hot path (forward ELBO + backward + RCCL gradient all-reduce + AdamW/EMA)
+on one synthetic CIFAR-shaped uint8 batch that is already resident in HBM.  Workload at every N: BASELINE.json
+configs[1] -- MuLAN-epsilon, ldm/configs/cifar10-conditioned.py (E=128, 32+2+33 ResBlocks), batch 128 per GPU
+(weak scaling: global batch 128*N), fp32 (the reference forces fp32 matmuls, ldm/main.py:39).
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel: the 3x3-conv implicit GEMM) and
+`cpu_baseline` (oracle port on the host cores, bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+FWD_GFLOP_PER_IMAGE = 57.78           # score 53.37 + encoder 4.33 + gamma 0.076 (CIFAR config)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--per-gpu-batch", type=int, default=128)
+    ap.add_argument("--vdm-type", default="mulan_epsilon")
+    ap.add_argument("--config", default=os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC pass")
+    ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg_path, vdm_type, batch, steps):
+    """The oracle's torch port of the same train step (fwd + bwd + AdamW) in fp32 on all host cores."""
+    import numpy as np
+    import torch
+    from mulan_amd.config import load_config_file
+    from oracle import torch_ref as tr
+    config = load_config_file(cfg_path)
+    m = config.model
+    ocfg = dict(vdm_type=vdm_type, n_embd=m.sm_n_embd, n_layer=m.sm_n_layer, forward_n_layer=m.forward_n_layer,
+                latent_k=m.get("latent_k", 15), unet_type=m.unet_type)
+    try:
+        cores = len(os.sched_getaffinity(0))      # cores this job may actually use (cgroup/affinity aware)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("MULAN_CPU_THREADS", "64"))))
+    torch.set_num_threads(cores)
+    params = tr.init_params(ocfg, seed=0, dtype=torch.float32)
+    leaves = [l.requires_grad_(True) for _, l in tr.tree_leaves(params)]
+    opt = torch.optim.AdamW(leaves, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    rng = np.random.default_rng(0)
+    keep = float(np.float32(1.0 - m.sm_pdrop))
+
+    def masks(names):
+        return {n: torch.from_numpy(rng.random((batch, 32, 32, m.sm_n_embd)) < keep) for n in names}
+    enc_names = [f"down.block_{i}" for i in range(m.forward_n_layer)] + ["mid.block_1", "mid.block_2"]
+    sc_names = ([f"down.block_{i}" for i in range(m.sm_n_layer)] + ["mid.block_1", "mid.block_2"]
+                + [f"up.block_{i}" for i in range(m.sm_n_layer + 1)])
+
+    def step():
+        x = torch.from_numpy(rng.integers(0, 256, (batch, 32, 32, 3)).astype(np.uint8))
+        raw = torch.from_numpy(rng.gamma(1.0 / 15, size=(10, batch, 50)).astype(np.float32))
+        e0 = torch.from_numpy(rng.standard_normal((batch, 32, 32, 3)).astype(np.float32))
+        e = torch.from_numpy(rng.standard_normal((batch, 32, 32, 3)).astype(np.float32))
+        out = tr.mulan_forward(params, ocfg, x, float(rng.random()), raw, e0, e, enc_masks=masks(enc_names),
+                               score_masks=masks(sc_names), keep=keep, dtype=torch.float32)
+        opt.zero_grad(set_to_none=True)
+        out["bpd"].backward()
+        opt.step()
+    step()                                   # untimed warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps (fwd+bwd+AdamW) of batch {batch}, full {vdm_type} CIFAR config, fp32, "
+                      f"oracle/torch_ref.py on {cores} threads"}
+
+
+def main():
+    a = parse()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(a.config, a.vdm_type, a.cpu_batch, a.cpu_steps)), flush=True)
+        return
+    import torch
+    import torch.distributed as dist
+    from mulan_amd import ops, parallel
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+
+    rank, world, local = parallel.init_distributed()
+    if world != a.gpus:
+        if a.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    config = load_config_file(a.config)
+    config.vdm_type = a.vdm_type
+    config.data.dataset = "synthetic"
+    config.training.batch_size_train = a.per_gpu_batch * world
+    config.training.batch_size_eval = a.per_gpu_batch * world
+    config.training.substeps = 1
+    exp = Experiment_VDM(config)
+    dev = exp.device
+    B = a.per_gpu_batch
+
+    g = torch.Generator().manual_seed(rank)
+    nb = a.steps + a.warmup
+    batches = [{"images": torch.randint(0, 256, (B, 32, 32, 3), generator=g, dtype=torch.uint8).to(dev),
+                "labels": torch.zeros(B, dtype=torch.int32, device=dev),
+                "conditioning": torch.zeros(B, dtype=torch.uint8, device=dev)} for _ in range(nb)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    state = exp.state
+    for i in range(a.warmup):
+        state, _ = exp.train_step(exp._train_rng, state, batches[i])
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        state, m = exp.train_step(exp._train_rng, state, batches[a.warmup + i])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    last_bpd = float(m["scalars"]["train_bpd"])
+
+    # ---- dominant-kernel timing: HIP events around every conv3x3 implicit-GEMM launch of one more step
+    roof = None
+    if rank == 0:
+        ops.KERNEL_TIMER = []
+        state, _ = exp.train_step(exp._train_rng, state, batches[-1])
+        torch.cuda.synchronize()
+        recs = ops.KERNEL_TIMER
+        ops.KERNEL_TIMER = None
+        sel = [(s.elapsed_time(e) * 1e-3, fl) for (name, s, e, fl) in recs if name == "conv3x3_fwd_kernel<128,2,2>"]
+        if sel:
+            tot_t = sum(t for t, _ in sel)
+            tot_f = sum(f for _, f in sel)
+            ach = tot_f / tot_t / 1e12
+            roof = {"bound": "mfma", "kernel": "conv3x3_fwd_kernel<128,2,2>", "achieved": round(ach, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": a.traffic, "launches_per_step": len(sel),
+                    "avg_launch_us": round(tot_t / len(sel) * 1e6, 1),
+                    "avg_gflop_per_launch": round(tot_f / len(sel) / 1e9, 3),
+                    "share_of_step": round(tot_t / (elapsed / a.steps), 3)}
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+        return
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:
+        # host leg in a child process (no GPU touched there) with a hard wall-clock bound
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", a.config, "--vdm-type",
+               a.vdm_type, "--cpu-batch", str(a.cpu_batch), "--cpu-steps", str(a.cpu_steps)]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=a.cpu_timeout,
+                               env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            cpu = json.loads(line[-1]) if line else {"value": None, "error": (r.stderr or "no output")[-300:]}
+        except subprocess.TimeoutExpired:
+            cpu = {"value": None, "error": f"cpu baseline exceeded {a.cpu_timeout}s"}
+    ms = elapsed / a.steps * 1e3
+    value = B * world * a.steps / elapsed
+    out = {
+        "metric": "train images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"MuLAN ({a.vdm_type}) CIFAR-10 config ldm/configs/cifar10-conditioned.py, full train "
+                               f"step (fwd+bwd+all-reduce+AdamW/EMA), batch {B}/GPU",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
+        "model_tflops_per_gpu": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3, 2),
+        "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+        "last_train_bpd": round(last_bpd, 4),
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,8 +55,10 @@ int mulan_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* works
  * (model_mulan_epsilon.py:153-154).  transA: A stored [K][lda]; transB: B stored [N][ldb]. */
 int mulan_gemm(const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N, int K,
                int lda, int ldb, int ldc, int ldr, int transA, int transB, int batch, long long strideA,
-               long long strideB, long long strideC, long long strideR, float alpha, float beta,
+               long long strideB, long long strideC, long long strideR, float alpha, float beta, float* workspace,
                mulan_stream_t stream);
+/* bytes of split-K workspace mulan_gemm can use for this shape (0: none needed; workspace may be NULL) */
+size_t mulan_gemm_workspace(int M, int N, int K, int batch);
 
 /* ---- GroupNorm (+SiLU) (+dropout), input = virtual channel concat [x1|x2] --------------------
  * nn.GroupNorm() + nn.swish + nn.Dropout in ResnetBlock (model_vdm.py:622-623,632,643-644), final

@@ -42,6 +42,48 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// Same reduction for C % 4 == 0 and 16-byte aligned rows: block = 16 row-lanes x 16 float4 columns,
+// 8 independent 16-byte loads in flight per thread.
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int seg,
+                                                         int C, int ld, int accumulate) {
+  __shared__ f32x4 red[256];
+  const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.y * 64 + cq * 4;
+  const int s = blockIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (col < C) {
+    const float* base = x + (size_t)s * seg * ld + col;
+    int r = rl;
+    for (; r + 7 * 16 < seg; r += 8 * 16) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(base + (size_t)(r + u * 16) * ld);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+    }
+    for (; r < seg; r += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)r * ld);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    if (rl < o) {
+      const f32x4 a = red[threadIdx.x], b = red[threadIdx.x + o * 16];
+      red[threadIdx.x] = f32x4{a[0] + b[0], a[1] + b[1], a[2] + b[2], a[3] + b[3]};
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && col < C) {
+    f32x4 v = red[threadIdx.x];
+    float* o = out + (size_t)s * C + col;
+    if (accumulate) { v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
 // y[row] = softmax(x[row]) over `cols` (<= 4096, multiple of 4); one 256-thread block per row.
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int cols) {
   __shared__ float red[4];
@@ -224,7 +266,13 @@ MULAN_API int mulan_act_bwd(const float* x, const float* dy, float* dx, size_t n
 MULAN_API int mulan_colsum(const float* x, float* out, int nseg, int seg, int C, int ld, int accumulate,
                            hipStream_t stream) {
   if (nseg <= 0 || seg <= 0 || C <= 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(colsum_kernel, dim3(nseg, (C + 63) / 64), dim3(256), 0, stream, x, out, seg, C, ld, accumulate);
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(colsum_vec_kernel, dim3(nseg, (C + 63) / 64), dim3(256), 0, stream, x, out, seg, C, ld,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(colsum_kernel, dim3(nseg, (C + 63) / 64), dim3(256), 0, stream, x, out, seg, C, ld, accumulate);
   MULAN_CHECK_LAUNCH();
 }
 MULAN_API int mulan_softmax_fwd(const float* x, float* y, size_t rows, int cols, hipStream_t stream) {

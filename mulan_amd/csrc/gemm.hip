@@ -23,6 +23,8 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc, ldr;
   long long sA, sB, sC, sR;   // batch strides (elements)
   float alpha, beta;
+  int ksplit, kchunk;         // split-K (batch == 1): blockIdx.z owns k in [z*kchunk, (z+1)*kchunk)
+  float* ws;                  // [ksplit][M][N] raw partial products
 };
 
 template <int BM, int BN, int WM, int WN, int TA, int TB, int VEC>
@@ -35,9 +37,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, bz = blockIdx.z;
-  const float* A = p.A + (size_t)bz * p.sA;
-  const float* B = p.B + (size_t)bz * p.sB;
-  const int M = p.M, N = p.N, K = p.K;
+  const bool split = p.ksplit > 1;
+  const float* A = p.A + (split ? 0 : (size_t)bz * p.sA);
+  const float* B = p.B + (split ? 0 : (size_t)bz * p.sB);
+  const int M = p.M, N = p.N;
+  const int kbeg = split ? bz * p.kchunk : 0;
+  const int K = split ? min(p.K, kbeg + p.kchunk) : p.K;   // exclusive upper bound of this block's k range
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -107,11 +112,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
   };
 
-  const int nk = (K + KC - 1) / KC;
+  const int nk = (K - kbeg + KC - 1) / KC;
   float* As0 = smem;
   float* Bs0 = smem + 2 * A_F;
-  gload(areg, A, p.lda, m0, M, 0, !TA, BM, AV);
-  gload(breg, B, p.ldb, n0, N, 0, TB, BN, BV);
+  gload(areg, A, p.lda, m0, M, kbeg, !TA, BM, AV);
+  gload(breg, B, p.ldb, n0, N, kbeg, TB, BN, BV);
   lstore(areg, As0, !TA, BM, AV);
   lstore(breg, Bs0, TB, BN, BV);
   __syncthreads();
@@ -121,8 +126,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const float* Bs = Bs0 + (kt & 1) * B_F;
     const bool has_next = kt + 1 < nk;
     if (has_next) {
-      gload(areg, A, p.lda, m0, M, (kt + 1) * KC, !TA, BM, AV);
-      gload(breg, B, p.ldb, n0, N, (kt + 1) * KC, TB, BN, BV);
+      gload(areg, A, p.lda, m0, M, kbeg + (kt + 1) * KC, !TA, BM, AV);
+      gload(breg, B, p.ldb, n0, N, kbeg + (kt + 1) * KC, TB, BN, BV);
     }
 #pragma unroll
     for (int k8 = 0; k8 < KC / 8; ++k8) {
@@ -160,6 +165,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     __syncthreads();
   }
 
+  if (split) {   // raw partial products; bias / alpha / residual are applied by splitk_reduce_kernel
+    float* W = p.ws + (size_t)bz * M * N;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wn * NT + nt) * 32 + li;
+      if (n >= N) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * MT + mt) * 32 + mfma32_row(r, lane);
+          if (m < M) W[(size_t)m * N + n] = acc[mt][nt][r];
+        }
+    }
+    return;
+  }
   float* Cb = p.C + (size_t)bz * p.sC;
   const float* Rb = p.R ? p.R + (size_t)bz * p.sR : nullptr;
 #pragma unroll
@@ -181,6 +202,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
 }
 
+// C = alpha * sum_s ws[s] + bias + beta * R   (fixed order => bitwise reproducible)
+__global__ void splitk_reduce_kernel(GemmArgs p) {
+  const size_t E = (size_t)p.M * p.N;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < p.ksplit; ++i) s += p.ws[(size_t)i * E + e];
+    const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
+    float v = p.alpha * s + (p.bias ? p.bias[n] : 0.f);
+    if (p.R) v += p.beta * p.R[(size_t)m * p.ldr + n];
+    p.C[(size_t)m * p.ldc + n] = v;
+  }
+}
+
+// split-K plan: only when the output has too few tiles to fill the chip and K is long
+int plan_ksplit(int M, int N, int K, int batch, int* kchunk) {
+  *kchunk = K;
+  if (batch != 1 || K < 4096) return 1;
+  const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+  if (tiles >= 256) return 1;
+  int s = (int)(1024 / tiles);
+  if (s > K / 512) s = K / 512;
+  if (s < 2) return 1;
+  int kc = ((K + s - 1) / s + 15) / 16 * 16;
+  *kchunk = kc;
+  return (K + kc - 1) / kc;
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch(const GemmArgs& a, int ta, int tb, int vec, int batch, hipStream_t st) {
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, batch), blk(256);
@@ -195,12 +243,34 @@ void launch(const GemmArgs& a, int ta, int tb, int vec, int batch, hipStream_t s
 
 }  // namespace
 
+MULAN_API size_t mulan_gemm_workspace(int M, int N, int K, int batch) {
+  int kc;
+  const int s = plan_ksplit(M, N, K, batch, &kc);
+  return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
 MULAN_API int mulan_gemm(const float* A, const float* B, float* C, const float* bias, const float* R, int M, int N,
                          int K, int lda, int ldb, int ldc, int ldr, int transA, int transB, int batch,
                          long long strideA, long long strideB, long long strideC, long long strideR, float alpha,
-                         float beta, hipStream_t stream) {
+                         float beta, float* workspace, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return (int)hipErrorInvalidValue;
-  GemmArgs a{A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, strideA, strideB, strideC, strideR, alpha, beta};
+  GemmArgs a{A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, strideA, strideB, strideC, strideR, alpha, beta,
+             1, K, nullptr};
+  if (workspace) {
+    int kc;
+    const int s = plan_ksplit(M, N, K, batch, &kc);
+    if (s > 1) {
+      a.ksplit = s; a.kchunk = kc; a.ws = workspace;
+      const auto al2 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+      const int cA = transA ? M : K, cB = transB ? K : N;
+      const int v = al2(A) && al2(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (cA % 4 == 0) && (cB % 4 == 0);
+      launch<64, 64, 2, 2>(a, transA, transB, v, s, stream);
+      const size_t E = (size_t)M * N;
+      const int blocks = (int)((E + 255) / 256 > 2048 ? 2048 : (E + 255) / 256);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+      MULAN_CHECK_LAUNCH();
+    }
+  }
   // float4 global loads need 16-byte aligned rows along the contiguous dimension of both operands.
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const int contigA = transA ? M : K, contigB = transB ? K : N;

@@ -19,7 +19,8 @@ SIGNATURES = {
     "mulan_conv3x3_wflip": [P, P, I, I, P],
     "mulan_conv3x3_wgrad_workspace": [I, I, I, I, I],
     "mulan_conv3x3_wgrad": [P, P, P, P, I, I, I, I, I, I, P],
-    "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P],
+    "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P],
+    "mulan_gemm_workspace": [I, I, I, I],
     "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P],
     "mulan_groupnorm_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, I, P],
     "mulan_act_fwd": [P, P, Z, I, F, P],
@@ -46,7 +47,7 @@ SIGNATURES = {
     "mulan_randn": [P, Z, U, U, P],
     "mulan_version": [],
 }
-_RESTYPES = {"mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_version": c_char_p}
+_RESTYPES = {"mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_gemm_workspace": c_size_t, "mulan_version": c_char_p}
 
 
 class MulanHipError(RuntimeError):

@@ -15,6 +15,7 @@ from .lib import call, ptr, stream
 H = W = 32
 HW = H * W
 D = HW * 3
+KERNEL_TIMER = None   # bench.py sets this to a list to time the dominant kernel with HIP events
 
 
 def _c(t):
@@ -36,7 +37,17 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
     mode = 0
     if cbias is not None:
         mode = 1 if cbias.dim() == 2 else 2
-    call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N, stream())
+    if KERNEL_TIMER is None:
+        call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N,
+             stream())
+    else:   # bench.py: HIP events on the launch stream around this one kernel
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N,
+             stream())
+        e.record()
+        variant = "<128,2,2>" if N > 64 else ("<64,2,2>" if N > 32 else "<32,4,1>")
+        KERNEL_TIMER.append(("conv3x3_fwd_kernel" + variant, s, e, 2.0 * B * HW * 9 * C * N))
     return y
 
 
@@ -63,12 +74,24 @@ def gemm_raw(A, Bm, M, N, K, *, bias=None, R=None, transA=False, transB=False, a
     ldb = ldb if ldb is not None else (K if transB else N)
     if out is None:
         out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=A.device, dtype=torch.float32)
+    ws = None
+    if batch == 1 and K >= 4096:
+        nbytes = lib.load().mulan_gemm_workspace(M, N, K, batch)
+        if nbytes:
+            ws = torch.empty(nbytes // 4, device=A.device, dtype=torch.float32)
     call("mulan_gemm", ptr(A), ptr(Bm), ptr(out), ptr(bias), ptr(R), M, N, K, lda, ldb, N, N, int(transA),
-         int(transB), batch, sA, sB, M * N, M * N, float(alpha), float(beta), stream())
+         int(transB), batch, sA, sB, M * N, M * N, float(alpha), float(beta), ptr(ws), stream())
     return out
 
 
 def colsum_raw(x2d, nseg, seg, C):
+    """out[s][c] = sum of `seg` consecutive rows; long segments are reduced in two stages so the grid
+    always has enough blocks to stream from HBM (fixed order => deterministic)."""
+    chunk = 512
+    if seg >= 4 * chunk and seg % chunk == 0:
+        part = torch.empty((nseg * (seg // chunk), C), device=x2d.device, dtype=torch.float32)
+        call("mulan_colsum", ptr(x2d), ptr(part), nseg * (seg // chunk), chunk, C, C, 0, stream())
+        x2d, seg = part, seg // chunk
     out = torch.empty((nseg, C), device=x2d.device, dtype=torch.float32)
     call("mulan_colsum", ptr(x2d), ptr(out), nseg, seg, C, C, 0, stream())
     return out

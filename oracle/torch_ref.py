@@ -27,7 +27,7 @@ def dense(x, p):
 
 def conv3x3(x, p):
     """flax nn.Conv((3,3)) SAME NHWC/HWIO (ldm/model_vdm.py:633-634)"""
-    w = p["kernel"].permute(3, 2, 0, 1)   # HWIO -> OIHW
+    w = p["kernel"].permute(3, 2, 0, 1).contiguous()   # HWIO -> OIHW
     y = F.conv2d(x.permute(0, 3, 1, 2), w, p.get("bias"), padding=1)
     return y.permute(0, 2, 3, 1)
 

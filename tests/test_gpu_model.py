@@ -84,8 +84,8 @@ def run_case(vdm_type, unet_type, vfe, train):
     assert np.array_equal(np.round(aux["emb"].detach().cpu().numpy()), np.round(ref["aux"]["emb"].detach().numpy()))
     assert rel(aux["zt"].detach().cpu().numpy(), ref["aux"]["z_t"].detach().numpy().reshape(B, -1)) < 1e-5
     assert rel(aux["net"].detach().cpu().numpy(), ref["aux"]["net"].detach().numpy().reshape(B, -1)) < 2e-4
-    assert rel(out.loss_recon.detach().cpu().numpy(), ref["loss_recon"].detach().numpy()) < 1e-5
-    assert rel(out.loss_klz.detach().cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-5
+    assert rel(out.loss_recon.detach().cpu().numpy(), ref["loss_recon"].detach().numpy()) < 1e-4
+    assert rel(out.loss_klz.detach().cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-4
     assert rel(out.loss_diff.detach().cpu().numpy(), ref["loss_diff"].detach().numpy()) < 5e-4
     r = 1.0 / (3072 * np.log(2.0))
     bpd = (out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) * r
