@@ -1,0 +1,233 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/mulan_hip.h declares (no compute), and the
+host logic around the kernels (config/flags, checkpoints, TrainState layout, rng, data, schedules)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from mulan_amd import build
+    return build.build_library()
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "mulan_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(mulan_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(3).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(2)] = n
+    return decls
+
+
+def test_header_and_binding_table_agree():
+    from mulan_amd import lib
+    decls = _header_decls()
+    assert set(decls) == set(lib.SIGNATURES), set(decls) ^ set(lib.SIGNATURES)
+    for name, n in decls.items():
+        assert len(lib.SIGNATURES[name]) == n, (name, n, len(lib.SIGNATURES[name]))
+
+
+def test_shared_object_exports_every_declared_symbol(built_lib):
+    h = ctypes.CDLL(built_lib)
+    for name in _header_decls():
+        assert getattr(h, name) is not None
+    h.mulan_version.restype = ctypes.c_char_p
+    assert b"gfx950" in h.mulan_version()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mulan_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.MulanHipError):
+        lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    for pkg in ("mulan_amd", "ldm"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith(".py"):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+
+
+# ------------------------------------------------------------------------------ config / flags
+def test_shipped_configs_and_overrides():
+    from mulan_amd.config import Flags, load_config_file
+    from mulan_amd.model import VDMConfig
+    c = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    i = load_config_file(os.path.join(ROOT, "ldm", "configs", "imagenet32.py"))
+    assert (c.vdm_type, c.model.sm_n_embd, c.training.batch_size_train) == ("mulan_velocity", 128, 128)
+    assert (i.vdm_type, i.model.sm_n_embd, i.training.batch_size_train) == ("mulan_epsilon", 256, 512)
+    assert c.optimizer.args.b2 == 0.99 and c.optimizer.ema_rate == 0.9999 and c.model.gamma_min == -13.3
+    VDMConfig(**c.model.to_dict())
+    VDMConfig(**i.model.to_dict())
+    with pytest.raises(TypeError):
+        VDMConfig(**dict(c.model.to_dict(), no_such_key=1))
+    F = Flags()
+    F.DEFINE_config_file("config")
+    F.DEFINE_string("workdir", None)
+    F.DEFINE_integer("n_timesteps", 128)
+    F.DEFINE_bool("deterministic_noise", False)
+    F.mark_flags_as_required(["config", "workdir"])
+    F.parse(["--config=" + os.path.join(ROOT, "ldm", "configs", "imagenet32.py"), "--workdir", "/tmp/w",
+             "--config.vdm_type=mulan_velocity", "--config.model.velocity_from_epsilon=True",
+             "--config.training.batch_size_train=64", "--n_timesteps=1000", "--deterministic_noise"])
+    assert F.config.vdm_type == "mulan_velocity" and F.config.model.velocity_from_epsilon is True
+    assert F.config.training.batch_size_train == 64 and F.n_timesteps == 1000 and F.deterministic_noise is True
+    with pytest.raises(SystemExit):
+        Flags().parse(["--bogus=1"])
+
+
+def test_reference_style_config_file_loads(tmp_path):
+    from mulan_amd.config import load_config_file
+    p = tmp_path / "cfg.py"
+    p.write_text("import ml_collections\n\ndef get_config():\n    c = ml_collections.ConfigDict()\n"
+                 "    c.a = ml_collections.ConfigDict(initial_dictionary=dict(b=3))\n    return c\n")
+    assert load_config_file(str(p)).a.b == 3
+
+
+def test_workdir_name_follows_overrides():
+    from ldm.utils import get_workdir
+    w = get_workdir(["prog", "--config=ldm/configs/cifar10-conditioned.py", "--workdir=/x",
+                     "--config.model.sm_n_layer=8", "--config.seed=1"])
+    assert w.startswith("cifar10-conditioned/") and "sm_n_layer=8" in w
+
+
+# ------------------------------------------------------------------------------ rng / data
+def test_rng_is_deterministic_and_splits_differ():
+    from mulan_amd.rng import PRNGKey
+    k = PRNGKey(1)
+    a, b = k.split()
+    assert a.v != b.v and PRNGKey(1).split()[0].v == a.v
+    assert k.fold_in(3).v != k.fold_in(4).v
+    assert 0 <= a.uniform() < 1
+
+
+def test_synthetic_stream_shapes_and_rank_shards():
+    from mulan_amd.config import ConfigDict
+    from mulan_amd import data
+    cfg = ConfigDict(dict(data=dict(dataset="synthetic"), training=dict(batch_size_train=8, batch_size_eval=4, substeps=3)))
+    tr0, ev0 = data.create_dataset(cfg, "cpu", seed=0, rank=0, world=2)
+    tr1, _ = data.create_dataset(cfg, "cpu", seed=0, rank=1, world=2)
+    b0, b1 = next(tr0), next(tr1)
+    assert b0["images"].shape == (3, 4, 32, 32, 3) and b0["images"].dtype == torch.uint8
+    assert not torch.equal(b0["images"], b1["images"])
+    assert ev0.next()["images"].shape == (2, 32, 32, 3)
+    with pytest.raises(ValueError):
+        data.BatchStream("synthetic", 7, train=True, device="cpu", world=2)
+
+
+def test_npz_one_pass_eval_is_sharded_in_order(tmp_path):
+    from mulan_amd.config import ConfigDict
+    from mulan_amd import data
+    imgs = np.arange(10, dtype=np.uint8)[:, None, None, None] * np.ones((1, 32, 32, 3), dtype=np.uint8)
+    np.savez(tmp_path / "d.npz", images=imgs)
+    cfg = ConfigDict(dict(data=dict(dataset=f"npz:{tmp_path / 'd.npz'}")))
+    seen = []
+    for rank in range(2):
+        it = data.create_one_time_eval_dataset(cfg, 1, "cpu", rank=rank, world=2)
+        seen.append([int(b["images"][0, 0, 0, 0]) for b in it])
+    assert seen == [[0, 2, 4, 6, 8], [1, 3, 5, 7, 9]]
+
+
+# ------------------------------------------------------------------------------ train state / checkpoints
+def _tiny_tree():
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g)
+    conv_in = r(3, 3, 16, 8)
+    conv_in[:, :, 15, :] = 0          # the 16th input channel is alignment padding and stays zero
+    return {"score_model": {"conv_in": {"kernel": conv_in, "bias": r(8)}, "GroupNorm_0": {"scale": r(8), "bias": r(8)}},
+            "encoder_model": {"dense": {"kernel": r(5, 3), "bias": r(3)}},
+            "gamma": {"dense_1": {"kernel": r(7, 2), "bias": r(2)}}}
+
+
+def test_train_state_layout_decay_mask_and_views():
+    from mulan_amd.train_state import TrainState
+    tree = _tiny_tree()
+    st = TrainState.create(apply_fn=None, variables={"params": tree}, device="cpu")
+    paths = ["/".join(p) for p, _, _ in st.layout]
+    n_bias = sum(1 for p in paths if p.endswith("/bias"))
+    assert all(p.endswith("/bias") for p in paths[-n_bias:]) and not any(p.endswith("/bias") for p in paths[:-n_bias])
+    assert "score_model/GroupNorm_0/scale" in paths[:-n_bias]          # GroupNorm scale IS decayed (experiment.py:139-146)
+    first_bias_off = st.layout[len(paths) - n_bias][1]
+    assert st.n_decay == first_bias_off and st.numel % 4 == 0
+    assert torch.equal(st.params["gamma"]["dense_1"]["kernel"].detach(), tree["gamma"]["dense_1"]["kernel"])
+    assert torch.equal(st.ema, st.flat)
+    leaf = st.params["encoder_model"]["dense"]["kernel"]
+    (leaf * 2).sum().backward()
+    off = dict((("/".join(p)), o) for p, o, _ in st.layout)["encoder_model/dense/kernel"]
+    assert torch.equal(st.grad[off:off + 15], torch.full((15,), 2.0))  # .grad is a view of the flat buffer
+    st.zero_grad()
+    assert float(leaf.grad.abs().sum()) == 0
+
+
+def test_checkpoint_roundtrip_pt_and_flax_msgpack(tmp_path):
+    from mulan_amd import checkpoint as ck
+    from mulan_amd.model import to_flax_layout
+    from mulan_amd.train_state import TrainState
+    st = TrainState.create(apply_fn=None, variables={"params": _tiny_tree()}, device="cpu")
+    st.step = 41
+    st.ema.mul_(0.5)
+    d = tmp_path / "checkpoints"
+    n = ck.save(str(d), st.state_dict())
+    assert n == 1 and ck.checkpoint_numbers(str(d)) == [1]
+    ck.save(str(d), st.state_dict())
+    assert ck.latest_checkpoint(str(d)).endswith("ckpt-2.pt")
+    st2 = TrainState.create(apply_fn=None, variables={"params": _tiny_tree()}, device="cpu")
+    st2.flat.zero_()
+    st2.load_state_dict(ck.restore_dict(os.path.join(str(d), "ckpt-2")))
+    assert st2.step == 41 and torch.equal(st2.flat, st.flat) and torch.equal(st2.ema, st.ema)
+    # reference layout: conv_in with 15 input channels, Flax msgpack, optimizer state as masked 2-tuple
+    sd = st.state_dict()
+    flax_sd = {"step": np.int32(7), "params": to_flax_layout(sd["params"]), "ema_params": to_flax_layout(sd["ema_params"]),
+               "opt_state": {"0": {"inner_state": {"0": {"count": np.int32(7), "mu": to_flax_layout(sd["opt_state"]["mu"]),
+                                                         "nu": to_flax_layout(sd["opt_state"]["nu"])}}}}}
+    assert flax_sd["params"]["score_model"]["conv_in"]["kernel"].shape[2] == 15
+    ck.save_flax(str(d / "ckpt-9.flax"), flax_sd)
+    assert ck.checkpoint_numbers(str(d)) == [1, 2, 9]
+    back = ck.restore_dict(os.path.join(str(d), "ckpt-9"))
+    assert back["step"] == 7 and "mu" in back["opt_state"]
+    st3 = TrainState.create(apply_fn=None, variables={"params": _tiny_tree()}, device="cpu")
+    st3.flat.zero_()
+    st3.load_state_dict(back)
+    assert torch.equal(st3.flat, st.flat) and torch.equal(st3.ema, st.ema) and st3.step == 7
+
+
+def test_partial_restore_overlays_only_present_keys():
+    from mulan_amd.experiment import restore_partial
+    from mulan_amd.train_state import TrainState
+    st = TrainState.create(apply_fn=None, variables={"params": _tiny_tree()}, device="cpu")
+    before = st.params["gamma"]["dense_1"]["kernel"].detach().clone()
+    new = torch.ones(5, 3)
+    restore_partial(st, {"params": {"encoder_model": {"dense": {"kernel": new}}}})
+    assert torch.equal(st.params["encoder_model"]["dense"]["kernel"].detach(), new)
+    assert torch.equal(st.params["gamma"]["dense_1"]["kernel"].detach(), before)
+
+
+def test_model_init_matches_reference_parameter_counts():
+    """CIFAR config 71.15 M parameters (score 30.60 + encoder 2.63 + gamma 37.92)."""
+    from mulan_amd.config import load_config_file
+    from mulan_amd.model import VDMConfig, make_vdm, to_flax_layout, tree_leaves
+    from mulan_amd.rng import PRNGKey
+    c = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    vdm = make_vdm(c.vdm_type, VDMConfig(**c.model.to_dict()))
+    tree = to_flax_layout(vdm.init(PRNGKey(1)))
+    count = lambda t: sum(v.numel() for _, v in tree_leaves(t))
+    assert count(tree["score_model"]) == 30_603_267
+    assert count(tree["encoder_model"]) == 2_632_883
+    assert count(tree["gamma"]) == 37_917_696
+    assert tree["score_model"]["dense0"]["kernel"].shape == (178, 512)
+    assert tree["score_model"]["up.block_3"]["conv1"]["kernel"].shape == (3, 3, 256, 128)
+    assert float(tree["score_model"]["conv_out"]["kernel"].abs().sum()) == 0       # zero-init (model_vdm.py:382)
+    assert float(tree["gamma"]["dense_out_a"]["kernel"].abs().sum()) == 0         # model_mulan_epsilon.py:495-500

@@ -1,0 +1,181 @@
+"""CPU tests of the oracle: analytic known-answer tests, agreement of the NumPy and torch
+restatements, and the committed golden fixtures.  The reference has no tests or vectors of its own."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import mulan_np as onp
+from oracle import torch_ref as tr
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _abc(rng, B=4):
+    a = rng.standard_normal((B, 3072))
+    b = rng.standard_normal((B, 3072))
+    c = 1e-3 + np.logaddexp(rng.standard_normal((B, 3072)), 0)
+    return a, b, c
+
+
+def test_gamma_fixed_end_points_and_monotone():
+    rng = np.random.default_rng(0)
+    a, b, c = _abc(rng)
+    assert np.allclose(onp.poly_gamma(a, b, c, np.zeros(4)), -13.3, atol=1e-12)      # A.9 #1
+    assert np.allclose(onp.poly_gamma(a, b, c, np.ones(4)), 5.0, atol=1e-9)
+    ts = np.linspace(0, 1, 33)
+    g = np.stack([onp.poly_gamma(a, b, c, np.full(4, t)) for t in ts])
+    assert np.all(np.diff(g, axis=0) >= -1e-9)                                        # A.9 #3
+    assert np.all(onp.poly_gamma_grad_t(a, b, c, np.full(4, 0.3)) >= 0)
+
+
+def test_gamma_grad_matches_finite_difference():
+    rng = np.random.default_rng(1)
+    a, b, c = _abc(rng)
+    t = rng.uniform(0.05, 0.95, 4)
+    h = 1e-6
+    fd = (onp.poly_gamma(a, b, c, t + h) - onp.poly_gamma(a, b, c, t - h)) / (2 * h)
+    assert np.allclose(fd, onp.poly_gamma_grad_t(a, b, c, t), rtol=1e-6, atol=1e-6)   # A.9 #2
+
+
+def test_fresh_init_gamma_is_cubic():
+    rng = np.random.default_rng(2)
+    _, b, c = _abc(rng)
+    a = np.zeros_like(b)                                                              # dense_out_a zero-init
+    ts = np.linspace(0, 1, 9)
+    g = np.stack([onp.poly_gamma(a, b, c, np.full(4, t))[0, :5] for t in ts])
+    coef = np.polyfit(ts, g, 3)
+    assert np.allclose(np.polyval(coef, ts[:, None] * np.ones((1, 5))), g, atol=1e-9)  # A.9 #4
+
+
+def test_velocity_loss_equals_epsilon_loss_under_reparameterisation():
+    rng = np.random.default_rng(3)
+    B = 2
+    f = rng.uniform(-1, 1, (B, 32, 32, 3))
+    g = rng.uniform(-10, 4, (B, 32, 32, 3))
+    gp = rng.uniform(1, 30, (B, 32, 32, 3))
+    eps, eps_hat = rng.standard_normal(f.shape), rng.standard_normal(f.shape)
+    s2 = onp.sigmoid(g)
+    al, sg = np.sqrt(1 - s2), np.sqrt(s2)
+    zt = al * f + sg * eps
+    v_hat = (eps_hat - sg * zt) / al
+    lv = onp.diffusion_loss_velocity(f, g, gp, eps, zt, v_hat)
+    le = onp.diffusion_loss_epsilon(gp, eps, eps_hat)
+    assert np.allclose(lv, le, rtol=1e-9)                                             # A.9 #5
+    lvfe = onp.diffusion_loss_velocity(f, g, gp, eps, zt, eps_hat, velocity_from_epsilon=True)
+    assert np.allclose(lvfe, le, rtol=1e-9)                                           # A.9 #6
+
+
+def test_decoder_is_a_distribution_and_picks_the_bin():
+    rng = np.random.default_rng(4)
+    x = rng.integers(0, 256, (2, 4, 4, 3))
+    f = onp.encode(x)
+    lp = onp.decode_logprobs(f, np.full(f.shape, -13.3))
+    assert np.allclose(np.exp(lp).sum(-1), 1.0)
+    assert np.array_equal(lp.argmax(-1), x)
+    top2 = np.sort(lp, axis=-1)[..., -2:]
+    assert np.allclose(top2[..., 1] - top2[..., 0], 0.5 * (2 / 256 * np.exp(6.65)) ** 2, rtol=1e-3)  # gap ~18.2
+    assert np.all(onp.logprob(x, f, np.full(f.shape, -13.3)) <= 0)                   # A.9 #8
+
+
+def test_klz_closed_form():
+    f = np.full((1, 32, 32, 3), 0.5)
+    z = np.zeros_like(f)
+    _, _, _, klz, _, v1 = onp.elbo_pre(np.full((1, 32, 32, 3), 191), np.full_like(f, -13.3), np.full_like(f, 5.0),
+                                       np.full_like(f, 0.0), z, z)
+    s2 = 1 / (1 + np.exp(-5.0))
+    fx = onp.encode(np.array(191.0))
+    assert np.isclose(v1, s2) and abs(s2 - 0.993307) < 1e-6
+    assert np.isclose(klz[0], 3072 * 0.5 * ((1 - s2) * fx ** 2 + s2 - np.log(s2) - 1))  # A.9 #9
+
+
+def test_antithetic_times_cover_unit_interval():
+    t = onp.antithetic_t(0.73, 8)
+    assert np.allclose(np.sort(t), (0.73 % 0.125) + np.arange(8) / 8)                # A.9 #10
+
+
+def test_topk_is_k_hot_with_straight_through_value():
+    rng = np.random.default_rng(5)
+    logits = rng.standard_normal((6, 50))
+    raw = rng.gamma(1 / 15, size=(10, 6, 50))
+    emb, kl, soft = onp.topk_embedding_and_loss(logits, raw, 15)
+    assert np.all(np.round(emb).sum(1) == 15) and np.allclose(emb, np.round(emb), atol=1e-12)
+    assert np.all(kl >= 0) and np.allclose(np.linalg.norm(soft, axis=1), 1)
+
+
+def test_adamw_matches_torch_optimizer():
+    rng = np.random.default_rng(6)                                                    # A.9 #11
+    p0, g = rng.standard_normal(50), rng.standard_normal(50)
+    tp = torch.tensor(p0, requires_grad=True)
+    opt = torch.optim.AdamW([tp], lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    p, m, v, ema = p0.copy(), np.zeros(50), np.zeros(50), p0.copy()
+    for step in range(1, 4):
+        tp.grad = torch.tensor(g * step)
+        opt.step()
+        p, m, v, ema = onp.adamw_ema_step(p, g * step, m, v, ema, 2e-4, step, np.ones(50))
+    # torch decays with p*(1 - lr*wd) before the Adam update; optax adds wd*p to the update: equal to O(lr^2)
+    assert np.allclose(p, tp.detach().numpy(), atol=1e-8)
+    assert not np.allclose(ema, p)
+
+
+def test_lr_schedule_warmup():
+    assert onp.lr_schedule(0) == 0 and np.isclose(onp.lr_schedule(50), 1e-4) and onp.lr_schedule(5000) == 2e-4
+
+
+def test_philox_known_answer():
+    # Random123 known-answer vector for philox4x32-10: counter = key = 0
+    r = onp.philox4x32_10(0, np.array([0], dtype=np.uint64))[0]
+    assert [hex(int(v)) for v in r] == ['0x6627e8d5', '0xe169c58d', '0xbc57ac4c', '0x9b00dbd8']
+
+
+def test_numpy_and_torch_restatements_agree():
+    cfg = dict(vdm_type='mulan_velocity', n_embd=32, n_layer=1, forward_n_layer=1, latent_k=15, unet_type='vdm')
+    P = tr.init_params(cfg, seed=0)
+    rng = np.random.default_rng(0)
+    B = 2
+    x = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    raw = rng.gamma(1 / 15, size=(10, B, 50))
+    e0, e = rng.standard_normal((B, 32, 32, 3)), rng.standard_normal((B, 32, 32, 3))
+    for extra in ({}, {"velocity_from_epsilon": True}, {"vdm_type": "mulan_epsilon"}, {"unet_type": "ldm"}):
+        c = dict(cfg, **extra)
+        Pc = tr.init_params(c, seed=1) if extra.get("unet_type") == "ldm" else P
+        a = onp.mulan_forward(tr.to_np_tuples(Pc), c, x, 0.3, raw, e0, e)
+        b = tr.mulan_forward(Pc, c, torch.from_numpy(x), 0.3, torch.from_numpy(raw), torch.from_numpy(e0),
+                             torch.from_numpy(e))
+        assert abs(a["bpd"] - float(b["bpd"])) < 1e-10 * abs(a["bpd"])
+        assert np.allclose(a["loss_diff"], b["loss_diff"].detach().numpy(), rtol=1e-10)
+
+
+def test_golden_closed_forms_fixture():
+    z = np.load(os.path.join(GOLD, "closed_forms.npz"))
+    a, b, c, t = z["a"], z["b"], z["c"], z["t"]
+    shp = z["eps"].shape
+    gt = onp.poly_gamma(a, b, c, t).reshape(shp)
+    gp = onp.poly_gamma_grad_t(a, b, c, t).reshape(shp)
+    assert np.allclose(gt, z["g_t"], rtol=1e-12) and np.allclose(gp, z["g_prime"], rtol=1e-12)
+    g0 = onp.poly_gamma(a, b, c, np.zeros(len(t))).reshape(shp)
+    g1 = onp.poly_gamma(a, b, c, np.ones(len(t))).reshape(shp)
+    f, zt, recon, klz, v0, v1 = onp.elbo_pre(z["x"], g0, g1, gt, z["eps_0"], z["eps"])
+    assert np.allclose(zt, z["z_t"]) and np.allclose(recon, z["loss_recon"]) and np.allclose(klz, z["loss_klz"])
+    assert np.allclose(onp.diffusion_loss_velocity(f, gt, gp, z["eps"], zt, z["net"]), z["loss_diff_velocity"])
+    assert np.allclose(onp.diffusion_loss_velocity(f, gt, gp, z["eps"], zt, z["net"], True), z["loss_diff_vfe"])
+    assert np.allclose(onp.diffusion_loss_epsilon(gp, z["eps"], z["net"]), z["loss_diff_epsilon"])
+    emb, kl, _ = onp.topk_embedding_and_loss(z["logits"], z["gamma_raw"], 15)
+    assert np.array_equal(emb, z["embedding"]) and np.allclose(kl, z["kl_z"])
+    assert np.allclose(onp.timestep_embedding(z["temb_t"], 128), z["temb"])
+    assert np.allclose(onp.fourier_features(z["fourier_z"]), z["fourier"])
+    # torch restatement against the same file
+    tt = lambda v: torch.tensor(v)
+    assert np.allclose(tr.poly_gamma(tt(a), tt(b), tt(c), tt(t)).numpy().reshape(shp), z["g_t"], rtol=1e-12)
+    e2, k2 = tr.topk_embedding_and_loss(tt(z["logits"]), tt(z["gamma_raw"]), 15)
+    assert np.allclose(e2.numpy(), z["embedding"]) and np.allclose(k2.numpy(), z["kl_z"])
+
+
+def test_golden_tiny_model_fixture():
+    z = np.load(os.path.join(GOLD, "tiny_model.npz"))
+    cfg = dict(vdm_type="mulan_epsilon", n_embd=128, n_layer=1, forward_n_layer=1, latent_k=15, unet_type="vdm")
+    P = tr.init_params(cfg, seed=int(z["param_seed"]), dtype=torch.float64)
+    r = tr.mulan_forward(P, cfg, torch.tensor(z["x"]), float(z["t0"]), torch.tensor(z["gamma_raw"]),
+                         torch.tensor(z["eps_0"]), torch.tensor(z["eps"]))
+    assert abs(float(r["bpd"]) - float(z["epsilon_bpd"])) < 1e-9 * abs(float(z["epsilon_bpd"]))
+    assert np.allclose(r["loss_diff"].detach().numpy(), z["epsilon_diff"], rtol=1e-9)

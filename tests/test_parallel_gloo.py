@@ -1,0 +1,94 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: the bucketed gradient reducer over the flat buffer equals the
+big-batch gradient, scalar metrics are averaged like lax.pmean, and the sharded dense-eval reduction is
+partition invariant.  (RCCL is the same torch.distributed API with backend 'nccl'.)"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from mulan_amd import parallel
+    from mulan_amd.train_state import TrainState, tree_leaves_in_layout
+    r, w, _ = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(0)
+    tree = {"score_model": {"a": {"kernel": torch.randn(40, 30, generator=g), "bias": torch.randn(30, generator=g)},
+                            "b": {"kernel": torch.randn(30, 7, generator=g), "bias": torch.randn(7, generator=g)}},
+            "gamma": {"c": {"kernel": torch.randn(7, 5, generator=g)}}}
+    st = TrainState.create(apply_fn=None, variables={"params": tree}, device="cpu")
+    leaves = [(leaf, off, leaf.numel()) for (path, off, shape), (_, leaf) in
+              zip(st.layout, tree_leaves_in_layout(st.params, st.layout))]
+    red = parallel.GradReducer(st.grad, leaves, bucket_bytes=4 * 400)   # several buckets
+    assert len(red.buckets) > 1
+
+    def loss(params, x):
+        h = torch.tanh(x @ params["score_model"]["a"]["kernel"] + params["score_model"]["a"]["bias"])
+        h = torch.tanh(h @ params["score_model"]["b"]["kernel"] + params["score_model"]["b"]["bias"])
+        return (h @ params["gamma"]["c"]["kernel"]).pow(2).mean()
+
+    xg = torch.randn(8, 40, generator=torch.Generator().manual_seed(1))
+    shard = xg[rank * 4:(rank + 1) * 4]
+    ok = True
+    for _ in range(2):                       # two steps: hooks / buckets re-arm correctly
+        st.zero_grad()
+        red.prepare()
+        loss(st.params, shard).backward()
+        red.finish()
+        mean_grad = st.grad / world          # the optimizer kernel applies 1/world as grad_scale
+        ref = TrainState.create(apply_fn=None, variables={"params": tree}, device="cpu")
+        loss(ref.params, xg).backward()      # big-batch gradient on one process
+        ok = ok and torch.allclose(mean_grad, ref.grad, atol=1e-6)
+    m = parallel.allreduce_mean_scalars({"bpd": torch.tensor(float(rank + 1)), "var": 2.0 * (rank + 1)}, "cpu")
+    ok = ok and abs(float(m["bpd"]) - 1.5) < 1e-6 and abs(float(m["var"]) - 3.0) < 1e-6
+    # sharded evaluator reduction: per-image values split by index, (sum, count) all-reduced
+    from mulan_amd.evaluators import _reduce_mean
+    vals = [float(i) for i in range(10)]
+    mine = vals[rank::world]
+    mean, n = _reduce_mean(sum(mine), len(mine), "cpu")
+    ok = ok and n == 10 and abs(mean - 4.5) < 1e-12
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_reduction_matches_big_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_single_process_reducer_is_a_noop():
+    from mulan_amd import parallel
+    flat = torch.zeros(16)
+    t = flat[:8].view(2, 4).detach().requires_grad_(True)
+    red = parallel.GradReducer(flat, [(t, 0, 8)])
+    red.prepare()
+    red.finish()
+    assert not red.enabled and parallel.world_size() == 1
