@@ -30,6 +30,8 @@ extern "C" {
 #endif
 
 const char* mulan_version(void);
+/* developer knob for kernel-variant A/B runs (tools/kbench.py); never needed in production */
+int mulan_set_tuning(int key, int value);
 
 /* ---- 3x3 SAME convolution, NHWC, HWIO weights [3,3,C,N] --------------------------------------
  * flax nn.Conv(kernel_size=(3,3)) in ResnetBlock conv1/conv2 (ldm/model_vdm.py:633-634,645-650;

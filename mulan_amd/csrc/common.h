@@ -10,6 +10,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MULAN_CHECK_LAUNCH() return (int)hipGetLastError()
 
+// developer tuning knobs (mulan_set_tuning): [0] conv fwd variant, [1] wgrad resident-block target
+extern int g_mulan_tune[16];
+
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] lives in accumulator register r (0..15).
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

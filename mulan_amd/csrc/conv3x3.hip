@@ -30,7 +30,10 @@ struct ConvArgs {
   int B, H, C, N, cbias_mode;
 };
 
-template <int BN, int WM, int WN>
+// VEC: C % 4 == 0 and N % 4 == 0.  The VEC loaders are branch free (clamped address + validity mask applied at
+// the LDS store): a divergent branch around a prefetch load makes hipcc wait vmcnt(0) right after issuing it,
+// which serialises the global-load latency in front of every MFMA cluster.
+template <int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
   constexpr int MT = TROWS / WM;        // image rows per wave
   constexpr int NT = BN / 32 / WN;      // 32-wide cout tiles per wave
@@ -50,8 +53,8 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
   const int h0 = (blockIdx.x % tiles_per_img) * TROWS;
   const int n0 = blockIdx.y * BN;
   const int C = p.C, N = p.N;
-  const bool vec_in = (C & 3) == 0;
-  const bool vec_w = (N & 3) == 0;
+  const bool vec_in = VEC || (C & 3) == 0;
+  const bool vec_w = VEC || (N & 3) == 0;
   const int nchunks = (C + CK - 1) / CK;
   const float* xb = p.x + (size_t)b * p.H * kW * C;
 
@@ -65,8 +68,25 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
 
   f32x4 preg[PV];
   f32x4 wreg[WV];
+  unsigned pmask = 0, wmask = 0;   // validity bits of the prefetched slots (VEC path)
 
   auto gload_patch = [&](int cc) {
+    if (VEC) {
+      pmask = 0;
+#pragma unroll
+      for (int s = 0; s < PV; ++s) {
+        const int slot = tid + s * 256;
+        const int q = slot & 3, pix = slot >> 2;
+        const int prow = pix / kPW, pcol = pix - prow * kPW;
+        const int hh = h0 + prow - 1, ww = pcol - 1;
+        const int c = cc * CK + q * 4;
+        const bool ok = slot < (TROWS + 2) * kPW * (CK / 4) && hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C;
+        const float* src = ok ? xb + ((size_t)hh * kW + ww) * C + c : p.x;
+        preg[s] = *reinterpret_cast<const f32x4*>(src);
+        pmask |= (ok ? 1u : 0u) << s;
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < PV; ++s) {
       const int slot = tid + s * 256;
@@ -97,11 +117,26 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
       const int slot = tid + s * 256;
       if (slot < (TROWS + 2) * kPW * (CK / 4)) {
         const int q = slot & 3, pix = slot >> 2;
-        *reinterpret_cast<f32x4*>(pb + pix * PS + q * 4) = preg[s];
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(pb + pix * PS + q * 4) = (!VEC || ((pmask >> s) & 1u)) ? preg[s] : z;
       }
     }
   };
   auto gload_w = [&](int cc, int tap) {
+    if (VEC) {
+      wmask = 0;
+#pragma unroll
+      for (int s = 0; s < WV; ++s) {
+        const int slot = tid + s * 256;
+        const int k = slot / (BN / 4), nq = slot - k * (BN / 4);
+        const int c = cc * CK + k, n = n0 + nq * 4;
+        const bool ok = slot < WT_F / 4 && c < C && n < N;
+        const float* src = ok ? p.w + ((size_t)tap * C + c) * N + n : p.w;
+        wreg[s] = *reinterpret_cast<const f32x4*>(src);
+        wmask |= (ok ? 1u : 0u) << s;
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < WV; ++s) {
       const int slot = tid + s * 256;
@@ -128,7 +163,8 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
 #pragma unroll
     for (int s = 0; s < WV; ++s) {
       const int slot = tid + s * 256;
-      if (slot < WT_F / 4) *reinterpret_cast<f32x4*>(wb + slot * 4) = wreg[s];
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (slot < WT_F / 4) *reinterpret_cast<f32x4*>(wb + slot * 4) = (!VEC || ((wmask >> s) & 1u)) ? wreg[s] : z;
     }
   };
 
@@ -153,28 +189,43 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
         if (tap < 8) gload_w(cc, tap + 1); else gload_w(cc + 1, 0);
       }
       if (tap == 7 && more_chunks) gload_patch(cc + 1);
+      // keep the prefetch loads above and their LDS stores below the MFMA cluster (hipcc otherwise sinks a
+      // load past the cluster and exposes its latency in front of the barrier)
+      __builtin_amdgcn_sched_barrier(0);
 
+      {
+        // A fragments of the whole stage up front (ds_read_b128), B fragments double-buffered one k-step
+        // ahead (ds_read_b32) so no MFMA group waits on an LDS read issued right in front of it.
+        f32x4 a4[CK / 8][MT];
 #pragma unroll
-      for (int k8 = 0; k8 < CK / 8; ++k8) {
-        f32x4 a4[MT];
+        for (int k8 = 0; k8 < CK / 8; ++k8)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int prow = wm * MT + mt + kh, pcol = li + kw;
-          a4[mt] = *reinterpret_cast<const f32x4*>(pb + (prow * kPW + pcol) * PS + k8 * 8 + 4 * lh);
-        }
+          for (int mt = 0; mt < MT; ++mt) {
+            const int prow = wm * MT + mt + kh, pcol = li + kw;
+            a4[k8][mt] = *reinterpret_cast<const f32x4*>(pb + (prow * kPW + pcol) * PS + k8 * 8 + 4 * lh);
+          }
+        float bcur[NT], bnext[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int kk = k8 * 8 + 4 * lh + j;   // k permutation shared by A and B
-          float bf[NT];
+        for (int nt = 0; nt < NT; ++nt) bcur[nt] = wb[(4 * lh) * BN + (wn * NT + nt) * 32 + li];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bf[nt] = wb[kk * BN + (wn * NT + nt) * 32 + li];
+        for (int st = 0; st < CK / 2; ++st) {
+          const int k8 = st >> 2, j = st & 3;
+          if (st + 1 < CK / 2) {
+            const int kk = ((st + 1) >> 2) * 8 + 4 * lh + ((st + 1) & 3);   // k permutation shared by A and B
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bnext[nt] = wb[kk * BN + (wn * NT + nt) * 32 + li];
+          }
+          __builtin_amdgcn_sched_barrier(0);   // the read of step st+1 stays in front of step st's MFMAs
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(a4[mt][j], bf[nt], acc[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(a4[k8][mt][j], bcur[nt], acc[mt][nt]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnext[nt];
         }
       }
 
+      __builtin_amdgcn_sched_barrier(0);
       if (has_next) store_w(wb_next);
       if (tap == 8 && more_chunks) store_patch(pbuf0 + ((cc + 1) & 1) * PATCH_F);
       __syncthreads();
@@ -227,6 +278,7 @@ struct WgradArgs {
   int B, H, C, N, S;
 };
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[WG_XP + WG_DY];
   float* xp = smem;
@@ -236,7 +288,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
   const int wci = wave >> 1, wco = wave & 1;
   const int C = p.C, N = p.N;
   const int c0 = blockIdx.y * WG_T, n0 = blockIdx.z * WG_T;
-  const bool vec_x = (C & 3) == 0, vec_dy = (N & 3) == 0;
+  const bool vec_x = VEC || (C & 3) == 0, vec_dy = VEC || (N & 3) == 0;
   const int pairs_per_img = p.H / WG_ROWS;
   const int total_pairs = p.B * pairs_per_img;
   const int per_split = (total_pairs + p.S - 1) / p.S;
@@ -249,33 +301,66 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int pr = pair_begin; pr < pair_end; ++pr) {
+  constexpr int XV = ((WG_ROWS + 2) * kPW * (WG_T / 4) + 255) / 256;   // 9 float4 slots / thread
+  constexpr int DV = (WG_ROWS * kW * (WG_T / 4) + 255) / 256;           // 4
+  f32x4 xreg[XV], dreg[DV];
+  unsigned xmask = 0, dmask = 0;
+  // global -> registers for row pair `pr` (x halo patch [4][34][64], dy tile [64 px][64]), zero filled.
+  // VEC path: branch-free clamped loads + validity mask applied at the LDS store (see conv3x3_fwd_kernel).
+  auto gload = [&](int pr) {
     const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
     const float* xb = p.x + (size_t)b * p.H * kW * C;
     const float* dyb = p.dy + ((size_t)b * p.H + h0) * kW * N;
-    __syncthreads();   // previous chunk fully consumed
-    // x halo patch: [4][34][64]
-    for (int slot = tid; slot < (WG_ROWS + 2) * kPW * (WG_T / 4); slot += 256) {
-      const int q = slot & 15, pix = slot >> 4;
-      const int prow = pix / kPW, pcol = pix - prow * kPW;
-      const int hh = h0 + prow - 1, ww = pcol - 1;
-      const int c = c0 + q * 4;
+    if (VEC) {
+      xmask = 0; dmask = 0;
+#pragma unroll
+      for (int i = 0; i < XV; ++i) {
+        const int slot = tid + i * 256;
+        const int q = slot & 15, pix = slot >> 4;
+        const int prow = pix / kPW, pcol = pix - prow * kPW;
+        const int hh = h0 + prow - 1, ww = pcol - 1;
+        const int c = c0 + q * 4;
+        const bool ok = slot < (WG_ROWS + 2) * kPW * (WG_T / 4) && hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C;
+        xreg[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)hh * kW + ww) * C + c : p.x);
+        xmask |= (ok ? 1u : 0u) << i;
+      }
+#pragma unroll
+      for (int i = 0; i < DV; ++i) {
+        const int slot = tid + i * 256;
+        const int q = slot & 15, pix = slot >> 4;
+        const int n = n0 + q * 4;
+        const bool ok = n < N;
+        dreg[i] = *reinterpret_cast<const f32x4*>(ok ? dyb + (size_t)pix * N + n : p.dy);
+        dmask |= (ok ? 1u : 0u) << i;
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int slot = tid + i * 256;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C) {
-        const float* src = xb + ((size_t)hh * kW + ww) * C + c;
-        if (vec_x) {
-          v = *reinterpret_cast<const f32x4*>(src);
-        } else {
-          v[0] = src[0];
-          if (c + 1 < C) v[1] = src[1];
-          if (c + 2 < C) v[2] = src[2];
-          if (c + 3 < C) v[3] = src[3];
+      if (slot < (WG_ROWS + 2) * kPW * (WG_T / 4)) {
+        const int q = slot & 15, pix = slot >> 4;
+        const int prow = pix / kPW, pcol = pix - prow * kPW;
+        const int hh = h0 + prow - 1, ww = pcol - 1;
+        const int c = c0 + q * 4;
+        if (hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C) {
+          const float* src = xb + ((size_t)hh * kW + ww) * C + c;
+          if (vec_x) {
+            v = *reinterpret_cast<const f32x4*>(src);
+          } else {
+            v[0] = src[0];
+            if (c + 1 < C) v[1] = src[1];
+            if (c + 2 < C) v[2] = src[2];
+            if (c + 3 < C) v[3] = src[3];
+          }
         }
       }
-      *reinterpret_cast<f32x4*>(xp + pix * WG_T + q * 4) = v;
+      xreg[i] = v;
     }
-    // dy tile: [64 px][64]
-    for (int slot = tid; slot < WG_ROWS * kW * (WG_T / 4); slot += 256) {
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int slot = tid + i * 256;
       const int q = slot & 15, pix = slot >> 4;
       const int n = n0 + q * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -290,20 +375,61 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
           if (n + 3 < N) v[3] = src[3];
         }
       }
-      *reinterpret_cast<f32x4*>(dyt + pix * WG_T + q * 4) = v;
+      dreg[i] = v;
     }
-    __syncthreads();
-#pragma unroll 4
-    for (int s = 0; s < WG_ROWS * kW / 2; ++s) {
-      const int pix = 2 * s + lh;            // K index = pixel inside the 2-row chunk
-      const int r = pix >> 5, ww = pix & 31;
-      const float bf = dyt[pix * WG_T + wco * 32 + li];
-      const float* xa = xp + (r * kPW + ww) * WG_T + wci * 32 + li;
+  };
+  auto lstore = [&]() {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int kh = t / 3, kw = t - kh * 3;
-        acc[t] = mfma32(xa[(kh * kPW + kw) * WG_T], bf, acc[t]);
+    for (int i = 0; i < XV; ++i) {
+      const int slot = tid + i * 256;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (slot < (WG_ROWS + 2) * kPW * (WG_T / 4))
+        *reinterpret_cast<f32x4*>(xp + slot * 4) = (!VEC || ((xmask >> i) & 1u)) ? xreg[i] : z;
+    }
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(dyt + (tid + i * 256) * 4) = (!VEC || ((dmask >> i) & 1u)) ? dreg[i] : z;
+    }
+  };
+
+  if (pair_begin < pair_end) {
+    gload(pair_begin);
+    lstore();
+  }
+  __syncthreads();
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    const bool has_next = pr + 1 < pair_end;
+    if (has_next) gload(pr + 1);          // in flight during this chunk's 288 MFMAs per wave
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // operands of k-step s+1 are read while the 9 MFMAs of k-step s issue
+      float acur[9], anext[9], bcur, bnext;
+      auto lds_read = [&](int s, float* av, float& bv) {
+        const int pix = 2 * s + lh;          // K index = pixel inside the 2-row chunk
+        const int r = pix >> 5, ww = pix & 31;
+        bv = dyt[pix * WG_T + wco * 32 + li];
+        const float* xa = xp + (r * kPW + ww) * WG_T + wci * 32 + li;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av[t] = xa[((t / 3) * kPW + (t % 3)) * WG_T];
+      };
+      lds_read(0, acur, bcur);
+#pragma unroll 2
+      for (int s = 0; s < WG_ROWS * kW / 2; ++s) {
+        if (s + 1 < WG_ROWS * kW / 2) lds_read(s + 1, anext, bnext);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = mfma32(acur[t], bcur, acc[t]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acur[t] = anext[t];
+        bcur = bnext;
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                       // chunk fully consumed
+    if (has_next) {
+      lstore();
+      __syncthreads();
     }
   }
 
@@ -326,14 +452,23 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   float s = 0.f;
-  for (int i = 0; i < S; ++i) s += slab[(size_t)i * E + e];
+  int i = 0;
+  for (; i + 8 <= S; i += 8) {           // 8 independent loads in flight, summed in index order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(i + u) * E + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < S; ++i) s += slab[(size_t)i * E + e];
   out[e] = accumulate ? out[e] + s : s;
 }
 
 int wgrad_splits(int B, int H, int C, int N) {
   const int tiles = ((C + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
   const int pairs = B * (H / WG_ROWS);
-  int S = 1024 / tiles;             // aim at ~4 resident blocks per CU worth of work
+  const int target = g_mulan_tune[1] > 0 ? g_mulan_tune[1] : 256;   // one fully pipelined block per CU
+  int S = target / tiles;
   if (S < 1) S = 1;
   if (S > pairs) S = pairs;
   // keep at least 4 row pairs per split so the slab traffic stays small next to the MFMA work
@@ -349,16 +484,18 @@ MULAN_API int mulan_conv3x3_fwd(const float* x, const float* w, const float* bia
   if (W != kW || H % TROWS != 0 || B <= 0 || C <= 0 || N <= 0) return (int)hipErrorInvalidValue;
   ConvArgs a{x, w, bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0};
   const int mtiles = B * (H / TROWS);
-  if (N > 64) {
-    dim3 grid(mtiles, (N + 127) / 128);
-    hipLaunchKernelGGL((conv3x3_fwd_kernel<128, 2, 2>), grid, dim3(256), 0, stream, a);
-  } else if (N > 32) {
-    dim3 grid(mtiles, 1);
-    hipLaunchKernelGGL((conv3x3_fwd_kernel<64, 2, 2>), grid, dim3(256), 0, stream, a);
-  } else {
-    dim3 grid(mtiles, 1);
-    hipLaunchKernelGGL((conv3x3_fwd_kernel<32, 4, 1>), grid, dim3(256), 0, stream, a);
-  }
+  const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool vec = (C % 4 == 0) && (N % 4 == 0) && al(x) && al(w);
+#define MULAN_CONV_LAUNCH(BN_, WM_, WN_, GY)                                                              \
+  do {                                                                                                    \
+    dim3 grid(mtiles, GY);                                                                                \
+    if (vec) hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, WM_, WN_, true>), grid, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, WM_, WN_, false>), grid, dim3(256), 0, stream, a);    \
+  } while (0)
+  if (N > 64) MULAN_CONV_LAUNCH(128, 2, 2, (N + 127) / 128);
+  else if (N > 32) MULAN_CONV_LAUNCH(64, 2, 2, 1);
+  else MULAN_CONV_LAUNCH(32, 4, 1, 1);
+#undef MULAN_CONV_LAUNCH
   MULAN_CHECK_LAUNCH();
 }
 
@@ -380,7 +517,11 @@ MULAN_API int mulan_conv3x3_wgrad(const float* x, const float* dy, float* dw, fl
   const int S = wgrad_splits(B, H, C, N);
   WgradArgs a{x, dy, workspace, B, H, C, N, S};
   dim3 grid(S, (C + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T);
-  hipLaunchKernelGGL(conv3x3_wgrad_kernel, grid, dim3(256), 0, stream, a);
+  const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if ((C % 4 == 0) && (N % 4 == 0) && al(x) && al(dy))
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<true>, grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<false>, grid, dim3(256), 0, stream, a);
   const int E = 9 * C * N;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E,
                      accumulate);

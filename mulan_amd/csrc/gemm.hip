@@ -11,6 +11,8 @@
 // k-contiguous operands are staged [row][k] (stride KC+4) and read with ds_read_b128 under the
 // k permutation k = 8c + 4*(lane>>5) + j; k-major operands are staged [k][row] and read with
 // ds_read_b32 under the same permutation, so any TA/TB combination shares one MFMA loop.
+// Long-K / few-tile shapes (weight gradients, K = B*1024) take a split-K path: raw partial slabs +
+// a fixed-order reduce (deterministic, no float atomics).
 #include "common.h"
 
 namespace {
@@ -27,6 +29,9 @@ struct GemmArgs {
   float* ws;                  // [ksplit][M][N] raw partial products
 };
 
+// VEC: both operands have 16-byte aligned rows along their contiguous dimension.  VEC loaders are branch
+// free (clamped address, validity mask applied at the LDS store) so the prefetch never forces a vmcnt(0)
+// in front of the MFMA cluster.
 template <int BM, int BN, int WM, int WN, int TA, int TB, int VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int MT = BM / 32 / WM, NT = BN / 32 / WN;
@@ -55,58 +60,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   constexpr int AV = (BM * KC / 4 + 255) / 256;
   constexpr int BV = (BN * KC / 4 + 255) / 256;
   f32x4 areg[AV], breg[BV];
+  unsigned amask = 0, bmask = 0;
 
-  // Generic tile loader: `rows` x KC tile of a matrix stored either [row][k] (kcontig) or [k][row].
-  auto gload = [&](f32x4* reg, const float* base, int ld, int row0, int rows_total, int k0, bool kcontig,
-                   int TILE, int nslots) {
+  // `TILE` rows x KC tile of a matrix stored either [row][k] (kcontig) or [k][row].
+  auto gload = [&](f32x4* reg, unsigned& mask, const float* base, int ld, int row0, int rows_total, int k0,
+                   bool kcontig, int TILE, int nslots) {
+    mask = 0;
 #pragma unroll
     for (int s = 0; s < nslots; ++s) {
       const int slot = tid + s * 256;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (slot < TILE * KC / 4) {
-        if (kcontig) {
-          const int r = slot / (KC / 4), kq = slot - r * (KC / 4);
-          const int row = row0 + r, k = k0 + kq * 4;
-          if (row < rows_total && k < K) {
-            const float* src = base + (size_t)row * ld + k;
-            if (VEC) {
-              v = *reinterpret_cast<const f32x4*>(src);
-            } else {
-              v[0] = src[0];
-              if (k + 1 < K) v[1] = src[1];
-              if (k + 2 < K) v[2] = src[2];
-              if (k + 3 < K) v[3] = src[3];
-            }
-          }
-        } else {
-          const int k = slot / (TILE / 4), rq = slot - k * (TILE / 4);
-          const int row = row0 + rq * 4, kk = k0 + k;
-          if (kk < K && row < rows_total) {
-            const float* src = base + (size_t)kk * ld + row;
-            if (VEC) {
-              v = *reinterpret_cast<const f32x4*>(src);
-            } else {
-              v[0] = src[0];
-              if (row + 1 < rows_total) v[1] = src[1];
-              if (row + 2 < rows_total) v[2] = src[2];
-              if (row + 3 < rows_total) v[3] = src[3];
-            }
-          }
-        }
+      int row, k;
+      if (kcontig) {
+        const int r = slot / (KC / 4), kq = slot - r * (KC / 4);
+        row = row0 + r; k = k0 + kq * 4;
+      } else {
+        const int kk = slot / (TILE / 4), rq = slot - kk * (TILE / 4);
+        row = row0 + rq * 4; k = k0 + kk;
       }
-      reg[s] = v;
+      const bool ok = slot < TILE * KC / 4 && row < rows_total && k < K;
+      const size_t off = kcontig ? (size_t)row * ld + k : (size_t)k * ld + row;
+      if (VEC) {
+        reg[s] = *reinterpret_cast<const f32x4*>(ok ? base + off : base);
+        mask |= (ok ? 1u : 0u) << s;
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* src = base + off;
+          const int lim = kcontig ? K - k : rows_total - row;    // valid elements along the contiguous dim
+          v[0] = src[0];
+          if (lim > 1) v[1] = src[1];
+          if (lim > 2) v[2] = src[2];
+          if (lim > 3) v[3] = src[3];
+        }
+        reg[s] = v;
+        mask |= 1u << s;
+      }
     }
   };
-  auto lstore = [&](const f32x4* reg, float* dst, bool kcontig, int TILE, int nslots) {
+  auto lstore = [&](const f32x4* reg, unsigned mask, float* dst, bool kcontig, int TILE, int nslots) {
 #pragma unroll
     for (int s = 0; s < nslots; ++s) {
       const int slot = tid + s * 256;
       if (slot < TILE * KC / 4) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = ((mask >> s) & 1u) ? reg[s] : z;
         if (kcontig) {
           const int r = slot / (KC / 4), kq = slot - r * (KC / 4);
-          *reinterpret_cast<f32x4*>(dst + r * KS + kq * 4) = reg[s];
+          *reinterpret_cast<f32x4*>(dst + r * KS + kq * 4) = v;
         } else {
-          *reinterpret_cast<f32x4*>(dst + slot * 4) = reg[s];   // [k][TILE]
+          *reinterpret_cast<f32x4*>(dst + slot * 4) = v;   // [k][TILE]
         }
       }
     }
@@ -115,10 +117,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   const int nk = (K - kbeg + KC - 1) / KC;
   float* As0 = smem;
   float* Bs0 = smem + 2 * A_F;
-  gload(areg, A, p.lda, m0, M, kbeg, !TA, BM, AV);
-  gload(breg, B, p.ldb, n0, N, kbeg, TB, BN, BV);
-  lstore(areg, As0, !TA, BM, AV);
-  lstore(breg, Bs0, TB, BN, BV);
+  gload(areg, amask, A, p.lda, m0, M, kbeg, !TA, BM, AV);
+  gload(breg, bmask, B, p.ldb, n0, N, kbeg, TB, BN, BV);
+  lstore(areg, amask, As0, !TA, BM, AV);
+  lstore(breg, bmask, Bs0, TB, BN, BV);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -126,41 +128,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const float* Bs = Bs0 + (kt & 1) * B_F;
     const bool has_next = kt + 1 < nk;
     if (has_next) {
-      gload(areg, A, p.lda, m0, M, kbeg + (kt + 1) * KC, !TA, BM, AV);
-      gload(breg, B, p.ldb, n0, N, kbeg + (kt + 1) * KC, TB, BN, BV);
+      gload(areg, amask, A, p.lda, m0, M, kbeg + (kt + 1) * KC, !TA, BM, AV);
+      gload(breg, bmask, B, p.ldb, n0, N, kbeg + (kt + 1) * KC, TB, BN, BV);
     }
+    __builtin_amdgcn_sched_barrier(0);     // prefetch loads stay above the MFMA cluster
+    {
+      // b128 fragments of the whole chunk up front; b32 fragments double-buffered one k-step ahead
+      f32x4 a4[KC / 8][MT], b4[KC / 8][NT];
 #pragma unroll
-    for (int k8 = 0; k8 < KC / 8; ++k8) {
-      f32x4 a4[MT], b4[NT];
-      if (!TA) {
+      for (int k8 = 0; k8 < KC / 8; ++k8) {
+        if (!TA) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          a4[mt] = *reinterpret_cast<const f32x4*>(As + ((wm * MT + mt) * 32 + li) * KS + k8 * 8 + 4 * lh);
+          for (int mt = 0; mt < MT; ++mt)
+            a4[k8][mt] = *reinterpret_cast<const f32x4*>(As + ((wm * MT + mt) * 32 + li) * KS + k8 * 8 + 4 * lh);
+        }
+        if (TB) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            b4[k8][nt] = *reinterpret_cast<const f32x4*>(Bs + ((wn * NT + nt) * 32 + li) * KS + k8 * 8 + 4 * lh);
+        }
       }
-      if (TB) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          b4[nt] = *reinterpret_cast<const f32x4*>(Bs + ((wn * NT + nt) * 32 + li) * KS + k8 * 8 + 4 * lh);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      float acur[MT], anext[MT], bcur[NT], bnext[NT];
+      auto frag = [&](int st, float* av, float* bv) {
+        const int k8 = st >> 2, j = st & 3;
         const int kk = k8 * 8 + 4 * lh + j;
-        float af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = TA ? As[kk * BM + (wm * MT + mt) * 32 + li] : a4[k8][mt][j];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = TB ? b4[k8][nt][j] : Bs[kk * BN + (wn * NT + nt) * 32 + li];
+      };
+      frag(0, acur, bcur);
+#pragma unroll
+      for (int st = 0; st < KC / 2; ++st) {
+        if (st + 1 < KC / 2) frag(st + 1, anext, bnext);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          af[mt] = TA ? As[kk * BM + (wm * MT + mt) * 32 + li] : a4[mt][j];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          bf[nt] = TB ? b4[nt][j] : Bs[kk * BN + (wn * NT + nt) * 32 + li];
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(acur[mt], bcur[nt], acc[mt][nt]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) acur[mt] = anext[mt];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(af[mt], bf[nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) bcur[nt] = bnext[nt];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (has_next) {
-      lstore(areg, As0 + ((kt + 1) & 1) * A_F, !TA, BM, AV);
-      lstore(breg, Bs0 + ((kt + 1) & 1) * B_F, TB, BN, BV);
+      lstore(areg, amask, As0 + ((kt + 1) & 1) * A_F, !TA, BM, AV);
+      lstore(breg, bmask, Bs0 + ((kt + 1) & 1) * B_F, TB, BN, BV);
     }
     __syncthreads();
   }
@@ -207,7 +222,15 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
   const size_t E = (size_t)p.M * p.N;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int i = 0; i < p.ksplit; ++i) s += p.ws[(size_t)i * E + e];
+    int i = 0;
+    for (; i + 8 <= p.ksplit; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p.ws[(size_t)(i + u) * E + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < p.ksplit; ++i) s += p.ws[(size_t)i * E + e];
     const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
     float v = p.alpha * s + (p.bias ? p.bias[n] : 0.f);
     if (p.R) v += p.beta * p.R[(size_t)m * p.ldr + n];
@@ -221,7 +244,7 @@ int plan_ksplit(int M, int N, int K, int batch, int* kchunk) {
   if (batch != 1 || K < 4096) return 1;
   const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
   if (tiles >= 256) return 1;
-  int s = (int)(1024 / tiles);
+  int s = (int)(512 / tiles);
   if (s > K / 512) s = K / 512;
   if (s < 2) return 1;
   int kc = ((K + s - 1) / s + 15) / 16 * 16;
@@ -256,26 +279,23 @@ MULAN_API int mulan_gemm(const float* A, const float* B, float* C, const float* 
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return (int)hipErrorInvalidValue;
   GemmArgs a{A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, strideA, strideB, strideC, strideR, alpha, beta,
              1, K, nullptr};
+  // float4 global loads need 16-byte aligned rows along the contiguous dimension of both operands.
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int contigA = transA ? M : K, contigB = transB ? K : N;
+  const int vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (contigA % 4 == 0) && (contigB % 4 == 0) &&
+                  (strideA % 4 == 0) && (strideB % 4 == 0);
   if (workspace) {
     int kc;
     const int s = plan_ksplit(M, N, K, batch, &kc);
     if (s > 1) {
       a.ksplit = s; a.kchunk = kc; a.ws = workspace;
-      const auto al2 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-      const int cA = transA ? M : K, cB = transB ? K : N;
-      const int v = al2(A) && al2(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (cA % 4 == 0) && (cB % 4 == 0);
-      launch<64, 64, 2, 2>(a, transA, transB, v, s, stream);
+      launch<64, 64, 2, 2>(a, transA, transB, vec, s, stream);
       const size_t E = (size_t)M * N;
       const int blocks = (int)((E + 255) / 256 > 2048 ? 2048 : (E + 255) / 256);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
       MULAN_CHECK_LAUNCH();
     }
   }
-  // float4 global loads need 16-byte aligned rows along the contiguous dimension of both operands.
-  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const int contigA = transA ? M : K, contigB = transB ? K : N;
-  const int vec = al(A) && al(B) && (lda % 4 == 0) && (ldb % 4 == 0) && (contigA % 4 == 0) && (contigB % 4 == 0) &&
-                  (strideA % 4 == 0) && (strideB % 4 == 0);
   const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128) * batch;
   if (M >= 128 && N >= 128 && tiles128 >= 256) {
     launch<128, 128, 2, 2>(a, transA, transB, vec, batch, stream);

@@ -101,4 +101,12 @@ MULAN_API int mulan_randn(float* out, size_t n, unsigned long long seed, unsigne
   MULAN_CHECK_LAUNCH();
 }
 
+int g_mulan_tune[16] = {0};
+
+MULAN_API int mulan_set_tuning(int key, int value) {
+  if (key < 0 || key >= 16) return (int)hipErrorInvalidValue;
+  g_mulan_tune[key] = value;
+  return 0;
+}
+
 MULAN_API const char* mulan_version(void) { return "mulan_hip 0.1 (gfx950, fp32 MFMA)"; }

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mulan_adamw_ema_step": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P],
     "mulan_randn": [P, Z, U, U, P],
     "mulan_version": [],
+    "mulan_set_tuning": [I, I],
 }
 _RESTYPES = {"mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_gemm_workspace": c_size_t, "mulan_version": c_char_p}
 

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on one MI355X (HIP events, random data): prints TFLOP/s or GB/s per kernel.
+Usage: python tools/kbench.py [--batch 128] [--reps 20] [--only conv,wgrad,gn,gemm,misc] [--tune k=v,...]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from mulan_amd import ops  # noqa: E402
+from mulan_amd.lib import call, ptr, stream  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="conv,wgrad,gn,gemm,misc")
+    ap.add_argument("--tune", default="")
+    a = ap.parse_args()
+    ops.lib.load()
+    for kv in filter(None, a.tune.split(",")):
+        k, v = kv.split("=")
+        call("mulan_set_tuning", int(k), int(v))
+    B, only = a.batch, set(a.only.split(","))
+    dev = "cuda"
+    r = lambda *s: torch.randn(*s, device=dev)
+    if "conv" in only:
+        for C, N in ((128, 128), (256, 128), (128, 256), (16, 128), (128, 3)):
+            x, w = r(B, 1024, C), r(3, 3, C, N) * 0.05
+            bias, cb, res = r(N), r(B, N), r(B, 1024, N)
+            t = timeit(lambda: ops.conv3x3_raw(x, w, bias, cb, res), a.reps)
+            fl = 2.0 * B * 1024 * 9 * C * N
+            print(f"conv3x3_fwd  C={C:3d} N={N:3d}: {t*1e6:8.1f} us  {fl/t/1e12:7.2f} TFLOP/s  ({fl/t/1e12/157.3*100:5.1f}% of fp32 MFMA peak)")
+    if "wgrad" in only:
+        for C, N in ((128, 128), (256, 128), (16, 128), (128, 3)):
+            x, dy = r(B, 1024, C), r(B, 1024, N)
+            t = timeit(lambda: ops.conv3x3_wgrad_raw(x, dy), a.reps)
+            fl = 2.0 * B * 1024 * 9 * C * N
+            print(f"conv3x3_wgrad C={C:3d} N={N:3d}: {t*1e6:8.1f} us  {fl/t/1e12:7.2f} TFLOP/s  ({fl/t/1e12/157.3*100:5.1f}%)  [incl. slab reduce]")
+    if "gn" in only:
+        for C1, C2 in ((128, 0), (128, 128)):
+            x1 = r(B, 1024, C1)
+            x2 = r(B, 1024, C2) if C2 else None
+            g, b_ = r(C1 + C2), r(C1 + C2)
+            y = torch.empty(B, 1024, C1 + C2, device=dev)
+            mean, rstd = torch.empty(B, 32, device=dev), torch.empty(B, 32, device=dev)
+            f = lambda keep: call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(g), ptr(b_), ptr(y), ptr(mean),
+                                  ptr(rstd), B, 1024, 32, 1e-6, 1, keep, 123, 0, stream())
+            for keep in (1.0, 0.9):
+                t = timeit(lambda: f(keep), a.reps)
+                by = 2.0 * B * 1024 * (C1 + C2) * 4
+                print(f"groupnorm_fwd C={C1}+{C2} keep={keep}: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s algorithmic")
+            dy = r(B, 1024, C1 + C2)
+            dx1 = torch.empty_like(x1)
+            dx2 = torch.empty_like(x2) if C2 else None
+            dgp, dbp = torch.empty(B, C1 + C2, device=dev), torch.empty(B, C1 + C2, device=dev)
+            fb = lambda: call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(g), ptr(b_), ptr(mean),
+                              ptr(rstd), ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, 1024, 32, 1, 0.9, 123, 0, 0, stream())
+            t = timeit(fb, a.reps)
+            by = 3.0 * B * 1024 * (C1 + C2) * 4
+            print(f"groupnorm_bwd C={C1}+{C2} keep=0.9: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s algorithmic (x, dy -> dx)")
+    if "gemm" in only:
+        M = B * 1024
+        for (m, n, k, ta, tb, tag) in ((M, 128, 128, 0, 0, "nin/qkv fwd"), (M, 128, 128, 0, 1, "dx"),
+                                       (128, 128, M, 1, 0, "dW split-K"), (B, 3072, 3072, 0, 0, "gamma MLP"),
+                                       (B, 128, 512, 0, 0, "cond_proj")):
+            A = r(k, m) if ta else r(m, k)
+            Bm = r(n, k) if tb else r(k, n)
+            t = timeit(lambda: ops.gemm_raw(A, Bm, m, n, k, transA=bool(ta), transB=bool(tb)), a.reps)
+            fl = 2.0 * m * n * k
+            print(f"gemm {tag:12s} M={m} N={n} K={k} ta={ta} tb={tb}: {t*1e6:8.1f} us  {fl/t/1e12:7.2f} TFLOP/s")
+        S, C = 1024, 128
+        q, k_, v = r(B, S, C), r(B, S, C), r(B, S, C)
+        t = timeit(lambda: ops.AttentionFn.apply(q, k_, v), max(2, a.reps // 4))
+        print(f"attention fwd B={B}: {t*1e6:8.1f} us  {4.0*B*S*S*C/t/1e12:7.2f} TFLOP/s")
+    if "misc" in only:
+        dy = r(B * 1024, 128)
+        t = timeit(lambda: ops.colsum_raw(dy, B, 1024, 128), a.reps)
+        print(f"colsum per-sample: {t*1e6:8.1f} us  {dy.numel()*4/t/1e9:8.1f} GB/s")
+        t = timeit(lambda: ops.colsum_raw(dy, 1, B * 1024, 128), a.reps)
+        print(f"colsum total     : {t*1e6:8.1f} us  {dy.numel()*4/t/1e9:8.1f} GB/s")
+        n = 71_200_000
+        p, g, m_, v_, e_ = (torch.randn(n, device=dev) for _ in range(5))
+        v_.abs_()
+        t = timeit(lambda: ops.adamw_ema_step(p, g, m_, v_, e_, n - 100000, 2e-4, 0.9, 0.99, 1e-8, 0.01, 5, 0.9999), a.reps)
+        print(f"adamw_ema 71.2M  : {t*1e6:8.1f} us  {36.0*n/t/1e9:8.1f} GB/s algorithmic (36 B/param)")
+
+
+if __name__ == "__main__":
+    main()
