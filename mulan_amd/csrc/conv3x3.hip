@@ -33,16 +33,20 @@ struct ConvArgs {
 // VEC: C % 4 == 0 and N % 4 == 0.  The VEC loaders are branch free (clamped address + validity mask applied at
 // the LDS store): a divergent branch around a prefetch load makes hipcc wait vmcnt(0) right after issuing it,
 // which serialises the global-load latency in front of every MFMA cluster.
-template <int BN, int WM, int WN, bool VEC>
+// TPS: taps per pipeline stage (1 or 3): one __syncthreads() per TPS*32 MFMAs per wave.
+template <int BN, int WM, int WN, bool VEC, int TPS>
 __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
   constexpr int MT = TROWS / WM;        // image rows per wave
   constexpr int NT = BN / 32 / WN;      // 32-wide cout tiles per wave
-  constexpr int WT_F = CK * BN;         // floats per weight buffer
+  constexpr int WT1 = CK * BN;          // floats per tap tile
+  constexpr int WT_F = TPS * WT1;       // floats per weight buffer
+  constexpr int NSG = 9 / TPS;          // stages per channel chunk
+  constexpr int NPB = TPS == 1 ? 2 : 1; // patch buffers (single buffer when the weight stage is large)
   constexpr int WV = (WT_F / 4 + 255) / 256;  // float4 weight slots per thread
   constexpr int PV = (PATCH_F / PS * (CK / 4) + 255) / 256;  // float4 patch slots per thread (4)
-  __shared__ __attribute__((aligned(16))) float smem[2 * PATCH_F + 2 * WT_F];
+  __shared__ __attribute__((aligned(16))) float smem[NPB * PATCH_F + 2 * WT_F];
   float* pbuf0 = smem;
-  float* wbuf0 = smem + 2 * PATCH_F;
+  float* wbuf0 = smem + NPB * PATCH_F;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -122,13 +126,15 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
       }
     }
   };
-  auto gload_w = [&](int cc, int tap) {
+  auto gload_w = [&](int cc, int sg) {
     if (VEC) {
       wmask = 0;
 #pragma unroll
       for (int s = 0; s < WV; ++s) {
         const int slot = tid + s * 256;
-        const int k = slot / (BN / 4), nq = slot - k * (BN / 4);
+        const int tl = slot / (WT1 / 4), rs = slot - tl * (WT1 / 4);
+        const int tap = sg * TPS + tl;
+        const int k = rs / (BN / 4), nq = rs - k * (BN / 4);
         const int c = cc * CK + k, n = n0 + nq * 4;
         const bool ok = slot < WT_F / 4 && c < C && n < N;
         const float* src = ok ? p.w + ((size_t)tap * C + c) * N + n : p.w;
@@ -142,7 +148,9 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
       const int slot = tid + s * 256;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (slot < WT_F / 4) {
-        const int k = slot / (BN / 4), nq = slot - k * (BN / 4);
+        const int tl = slot / (WT1 / 4), rs = slot - tl * (WT1 / 4);
+        const int tap = sg * TPS + tl;
+        const int k = rs / (BN / 4), nq = rs - k * (BN / 4);
         const int c = cc * CK + k, n = n0 + nq * 4;
         if (c < C && n < N) {
           const float* src = p.w + ((size_t)tap * C + c) * N + n;
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
     }
   };
 
-  // prologue: stage chunk 0 / tap 0
+  // prologue: stage chunk 0 / stage 0
   gload_patch(0);
   gload_w(0, 0);
   store_patch(pbuf0);
@@ -177,24 +185,28 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
 
   int step = 0;
   for (int cc = 0; cc < nchunks; ++cc) {
-    const float* pb = pbuf0 + (cc & 1) * PATCH_F;
+    const float* pb = pbuf0 + (NPB == 2 ? (cc & 1) * PATCH_F : 0);
     const bool more_chunks = cc + 1 < nchunks;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int kh = tap / 3, kw = tap - kh * 3;
-      const float* wb = wbuf0 + (step & 1) * WT_F;
+    for (int sg = 0; sg < NSG; ++sg, ++step) {
+      const float* wbs = wbuf0 + (step & 1) * WT_F;
       float* wb_next = wbuf0 + ((step + 1) & 1) * WT_F;
-      const bool has_next = (tap < 8) || more_chunks;
+      const bool last_sg = sg == NSG - 1;
+      const bool has_next = !last_sg || more_chunks;
       if (has_next) {
-        if (tap < 8) gload_w(cc, tap + 1); else gload_w(cc + 1, 0);
+        if (!last_sg) gload_w(cc, sg + 1); else gload_w(cc + 1, 0);
       }
-      if (tap == 7 && more_chunks) gload_patch(cc + 1);
+      if (last_sg && more_chunks) gload_patch(cc + 1);
       // keep the prefetch loads above and their LDS stores below the MFMA cluster (hipcc otherwise sinks a
       // load past the cluster and exposes its latency in front of the barrier)
       __builtin_amdgcn_sched_barrier(0);
 
-      {
-        // A fragments of the whole stage up front (ds_read_b128), B fragments double-buffered one k-step
+#pragma unroll
+      for (int tl = 0; tl < TPS; ++tl) {
+        const int tap = sg * TPS + tl;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const float* wb = wbs + tl * WT1;
+        // A fragments of the whole tap up front (ds_read_b128), B fragments double-buffered one k-step
         // ahead (ds_read_b32) so no MFMA group waits on an LDS read issued right in front of it.
         f32x4 a4[CK / 8][MT];
 #pragma unroll
@@ -227,8 +239,16 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
 
       __builtin_amdgcn_sched_barrier(0);
       if (has_next) store_w(wb_next);
-      if (tap == 8 && more_chunks) store_patch(pbuf0 + ((cc + 1) & 1) * PATCH_F);
-      __syncthreads();
+      if (NPB == 2) {
+        if (last_sg && more_chunks) store_patch(pbuf0 + ((cc + 1) & 1) * PATCH_F);
+        __syncthreads();
+      } else {
+        __syncthreads();
+        if (last_sg && more_chunks) {     // single patch buffer: overwrite only after every wave left this chunk
+          store_patch(pbuf0);
+          __syncthreads();
+        }
+      }
     }
   }
 
@@ -414,15 +434,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
         for (int t = 0; t < 9; ++t) av[t] = xa[((t / 3) * kPW + (t % 3)) * WG_T];
       };
       lds_read(0, acur, bcur);
-#pragma unroll 2
-      for (int s = 0; s < WG_ROWS * kW / 2; ++s) {
-        if (s + 1 < WG_ROWS * kW / 2) lds_read(s + 1, anext, bnext);
+      // explicit ping-pong (no register copies): the reads of k-step s+1 are in flight during step s's 9 MFMAs
+      for (int s = 0; s < WG_ROWS * kW / 2; s += 2) {
+        lds_read(s + 1, anext, bnext);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] = mfma32(acur[t], bcur, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < WG_ROWS * kW / 2) lds_read(s + 2, acur, bcur);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acur[t] = anext[t];
-        bcur = bnext;
+        for (int t = 0; t < 9; ++t) acc[t] = mfma32(anext[t], bnext, acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -489,10 +512,13 @@ MULAN_API int mulan_conv3x3_fwd(const float* x, const float* w, const float* bia
 #define MULAN_CONV_LAUNCH(BN_, WM_, WN_, GY)                                                              \
   do {                                                                                                    \
     dim3 grid(mtiles, GY);                                                                                \
-    if (vec) hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, WM_, WN_, true>), grid, dim3(256), 0, stream, a); \
-    else hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, WM_, WN_, false>), grid, dim3(256), 0, stream, a);    \
+    if (vec) hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, WM_, WN_, true, 1>), grid, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((conv3x3_fwd_kernel<BN_, WM_, WN_, false, 1>), grid, dim3(256), 0, stream, a);    \
   } while (0)
-  if (N > 64) MULAN_CONV_LAUNCH(128, 2, 2, (N + 127) / 128);
+  if (N > 64 && vec && g_mulan_tune[0] == 3) {
+    dim3 grid(mtiles, (N + 127) / 128);
+    hipLaunchKernelGGL((conv3x3_fwd_kernel<128, 2, 2, true, 3>), grid, dim3(256), 0, stream, a);
+  } else if (N > 64) MULAN_CONV_LAUNCH(128, 2, 2, (N + 127) / 128);
   else if (N > 32) MULAN_CONV_LAUNCH(64, 2, 2, 1);
   else MULAN_CONV_LAUNCH(32, 4, 1, 1);
 #undef MULAN_CONV_LAUNCH
