@@ -32,6 +32,8 @@ extern "C" {
 const char* mulan_version(void);
 /* developer knob for kernel-variant A/B runs (tools/kbench.py); never needed in production */
 int mulan_set_tuning(int key, int value);
+/* dev-only: device buffer (>= 64 x u64) that receives s_memtime stamps of block 0; NULL (default) disables */
+int mulan_set_debug_buffer(void* dev_ptr);
 
 /* ---- 3x3 SAME convolution, NHWC, HWIO weights [3,3,C,N] --------------------------------------
  * flax nn.Conv(kernel_size=(3,3)) in ResnetBlock conv1/conv2 (ldm/model_vdm.py:633-634,645-650;

@@ -12,6 +12,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // developer tuning knobs (mulan_set_tuning): [0] conv fwd variant, [1] wgrad resident-block target
 extern int g_mulan_tune[16];
+extern unsigned long long* g_mulan_debug_buffer;   // dev-only stamp buffer (>= 64 u64), normally null
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
 // D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] lives in accumulator register r (0..15).

@@ -28,7 +28,14 @@ struct ConvArgs {
   const float* res;    // [B,H,32,N] or null
   float* y;            // [B,H,32,N]
   int B, H, C, N, cbias_mode;
+  unsigned long long* stamps;   // dev-only: s_memtime stamps of block 0 / wave 0 (mulan_set_debug_buffer), else null
 };
+
+#define MULAN_STAMP(i)                                                                   \
+  do {                                                                                   \
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)              \
+      p.stamps[i] = __builtin_amdgcn_s_memtime();                                        \
+  } while (0)
 
 // VEC: C % 4 == 0 and N % 4 == 0.  The VEC loaders are branch free (clamped address + validity mask applied at
 // the LDS store): a divergent branch around a prefetch load makes hipcc wait vmcnt(0) right after issuing it,
@@ -74,19 +81,45 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
   f32x4 wreg[WV];
   unsigned pmask = 0, wmask = 0;   // validity bits of the prefetched slots (VEC path)
 
+  // VEC path: everything about a thread's prefetch slots that does not change from stage to stage is computed
+  // once here, so a stage's prefetch costs a handful of instructions (address arithmetic issued in front of an
+  // MFMA cluster is directly exposed: the probe in tools/mfma_probe.hip runs this loop shape at ~90 % of peak).
+  const float* pptr[PV];
+  const float* wptr[WV];
+  unsigned phalo = 0, wnok = 0;
+  int wk[WV];
+  if (VEC) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) {
+      const int slot = tid + s * 256;
+      const int q = slot & 3, pix = slot >> 2;
+      const int prow = pix / kPW, pcol = pix - prow * kPW;
+      const int hh = h0 + prow - 1, ww = pcol - 1;
+      const bool ok = slot < (TROWS + 2) * kPW * (CK / 4) && hh >= 0 && hh < p.H && ww >= 0 && ww < kW;
+      pptr[s] = ok ? xb + ((size_t)hh * kW + ww) * C + q * 4 : p.x;
+      phalo |= (ok ? 1u : 0u) << s;
+    }
+#pragma unroll
+    for (int s = 0; s < WV; ++s) {
+      const int slot = tid + s * 256;
+      const int tl = slot / (WT1 / 4), rs = slot - tl * (WT1 / 4);
+      const int k = rs / (BN / 4), nq = rs - k * (BN / 4);
+      const int n = n0 + nq * 4;
+      const bool ok = slot < WT_F / 4 && n < N;
+      wptr[s] = ok ? p.w + ((size_t)tl * C + k) * N + n : p.w;
+      wnok |= (ok ? 1u : 0u) << s;
+      wk[s] = k;
+    }
+  }
+
   auto gload_patch = [&](int cc) {
     if (VEC) {
       pmask = 0;
+      const int c0 = cc * CK;
 #pragma unroll
       for (int s = 0; s < PV; ++s) {
-        const int slot = tid + s * 256;
-        const int q = slot & 3, pix = slot >> 2;
-        const int prow = pix / kPW, pcol = pix - prow * kPW;
-        const int hh = h0 + prow - 1, ww = pcol - 1;
-        const int c = cc * CK + q * 4;
-        const bool ok = slot < (TROWS + 2) * kPW * (CK / 4) && hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C;
-        const float* src = ok ? xb + ((size_t)hh * kW + ww) * C + c : p.x;
-        preg[s] = *reinterpret_cast<const f32x4*>(src);
+        const bool ok = ((phalo >> s) & 1u) && (c0 + (int)(((tid + s * 256) & 3) * 4) < C);
+        preg[s] = *reinterpret_cast<const f32x4*>(ok ? pptr[s] + c0 : p.x);
         pmask |= (ok ? 1u : 0u) << s;
       }
       return;
@@ -129,16 +162,12 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
   auto gload_w = [&](int cc, int sg) {
     if (VEC) {
       wmask = 0;
+      const int c0 = cc * CK;
+      const size_t off = ((size_t)(sg * TPS) * C + c0) * N;   // wave uniform
 #pragma unroll
       for (int s = 0; s < WV; ++s) {
-        const int slot = tid + s * 256;
-        const int tl = slot / (WT1 / 4), rs = slot - tl * (WT1 / 4);
-        const int tap = sg * TPS + tl;
-        const int k = rs / (BN / 4), nq = rs - k * (BN / 4);
-        const int c = cc * CK + k, n = n0 + nq * 4;
-        const bool ok = slot < WT_F / 4 && c < C && n < N;
-        const float* src = ok ? p.w + ((size_t)tap * C + c) * N + n : p.w;
-        wreg[s] = *reinterpret_cast<const f32x4*>(src);
+        const bool ok = ((wnok >> s) & 1u) && (c0 + wk[s] < C);
+        wreg[s] = *reinterpret_cast<const f32x4*>(ok ? wptr[s] + off : p.w);
         wmask |= (ok ? 1u : 0u) << s;
       }
       return;
@@ -176,6 +205,8 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
     }
   };
 
+  MULAN_STAMP(0);
+  if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[30] = __builtin_amdgcn_s_memrealtime();
   // prologue: stage chunk 0 / stage 0
   gload_patch(0);
   gload_w(0, 0);
@@ -183,8 +214,10 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
   store_w(wbuf0);
   __syncthreads();
 
+  MULAN_STAMP(1);
   int step = 0;
   for (int cc = 0; cc < nchunks; ++cc) {
+    if (cc < 20) MULAN_STAMP(2 + cc);
     const float* pb = pbuf0 + (NPB == 2 ? (cc & 1) * PATCH_F : 0);
     const bool more_chunks = cc + 1 < nchunks;
 #pragma unroll
@@ -193,13 +226,6 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
       float* wb_next = wbuf0 + ((step + 1) & 1) * WT_F;
       const bool last_sg = sg == NSG - 1;
       const bool has_next = !last_sg || more_chunks;
-      if (has_next) {
-        if (!last_sg) gload_w(cc, sg + 1); else gload_w(cc + 1, 0);
-      }
-      if (last_sg && more_chunks) gload_patch(cc + 1);
-      // keep the prefetch loads above and their LDS stores below the MFMA cluster (hipcc otherwise sinks a
-      // load past the cluster and exposes its latency in front of the barrier)
-      __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
       for (int tl = 0; tl < TPS; ++tl) {
@@ -227,6 +253,16 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bnext[nt] = wb[kk * BN + (wn * NT + nt) * 32 + li];
           }
+          if (tl == 0 && st == 1) {
+            // next stage's prefetch is issued behind the first MFMA group so its address arithmetic runs in the
+            // shadow of the matrix pipe; pinned here (hipcc otherwise sinks a load past the cluster and exposes
+            // its latency in front of the barrier)
+            if (has_next) {
+              if (!last_sg) gload_w(cc, sg + 1); else gload_w(cc + 1, 0);
+            }
+            // the next chunk's activation patch comes from HBM (several us): request it a whole chunk ahead
+            if (sg == 0 && more_chunks) gload_patch(cc + 1);
+          }
           __builtin_amdgcn_sched_barrier(0);   // the read of step st+1 stays in front of step st's MFMAs
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
@@ -252,25 +288,92 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_kernel(ConvArgs p) {
     }
   }
 
+  MULAN_STAMP(22);
   // epilogue
+  const float* __restrict__ res = p.res;
+  const float* __restrict__ cbp = p.cbias;
+  float* __restrict__ yout = p.y;
+  if (VEC && NT == 2 && MT >= 1) {
+    // Transposed through LDS so every lane moves float4s: a wave instruction covers 4 pixels x 256 contiguous
+    // bytes (the accumulator layout itself would need 64 dword loads + 64 dword stores per lane).
+    constexpr int TS = 64 + 4;                       // staging row stride (floats), 16-byte aligned rows
+    float* stage = smem + wave * 32 * TS;            // one 32 px x 64 cout tile per wave
+    const int c4 = lane & 15, prl = lane >> 4;       // float4 column, pixel sub-row
+    const int nb = n0 + wn * 64 + c4 * 4;
+    const bool nok = nb < N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (nok) {
+      if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+      if (p.cbias_mode == 1) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + (size_t)b * N + nb);
+        bias4[0] += c[0]; bias4[1] += c[1]; bias4[2] += c[2]; bias4[3] += c[3];
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      __syncthreads();                               // previous users of this LDS region are done
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = acc[mt][nt][r];
+      __syncthreads();
+      const int hh = h0 + wm * MT + mt;
+      const size_t rowbase = (((size_t)b * p.H + hh) * kW) * N + nb;
+      f32x4 add[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) add[it] = bias4;
+      if (nok && p.cbias_mode == 2) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + rowbase + (size_t)(it * 4 + prl) * N);
+          add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+        }
+      }
+      if (nok && res) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(res + rowbase + (size_t)(it * 4 + prl) * N);
+          add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+        }
+      }
+      if (nok) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(stage + (it * 4 + prl) * TS + c4 * 4);
+          const f32x4 o = {a[0] + add[it][0], a[1] + add[it][1], a[2] + add[it][2], a[3] + add[it][3]};
+          *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * N) = o;
+        }
+      }
+    }
+    MULAN_STAMP(23);
+    if (p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.stamps[31] = __builtin_amdgcn_s_memrealtime();
+    return;
+  }
+  // generic epilogue: the loads of a whole 32x32 tile are issued before any store (the __restrict__ copies let
+  // hipcc do that; otherwise it serialises load -> wait -> store per element, 64 dependent round trips per block)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + (wn * NT + nt) * 32 + li;
     if (n >= N) continue;
     const float bv = p.bias ? p.bias[n] : 0.f;
-    const float cb1 = (p.cbias_mode == 1) ? p.cbias[(size_t)b * N + n] : 0.f;
+    const float cb1 = (p.cbias_mode == 1) ? cbp[(size_t)b * N + n] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int hh = h0 + wm * MT + mt;
+      const size_t rowbase = (((size_t)b * p.H + hh) * kW) * N + n;
+      float add[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ww = mfma32_row(r, lane);
-        const size_t o = (((size_t)b * p.H + hh) * kW + ww) * N + n;
-        float v = acc[mt][nt][r] + bv + cb1;
-        if (p.cbias_mode == 2) v += p.cbias[o];
-        if (p.res) v += p.res[o];
-        p.y[o] = v;
+      for (int r = 0; r < 16; ++r) add[r] = bv + cb1;
+      if (p.cbias_mode == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] += cbp[rowbase + (size_t)mfma32_row(r, lane) * N];
       }
+      if (res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] += res[rowbase + (size_t)mfma32_row(r, lane) * N];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yout[rowbase + (size_t)mfma32_row(r, lane) * N] = acc[mt][nt][r] + add[r];
     }
   }
 }
@@ -325,6 +428,31 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
   constexpr int DV = (WG_ROWS * kW * (WG_T / 4) + 255) / 256;           // 4
   f32x4 xreg[XV], dreg[DV];
   unsigned xmask = 0, dmask = 0;
+  // chunk-invariant part of the prefetch addressing (VEC path), see conv3x3_fwd_kernel
+  int xoff[XV], doff[DV];
+  unsigned xstat = 0, xtop = 0, xbot = 0, dstat = 0;
+  if (VEC) {
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int slot = tid + i * 256;
+      const int q = slot & 15, pix = slot >> 4;
+      const int prow = pix / kPW, pcol = pix - prow * kPW;
+      const int ww = pcol - 1, c = c0 + q * 4;
+      const bool ok = slot < (WG_ROWS + 2) * kPW * (WG_T / 4) && ww >= 0 && ww < kW && c < C;
+      xoff[i] = ((prow - 1) * kW + ww) * C + c;
+      xstat |= (ok ? 1u : 0u) << i;
+      xtop |= (prow == 0 ? 1u : 0u) << i;
+      xbot |= (prow == WG_ROWS + 1 ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const int slot = tid + i * 256;
+      const int q = slot & 15, pix = slot >> 4;
+      const int n = n0 + q * 4;
+      doff[i] = pix * N + n;
+      dstat |= (n < N ? 1u : 0u) << i;
+    }
+  }
   // global -> registers for row pair `pr` (x halo patch [4][34][64], dy tile [64 px][64]), zero filled.
   // VEC path: branch-free clamped loads + validity mask applied at the LDS store (see conv3x3_fwd_kernel).
   auto gload = [&](int pr) {
@@ -332,27 +460,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
     const float* xb = p.x + (size_t)b * p.H * kW * C;
     const float* dyb = p.dy + ((size_t)b * p.H + h0) * kW * N;
     if (VEC) {
-      xmask = 0; dmask = 0;
+      // per-slot offsets / static validity were computed once (xoff, doff, xstat, xtop, xbot, dstat)
+      const float* xrow = xb + (size_t)h0 * kW * C;
+      xmask = xstat & ~(h0 == 0 ? xtop : 0u) & ~(h0 + WG_ROWS >= p.H ? xbot : 0u);
+      dmask = dstat;
 #pragma unroll
-      for (int i = 0; i < XV; ++i) {
-        const int slot = tid + i * 256;
-        const int q = slot & 15, pix = slot >> 4;
-        const int prow = pix / kPW, pcol = pix - prow * kPW;
-        const int hh = h0 + prow - 1, ww = pcol - 1;
-        const int c = c0 + q * 4;
-        const bool ok = slot < (WG_ROWS + 2) * kPW * (WG_T / 4) && hh >= 0 && hh < p.H && ww >= 0 && ww < kW && c < C;
-        xreg[i] = *reinterpret_cast<const f32x4*>(ok ? xb + ((size_t)hh * kW + ww) * C + c : p.x);
-        xmask |= (ok ? 1u : 0u) << i;
-      }
+      for (int i = 0; i < XV; ++i)
+        xreg[i] = *reinterpret_cast<const f32x4*>(((xmask >> i) & 1u) ? xrow + xoff[i] : p.x);
 #pragma unroll
-      for (int i = 0; i < DV; ++i) {
-        const int slot = tid + i * 256;
-        const int q = slot & 15, pix = slot >> 4;
-        const int n = n0 + q * 4;
-        const bool ok = n < N;
-        dreg[i] = *reinterpret_cast<const f32x4*>(ok ? dyb + (size_t)pix * N + n : p.dy);
-        dmask |= (ok ? 1u : 0u) << i;
-      }
+      for (int i = 0; i < DV; ++i)
+        dreg[i] = *reinterpret_cast<const f32x4*>(((dmask >> i) & 1u) ? dyb + doff[i] : p.dy);
       return;
     }
 #pragma unroll
@@ -505,7 +622,7 @@ MULAN_API int mulan_conv3x3_fwd(const float* x, const float* w, const float* bia
                                 int cbias_mode, const float* res, float* y, int B, int H, int W, int C, int N,
                                 hipStream_t stream) {
   if (W != kW || H % TROWS != 0 || B <= 0 || C <= 0 || N <= 0) return (int)hipErrorInvalidValue;
-  ConvArgs a{x, w, bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0};
+  ConvArgs a{x, w, bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0, g_mulan_debug_buffer};
   const int mtiles = B * (H / TROWS);
   const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec = (C % 4 == 0) && (N % 4 == 0) && al(x) && al(w);

@@ -62,6 +62,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   f32x4 areg[AV], breg[BV];
   unsigned amask = 0, bmask = 0;
 
+  // chunk-invariant part of the prefetch addressing (VEC path): per-slot pointer at k = 0, row validity and the
+  // slot's k offset inside a chunk, so each chunk's prefetch is a pointer bump + one compare per slot
+  const float* aptr[AV]; const float* bptr[BV];
+  int ako[AV], bko[BV];
+  unsigned arow = 0, brow = 0;
+  auto setup = [&](const float** ptr, int* ko, unsigned& rowok, const float* base, int ld, int row0, int rows_total,
+                   bool kcontig, int TILE, int nslots) {
+#pragma unroll
+    for (int s = 0; s < nslots; ++s) {
+      const int slot = tid + s * 256;
+      int row, k;
+      if (kcontig) {
+        const int r = slot / (KC / 4), kq = slot - r * (KC / 4);
+        row = row0 + r; k = kq * 4;
+      } else {
+        const int kk = slot / (TILE / 4), rq = slot - kk * (TILE / 4);
+        row = row0 + rq * 4; k = kk;
+      }
+      const bool ok = slot < TILE * KC / 4 && row < rows_total;
+      ptr[s] = ok ? base + (kcontig ? (size_t)row * ld + k : (size_t)k * ld + row) : base;
+      ko[s] = k;
+      rowok |= (ok ? 1u : 0u) << s;
+    }
+  };
+  if (VEC) {
+    setup(aptr, ako, arow, A, p.lda, m0, M, !TA, BM, AV);
+    setup(bptr, bko, brow, B, p.ldb, n0, N, TB, BN, BV);
+  }
+  auto gload_fast = [&](f32x4* reg, unsigned& mask, const float* const* ptr, const int* ko, unsigned rowok,
+                        const float* base, int ld, int k0, bool kcontig, int nslots) {
+    mask = 0;
+    const size_t step = kcontig ? (size_t)k0 : (size_t)k0 * ld;   // wave uniform
+#pragma unroll
+    for (int s = 0; s < nslots; ++s) {
+      const bool ok = ((rowok >> s) & 1u) && (k0 + ko[s] < K);
+      reg[s] = *reinterpret_cast<const f32x4*>(ok ? ptr[s] + step : base);
+      mask |= (ok ? 1u : 0u) << s;
+    }
+  };
+
   // `TILE` rows x KC tile of a matrix stored either [row][k] (kcontig) or [k][row].
   auto gload = [&](f32x4* reg, unsigned& mask, const float* base, int ld, int row0, int rows_total, int k0,
                    bool kcontig, int TILE, int nslots) {
@@ -128,8 +168,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const float* Bs = Bs0 + (kt & 1) * B_F;
     const bool has_next = kt + 1 < nk;
     if (has_next) {
-      gload(areg, amask, A, p.lda, m0, M, kbeg + (kt + 1) * KC, !TA, BM, AV);
-      gload(breg, bmask, B, p.ldb, n0, N, kbeg + (kt + 1) * KC, TB, BN, BV);
+      if (VEC) {
+        gload_fast(areg, amask, aptr, ako, arow, A, p.lda, kbeg + (kt + 1) * KC, !TA, AV);
+        gload_fast(breg, bmask, bptr, bko, brow, B, p.ldb, kbeg + (kt + 1) * KC, TB, BV);
+      } else {
+        gload(areg, amask, A, p.lda, m0, M, kbeg + (kt + 1) * KC, !TA, BM, AV);
+        gload(breg, bmask, B, p.ldb, n0, N, kbeg + (kt + 1) * KC, TB, BN, BV);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);     // prefetch loads stay above the MFMA cluster
     {
@@ -196,24 +241,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
     return;
   }
-  float* Cb = p.C + (size_t)bz * p.sC;
-  const float* Rb = p.R ? p.R + (size_t)bz * p.sR : nullptr;
+  // residual loads of a whole tile are issued before its stores (see conv3x3_fwd_kernel's epilogue)
+  float* __restrict__ Cb = p.C + (size_t)bz * p.sC;
+  const float* __restrict__ Rb = p.R ? p.R + (size_t)bz * p.sR : nullptr;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + (wn * NT + nt) * 32 + li;
     if (n >= N) continue;
     const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+      const int mb = m0 + (wm * MT + mt) * 32;
+      float add[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * MT + mt) * 32 + mfma32_row(r, lane);
-        if (m < M) {
-          float v = p.alpha * acc[mt][nt][r] + bv;
-          if (Rb) v += p.beta * Rb[(size_t)m * p.ldr + n];
-          Cb[(size_t)m * p.ldc + n] = v;
+      for (int r = 0; r < 16; ++r) add[r] = bv;
+      if (Rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + mfma32_row(r, lane);
+          if (m < M) add[r] += p.beta * Rb[(size_t)m * p.ldr + n];
         }
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mb + mfma32_row(r, lane);
+        if (m < M) Cb[(size_t)m * p.ldc + n] = p.alpha * acc[mt][nt][r] + add[r];
+      }
+    }
   }
 }
 

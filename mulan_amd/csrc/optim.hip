@@ -102,6 +102,12 @@ MULAN_API int mulan_randn(float* out, size_t n, unsigned long long seed, unsigne
 }
 
 int g_mulan_tune[16] = {0};
+unsigned long long* g_mulan_debug_buffer = nullptr;
+
+MULAN_API int mulan_set_debug_buffer(void* dev_ptr) {
+  g_mulan_debug_buffer = static_cast<unsigned long long*>(dev_ptr);
+  return 0;
+}
 
 MULAN_API int mulan_set_tuning(int key, int value) {
   if (key < 0 || key >= 16) return (int)hipErrorInvalidValue;

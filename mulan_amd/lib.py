@@ -47,6 +47,7 @@ SIGNATURES = {
     "mulan_randn": [P, Z, U, U, P],
     "mulan_version": [],
     "mulan_set_tuning": [I, I],
+    "mulan_set_debug_buffer": [P],
 }
 _RESTYPES = {"mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_gemm_workspace": c_size_t, "mulan_version": c_char_p}
 
