@@ -111,6 +111,10 @@ int mulan_poly_gamma_fwd(const float* a, const float* b, const float* c, const f
 int mulan_poly_gamma_bwd(const float* a, const float* b, const float* c, const float* t, const float* dgt,
                          const float* dgprime, float* da, float* db, float* dc, int B, int d, float gamma_min,
                          float gamma_max, mulan_stream_t stream);
+/* discrete-time (T > 0) loss weight w = T * expm1(gamma_t - gamma_s) (model_mulan_epsilon.py:348-355) */
+int mulan_expm1_weight_fwd(const float* gt, const float* gs, float* w, size_t n, float T, mulan_stream_t stream);
+int mulan_expm1_weight_bwd(const float* gt, const float* gs, const float* dw, float* dgt, float* dgs, size_t n,
+                           float T, mulan_stream_t stream);
 /* VDM.__call__ up to the score-model call (model_mulan_velocity.py:208-236, model_mulan_epsilon.py:300-328,
  * model_vdm.py:119-151) with EncDec.encode/decode/logprob (model_vdm.py:274-303) fused in.
  * per_element_gamma: g* are [B,d] (MuLAN) or [B] (scalar schedule of model_vdm.VDM). */

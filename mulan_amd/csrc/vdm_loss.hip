@@ -71,6 +71,22 @@ __global__ void poly_gamma_bwd_kernel(const float* __restrict__ a, const float* 
   }
 }
 
+// discrete-time loss weight  w = T * expm1(gamma_t - gamma_s)   (ldm/model_mulan_epsilon.py:348-355, model_vdm.py:162-170)
+__global__ void expm1_weight_fwd_kernel(const float* __restrict__ gt, const float* __restrict__ gs, float* __restrict__ w,
+                                        size_t n, float T) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    w[i] = T * expm1f(gt[i] - gs[i]);
+}
+__global__ void expm1_weight_bwd_kernel(const float* __restrict__ gt, const float* __restrict__ gs,
+                                        const float* __restrict__ dw, float* __restrict__ dgt, float* __restrict__ dgs,
+                                        size_t n, float T) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float g = dw[i] * T * expf(gt[i] - gs[i]);
+    dgt[i] = g;
+    dgs[i] = -g;
+  }
+}
+
 // ------------------------------------------------------------------ q-sample + ELBO "pre" terms
 __device__ __forceinline__ float encode_u8(unsigned char x) { return 2.f * (((float)x + 0.5f) / 256.f) - 1.f; }
 __device__ __forceinline__ float bin_val(int j) { return 2.f * (((float)j + 0.5f) / 256.f) - 1.f; }
@@ -329,6 +345,15 @@ MULAN_API int mulan_poly_gamma_bwd(const float* a, const float* b, const float* 
   if (d != D || B <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(poly_gamma_bwd_kernel, dim3(nblocks((size_t)B * D)), dim3(256), 0, stream, a, b, c, t, dgt,
                      dgprime, da, db, dc, B, gamma_max - gamma_min);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_expm1_weight_fwd(const float* gt, const float* gs, float* w, size_t n, float T, hipStream_t stream) {
+  hipLaunchKernelGGL(expm1_weight_fwd_kernel, dim3(nblocks(n)), dim3(256), 0, stream, gt, gs, w, n, T);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_expm1_weight_bwd(const float* gt, const float* gs, const float* dw, float* dgt, float* dgs,
+                                     size_t n, float T, hipStream_t stream) {
+  hipLaunchKernelGGL(expm1_weight_bwd_kernel, dim3(nblocks(n)), dim3(256), 0, stream, gt, gs, dw, dgt, dgs, n, T);
   MULAN_CHECK_LAUNCH();
 }
 MULAN_API int mulan_qsample_fwd(const unsigned char* x, const float* g0, const float* g1, const float* gt,

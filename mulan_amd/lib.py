@@ -37,6 +37,8 @@ SIGNATURES = {
     "mulan_encode_u8": [P, P, Z, P],
     "mulan_poly_gamma_fwd": [P, P, P, P, P, P, P, P, I, I, F, F, P],
     "mulan_poly_gamma_bwd": [P, P, P, P, P, P, P, P, P, I, I, F, F, P],
+    "mulan_expm1_weight_fwd": [P, P, P, Z, F, P],
+    "mulan_expm1_weight_bwd": [P, P, P, P, P, Z, F, P],
     "mulan_qsample_fwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
     "mulan_qsample_bwd": [P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "mulan_diffloss_fwd": [I, P, P, P, I, P, P, P, P, I, I, P],

@@ -361,7 +361,9 @@ class MulanVDM(_VDMBase):
         elif T == 0:
             loss_diff = ops.diffusion_loss(2, x, gt, gp, noise["eps"], zt, net)
         else:
-            raise NotImplementedError("mulan_epsilon with sm_n_timesteps > 0 (ldm/model_mulan_epsilon.py:348-355)")
+            # finite depth T (ldm/model_mulan_epsilon.py:348-355): s = t - 1/T, weight T * expm1(g_t - g_s)
+            _, _, gs, _ = ops.poly_gamma(a, b, c, t - 1.0 / T, cfg.gamma_min, cfg.gamma_max)
+            loss_diff = ops.diffusion_loss(2, x, gt, ops.expm1_weight(gt, gs, T), noise["eps"], zt, net)
         out = VDMOutput(loss_recon=loss_recon, loss_klz=kl_z + loss_klz, loss_diff=loss_diff, var_0=v0.mean(),
                         var_1=v1.mean())
         if return_aux:

@@ -453,6 +453,31 @@ def poly_gamma(a, b, c, t, gmin, gmax):
     return PolyGammaFn.apply(a, b, c, t, gmin, gmax)
 
 
+class Expm1WeightFn(torch.autograd.Function):
+    """w = T * expm1(gamma_t - gamma_s): discrete-time loss weight (ldm/model_mulan_epsilon.py:348-355)"""
+
+    @staticmethod
+    def forward(ctx, gt, gs, T):
+        gt, gs = _c(gt), _c(gs)
+        w = torch.empty_like(gt)
+        call("mulan_expm1_weight_fwd", ptr(gt), ptr(gs), ptr(w), gt.numel(), float(T), stream())
+        ctx.save_for_backward(gt, gs)
+        ctx.T = float(T)
+        return w
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dw):
+        gt, gs = ctx.saved_tensors
+        dgt, dgs = torch.empty_like(gt), torch.empty_like(gs)
+        call("mulan_expm1_weight_bwd", ptr(gt), ptr(gs), ptr(_c(dw)), ptr(dgt), ptr(dgs), gt.numel(), ctx.T, stream())
+        return dgt, dgs, None
+
+
+def expm1_weight(gt, gs, T):
+    return Expm1WeightFn.apply(gt, gs, T)
+
+
 class QSampleFn(torch.autograd.Function):
     """(z_t, mean gamma_t, loss_recon, loss_klz, var0, var1) from (x, gamma_0, gamma_1, gamma_t, eps0, eps)
     (ldm/model_mulan_velocity.py:208-236; ldm/model_vdm.py:119-151,274-303)."""

@@ -186,6 +186,8 @@ def mulan_forward(params, cfg, x_u8, t0, raw_gamma, eps_0, eps, enc_masks=None, 
     B = x_u8.shape[0]
     x = x_u8.reshape(B, 32, 32, 3)
     t = torch.remainder(t0 + torch.arange(B, dtype=dtype) / B, 1.)
+    if cfg.get("n_timesteps", 0) > 0:   # ldm/model_mulan_epsilon.py:295-297
+        t = torch.ceil(t * cfg["n_timesteps"]) / cfg["n_timesteps"]
     f = encode(x.to(dtype))
     logits = unet_encoder(f, params["encoder_model"], cfg["n_embd"], cfg["forward_n_layer"], enc_masks, keep)
     emb, kl_z = topk_embedding_and_loss(logits, raw_gamma, cfg["latent_k"])
@@ -210,8 +212,12 @@ def mulan_forward(params, cfg, x_u8, t0, raw_gamma, eps_0, eps, enc_masks=None, 
             v_hat = -torch.exp(0.5 * g_t) * z_t + torch.sqrt(1 + torch.exp(g_t)) * net
         v_target = torch.sqrt(1. - var_t) * eps - torch.sqrt(var_t) * f
         loss_diff = .5 * ((1 - var_t) * g_p * (v_target - v_hat) ** 2).reshape(B, -1).sum(dim=1)
-    else:
+    elif cfg.get("n_timesteps", 0) == 0:
         loss_diff = .5 * (g_p * (eps - net) ** 2).reshape(B, -1).sum(dim=1)
+    else:   # ldm/model_mulan_epsilon.py:348-355
+        T = cfg["n_timesteps"]
+        g_s = poly_gamma(a, b, c, t - 1. / T).reshape(shp)
+        loss_diff = .5 * T * (torch.expm1(g_t - g_s) * (eps - net) ** 2).reshape(B, -1).sum(dim=1)
     klz = kl_z + loss_klz
     r = 1. / (3072 * math.log(2.))
     return dict(loss_recon=loss_recon, loss_klz=klz, loss_diff=loss_diff, var_0=var_0.mean(), var_1=var_1.mean(),
@@ -311,3 +317,40 @@ def init_params(cfg, seed=0, dtype=torch.float64, zero_init=False, latent=50):
              "dense_out_b": {"kernel": rnd(Dm, Dm), "bias": rnd(Dm, scale=0.1)},
              "dense_out_c": {"kernel": rnd(Dm, Dm), "bias": rnd(Dm, scale=0.1)}}
     return {"score_model": score, "encoder_model": enc, "gamma": gamma}
+
+
+def plain_vdm_forward(params, cfg, x_u8, t0, eps_0, eps, gmin=GAMMA_MIN, gmax=GAMMA_MAX, dtype=torch.float64):
+    """model_vdm.VDM.__call__ (ldm/model_vdm.py:110-180) with gamma_type 'fixed' (:462-468) or 'learnable_scalar'
+    (:418-431), epsilon prediction, T = 0 (:158-161) or T > 0 with the 'noise' weighting (:162-170)."""
+    B = x_u8.shape[0]
+    x = x_u8.reshape(B, 32, 32, 3)
+    T = cfg.get("n_timesteps", 0)
+    t = torch.remainder(t0 + torch.arange(B, dtype=dtype) / B, 1.)
+    if T > 0:
+        t = torch.ceil(t * T) / T
+    if "gamma" in params:
+        w, b = torch.abs(params["gamma"]["w"]), params["gamma"]["b"]
+        gamma = lambda tt: b + w * tt
+        slope = w.expand(B)
+    else:
+        gamma = lambda tt: gmin + (gmax - gmin) * tt
+        slope = torch.full((B,), gmax - gmin, dtype=dtype)
+    g_0, g_1, g_t = gamma(torch.zeros(B, dtype=dtype)), gamma(torch.ones(B, dtype=dtype)), gamma(t)
+    bc = lambda g: g[:, None, None, None]
+    f = encode(x.to(dtype))
+    var_0, var_1, var_t = torch.sigmoid(g_0), torch.sigmoid(g_1), torch.sigmoid(g_t)
+    z_0 = f + torch.exp(0.5 * bc(g_0)) * eps_0
+    loss_recon = -logprob(x, z_0, bc(g_0) * torch.ones_like(f))
+    v1 = bc(var_1) * torch.ones_like(f)
+    loss_klz = 0.5 * ((1. - v1) * f * f + v1 - torch.log(v1) - 1.).reshape(B, -1).sum(dim=1)
+    z_t = torch.sqrt(1. - bc(var_t)) * f + torch.sqrt(bc(var_t)) * eps
+    eps_hat = score_unet(z_t, g_t, torch.zeros(B, 1, dtype=dtype), params["score_model"], cfg["n_embd"], cfg["n_layer"],
+                         gmin=gmin, gmax=gmax)
+    mse = ((eps - eps_hat) ** 2).reshape(B, -1).sum(dim=1)
+    if T == 0:
+        loss_diff = .5 * slope * mse
+    else:
+        loss_diff = .5 * T * torch.expm1(g_t - gamma(t - 1. / T)) * mse
+    r = 1. / (3072 * math.log(2.))
+    return dict(loss_recon=loss_recon, loss_klz=loss_klz, loss_diff=loss_diff, var_0=var_0.mean(), var_1=var_1.mean(),
+                bpd=(loss_recon.mean() + loss_klz.mean() + loss_diff.mean()) * r)

@@ -163,3 +163,120 @@ def test_train_steps_reduce_loss_and_ema():
     assert not torch.equal(exp.state.flat, exp.state.ema)
     m = exp.eval_step(exp._eval_rng, exp.state.ema_params, sub, 0)
     assert np.isfinite(float(m['scalars']['eval_bpd']))
+
+
+def test_mulan_epsilon_discrete_time_T1000():
+    """sm_n_timesteps = 1000 branch of model_mulan_epsilon (ldm/model_mulan_epsilon.py:295-297,348-355): forward
+    terms and a few gradients vs the float64 oracle."""
+    import dataclasses
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, ocfg = make_cfg("mulan_epsilon")
+    cfg = dataclasses.replace(cfg, sm_n_timesteps=1000)
+    ocfg = dict(ocfg, n_timesteps=1000)
+    B = 4
+    rng = np.random.default_rng(5)
+    ref_params = tr.init_params(ocfg, seed=9, dtype=torch.float64)
+    for _, leaf in tr.tree_leaves(ref_params):
+        leaf.requires_grad_(True)
+    vdm = M.make_vdm("mulan_epsilon", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
+    M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), ref_params), params)
+    for _, leaf in M.tree_leaves(params):
+        leaf.requires_grad_(True)
+    x = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    raw = rng.gamma(1.0 / 15, size=(10, B, 50))
+    e0, e = rng.standard_normal((B, 3072)), rng.standard_normal((B, 3072))
+    noise = dict(t0=0.411, gamma_raw=torch.tensor(raw, dtype=torch.float32).cuda(),
+                 eps_0=torch.tensor(e0, dtype=torch.float32).cuda(), eps=torch.tensor(e, dtype=torch.float32).cuda())
+    ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), 0.411, torch.tensor(raw),
+                           torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3))
+    out = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs=None, deterministic=True, noise=noise)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+    # fp32 expm1(gamma_t - gamma_s) of a ~1e-2 difference of O(10) numbers: 2e-3 relative on the loss
+    assert rel(out.loss_diff.detach().cpu().numpy(), ref["loss_diff"].detach().numpy()) < 2e-3
+    (out.loss_diff.mean()).backward()
+    ref["loss_diff"].mean().backward()
+    g = params["gamma"]["dense_out_b"]["bias"].grad.cpu().double().numpy()
+    rg = ref_params["gamma"]["dense_out_b"]["bias"].grad.numpy()
+    assert rel(g, rg) < 2e-2
+    g = params["score_model"]["conv_out"]["kernel"].grad.cpu().double().numpy()
+    rg = ref_params["score_model"]["conv_out"]["kernel"].grad.numpy()
+    assert rel(g, rg) < 2e-3
+
+
+@pytest.mark.parametrize("gamma_type,T", [("fixed", 0), ("learnable_scalar", 0), ("fixed", 1000)])
+def test_plain_vdm_matches_oracle(gamma_type, T):
+    """BASELINE config #1 model (ldm/model_vdm.py:95-180): scalar schedule VDM, forward + schedule / U-Net grads."""
+    import dataclasses
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, ocfg = make_cfg()
+    cfg = dataclasses.replace(cfg, gamma_type=gamma_type, sm_n_timesteps=T, z_conditioning=False, reparam_type='noise')
+    ocfg = dict(ocfg, n_timesteps=T)
+    B = 4
+    rng = np.random.default_rng(6)
+    full = tr.init_params(ocfg, seed=4, dtype=torch.float64)
+    ref_params = {"score_model": full["score_model"]}
+    ref_params["score_model"]["dense0"]["kernel"] = ref_params["score_model"]["dense0"]["kernel"][:129].clone()
+    if gamma_type == "learnable_scalar":
+        ref_params["gamma"] = {"w": torch.tensor([-17.0], dtype=torch.float64), "b": torch.tensor([-12.5], dtype=torch.float64)}
+    for _, leaf in tr.tree_leaves(ref_params):
+        leaf.requires_grad_(True)
+    vdm = M.make_vdm("vdm", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
+    M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), ref_params), params)
+    for _, leaf in M.tree_leaves(params):
+        leaf.requires_grad_(True)
+    x = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    e0, e = rng.standard_normal((B, 3072)), rng.standard_normal((B, 3072))
+    # t0 keeps t * T away from integers: ceil(t * T) at an exact grid point flips with fp32 vs fp64 rounding
+    noise = dict(t0=0.2713, eps_0=torch.tensor(e0, dtype=torch.float32).cuda(), eps=torch.tensor(e, dtype=torch.float32).cuda())
+    ref = tr.plain_vdm_forward(ref_params, ocfg, torch.tensor(x), 0.2713, torch.tensor(e0).view(B, 32, 32, 3),
+                               torch.tensor(e).view(B, 32, 32, 3))
+    out = vdm.apply(params, torch.tensor(x).cuda(), None, torch.zeros(B, dtype=torch.uint8).cuda(), step=0, rngs=None,
+                    deterministic=True, noise=noise)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+    assert rel(out.loss_recon.detach().cpu().numpy(), ref["loss_recon"].detach().numpy()) < 1e-4
+    assert rel(out.loss_klz.detach().cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-4
+    assert rel(out.loss_diff.detach().cpu().numpy(), ref["loss_diff"].detach().numpy()) < (2e-3 if T else 5e-4)
+    r = 1.0 / (3072 * np.log(2.0))
+    ((out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) * r).backward()
+    ref["bpd"].backward()
+    g = params["score_model"]["conv_out"]["kernel"].grad.cpu().double().numpy()
+    assert rel(g, ref_params["score_model"]["conv_out"]["kernel"].grad.numpy()) < 2e-3
+    if gamma_type == "learnable_scalar":
+        for k in ("w", "b"):
+            assert rel(params["gamma"][k].grad.cpu().double().numpy(), ref_params["gamma"][k].grad.numpy()) < 5e-3
+
+
+def test_cli_train_checkpoint_and_dense_eval(tmp_path):
+    """H2: python -m ldm.main (2 optimiser steps, synthetic data, checkpoint) then python -m ldm.eval_bpd dense and
+    sparse on an npz test set through the same flag surface as the reference."""
+    import os
+    import ldm.main
+    import ldm.eval_bpd
+    from mulan_amd import checkpoint as ck
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfgp = os.path.join(root, "ldm", "configs", "cifar10-conditioned.py")
+    imgs = np.random.default_rng(0).integers(0, 256, (6, 32, 32, 3)).astype(np.uint8)
+    np.savez(tmp_path / "test.npz", images=imgs)
+    common = ["--config=" + cfgp, "--config.model.sm_n_layer=1", "--config.model.forward_n_layer=1",
+              "--config.training.batch_size_train=4", "--config.training.batch_size_eval=2",
+              "--config.training.substeps=1", "--config.training.num_steps_train=2", "--config.training.num_steps_eval=1",
+              "--config.training.steps_per_logging=1", "--config.training.steps_per_eval=2",
+              "--config.training.steps_per_save=2"]
+    ldm.main.main(common + ["--config.data.dataset=synthetic", "--workdir=" + str(tmp_path / "run")])
+    ckdirs = [os.path.join(dp, d) for dp, dn, _ in os.walk(tmp_path / "run") for d in dn if d == "checkpoints"]
+    assert len(ckdirs) == 1 and ck.checkpoint_numbers(ckdirs[0]) == [1]
+    sd = ck.restore_dict(ckdirs[0])
+    assert sd["step"] == 2 and "ema_params" in sd
+    ldm.eval_bpd.FLAGS.__init__()
+    import importlib
+    importlib.reload(ldm.eval_bpd)
+    ldm.eval_bpd.main(common + ["--config.data.dataset=npz:" + str(tmp_path / "test.npz"),
+                                "--checkpoint_directory=" + ckdirs[0], "--bpd_eval_method=dense", "--n_timesteps=8",
+                                "--max_images=3"])
+    importlib.reload(ldm.eval_bpd)
+    ldm.eval_bpd.main(common + ["--config.data.dataset=npz:" + str(tmp_path / "test.npz"),
+                                "--checkpoint_directory=" + ckdirs[0], "--checkpoint=1", "--bpd_eval_method=sparse"])
