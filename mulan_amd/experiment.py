@@ -108,6 +108,7 @@ class Experiment(abc.ABC):
         self.reducer.prepare()
         bpd, metrics = self.loss_fn(state.params, batch, step=state.step, rng=rng, is_train=True)
         bpd.backward()
+        state.collect_grads()
         self.reducer.finish()
         learning_rate = self.lr_schedule(state.step)
         state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate, grad_scale=1.0 / self.world)

@@ -58,11 +58,21 @@ def conv3x3_dgrad_raw(dy, w):
     return conv3x3_raw(dy, wT)
 
 
-def conv3x3_wgrad_raw(x, dy):
+def _gv(t):
+    """flat-gradient-buffer view registered for a parameter leaf by TrainState (None for ordinary tensors)"""
+    return getattr(t, "_gview", None) if t is not None else None
+
+
+def _fresh(view):
+    """a new tensor object over the same storage: lets autograd's AccumulateGrad adopt it without a copy"""
+    return view.view(view.shape)
+
+
+def conv3x3_wgrad_raw(x, dy, out=None):
     B, C, N = x.shape[0], x.shape[-1], dy.shape[-1]
     nbytes = lib.load().mulan_conv3x3_wgrad_workspace(B, H, W, C, N)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
-    dw = torch.empty((3, 3, C, N), device=x.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((3, 3, C, N), device=x.device, dtype=torch.float32)
     call("mulan_conv3x3_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
     return dw
 
@@ -84,7 +94,7 @@ def gemm_raw(A, Bm, M, N, K, *, bias=None, R=None, transA=False, transB=False, a
     return out
 
 
-def colsum_raw(x2d, nseg, seg, C):
+def colsum_raw(x2d, nseg, seg, C, out=None):
     """out[s][c] = sum of `seg` consecutive rows; long segments are reduced in two stages so the grid
     always has enough blocks to stream from HBM (fixed order => deterministic)."""
     chunk = 512
@@ -92,7 +102,8 @@ def colsum_raw(x2d, nseg, seg, C):
         part = torch.empty((nseg * (seg // chunk), C), device=x2d.device, dtype=torch.float32)
         call("mulan_colsum", ptr(x2d), ptr(part), nseg * (seg // chunk), chunk, C, C, 0, stream())
         x2d, seg = part, seg // chunk
-    out = torch.empty((nseg, C), device=x2d.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((nseg, C), device=x2d.device, dtype=torch.float32)
     call("mulan_colsum", ptr(x2d), ptr(out), nseg, seg, C, C, 0, stream())
     return out
 
@@ -113,6 +124,7 @@ class Conv3x3Fn(torch.autograd.Function):
         y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res))
         ctx.save_for_backward(x, w)
         ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
+        ctx.gv = (_gv(w), _gv(bias))
         return y
 
     @staticmethod
@@ -121,15 +133,18 @@ class Conv3x3Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = _c(dy)
         has_bias, cb_dim, has_res = ctx.has
+        gvw, gvb = ctx.gv
         B, N = dy.shape[0], dy.shape[-1]
         dx = conv3x3_dgrad_raw(dy, w) if ctx.needs_input_grad[0] else None
-        dw = conv3x3_wgrad_raw(x, dy) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
+            dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None)
         dbias = dcb = None
         per_sample = None
         if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):
             per_sample = colsum_raw(dy, B, HW, N)          # [B,N]
         if has_bias and ctx.needs_input_grad[2]:
-            dbias = colsum_raw(per_sample, 1, B, N).view(N)
+            dbias = colsum_raw(per_sample, 1, B, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
         if cb_dim is not None and ctx.needs_input_grad[3]:
             dcb = per_sample if cb_dim == 2 else dy
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
@@ -153,6 +168,7 @@ class LinearFn(torch.autograd.Function):
         y = gemm_raw(x2, w, M, N, K, bias=_c(bias), R=None if res is None else _c(res).reshape(M, N))
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, bias is not None, res is not None)
+        ctx.gv = (_gv(w), _gv(bias))
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -166,10 +182,11 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = gemm_raw(dy2, w, M, K, N, transB=True).view(xshape)
+        gvw, gvb = ctx.gv
         if ctx.needs_input_grad[1]:
-            dw = gemm_raw(x2, dy2, K, N, M, transA=True)
+            dw = gemm_raw(x2, dy2, K, N, M, transA=True, out=_fresh(gvw) if gvw is not None else None)
         if has_bias and ctx.needs_input_grad[2]:
-            db = colsum_raw(dy2, 1, M, N).view(N)
+            db = colsum_raw(dy2, 1, M, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres
 
@@ -192,6 +209,7 @@ class Linear2Fn(torch.autograd.Function):
         y = gemm_raw(a2, w[K1:], M, N, K2, R=y, out=torch.empty_like(y))
         ctx.save_for_backward(a1, a2, w)
         ctx.shape = x1.shape[:-1]
+        ctx.gv = (_gv(w), _gv(bias))
         return y.view(*x1.shape[:-1], N)
 
     @staticmethod
@@ -204,11 +222,14 @@ class Linear2Fn(torch.autograd.Function):
         dx1 = gemm_raw(dy2, w[:K1], M, K1, N, transB=True).view(*ctx.shape, K1) if ctx.needs_input_grad[0] else None
         dx2 = gemm_raw(dy2, w[K1:], M, K2, N, transB=True).view(*ctx.shape, K2) if ctx.needs_input_grad[1] else None
         dw = None
+        gvw, gvb = ctx.gv
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(w)
+            dw = _fresh(gvw) if gvw is not None else torch.empty_like(w)
             gemm_raw(a1, dy2, K1, N, M, transA=True, out=dw[:K1])
             gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])
-        db = colsum_raw(dy2, 1, M, N).view(N) if ctx.needs_input_grad[3] else None
+        db = None
+        if ctx.needs_input_grad[3]:
+            db = colsum_raw(dy2, 1, M, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
         return dx1, dx2, dw, db
 
 
@@ -261,6 +282,7 @@ class GroupNormFn(torch.autograd.Function):
              HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), stream())
         ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
         ctx.meta = (groups, int(act), float(keep), int(seed), int(offset))
+        ctx.gv = (_gv(gamma), _gv(beta))
         return y
 
     @staticmethod
@@ -278,8 +300,9 @@ class GroupNormFn(torch.autograd.Function):
         dbp = torch.empty_like(dgp)
         call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
              ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, stream())
-        dgamma = colsum_raw(dgp, 1, B, Ct).view(Ct)
-        dbeta = colsum_raw(dbp, 1, B, Ct).view(Ct)
+        gvg, gvb = ctx.gv
+        dgamma = colsum_raw(dgp, 1, B, Ct, out=_fresh(gvg).view(1, Ct) if gvg is not None else None).view(Ct)
+        dbeta = colsum_raw(dbp, 1, B, Ct, out=_fresh(gvb).view(1, Ct) if gvb is not None else None).view(Ct)
         return dx1, dx2, dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -100,6 +100,9 @@ class GradReducer:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _hook(self, t):
+        gv = getattr(t, "_gview", None)     # gradient that did not land in the flat buffer yet (no sink for this op)
+        if gv is not None and t.grad is not None and t.grad.data_ptr() != gv.data_ptr():
+            gv.copy_(t.grad)
         bi = self.leaf_bucket[id(t)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and not self.launched[bi]:

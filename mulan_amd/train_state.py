@@ -54,9 +54,13 @@ class TrainState:
                 self.flat[off_:off_ + src.numel()].copy_(src.reshape(-1).to(device))
         self.ema.copy_(self.flat)            # ema_params = deepcopy(params), ldm/train_state.py:110
         self.ema_params = self._views(self.ema, requires_grad=False)
+        self._leaves = []
         for (path, off_, shape), (_, leaf) in zip(self.layout, tree_leaves_in_layout(self.params, self.layout)):
             n = leaf.numel()
-            leaf.grad = self.grad[off_:off_ + n].view(shape)
+            # gradient sink: backward kernels write this leaf's gradient straight into the flat buffer
+            # (mulan_amd.ops reads `_gview`), autograd then adopts the view as .grad without an extra add
+            leaf._gview = self.grad[off_:off_ + n].view(shape)
+            self._leaves.append(leaf)
 
     @classmethod
     def create(cls, *, apply_fn, variables, device, optimizer_args=None):
@@ -78,7 +82,19 @@ class TrainState:
         return tree
 
     def zero_grad(self):
+        """Call before each backward: clears the flat buffer and detaches stale .grad handles."""
         self.grad.zero_()
+        for leaf in self._leaves:
+            leaf.grad = None
+
+    def collect_grads(self):
+        """Call after backward: any gradient that did not land in the flat buffer (ops without a sink, or a
+        copy made by autograd) is copied in, so `self.grad` is complete for the all-reduce / optimizer."""
+        for leaf in self._leaves:
+            g = leaf.grad
+            if g is not None and g.data_ptr() != leaf._gview.data_ptr():
+                leaf._gview.copy_(g)
+                leaf.grad = leaf._gview
 
     def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0):
         """TrainState.apply_gradients (ldm/train_state.py:70-102) on the flat gradient buffer."""

@@ -165,11 +165,14 @@ def test_train_state_layout_decay_mask_and_views():
     assert torch.equal(st.params["gamma"]["dense_1"]["kernel"].detach(), tree["gamma"]["dense_1"]["kernel"])
     assert torch.equal(st.ema, st.flat)
     leaf = st.params["encoder_model"]["dense"]["kernel"]
-    (leaf * 2).sum().backward()
-    off = dict((("/".join(p)), o) for p, o, _ in st.layout)["encoder_model/dense/kernel"]
-    assert torch.equal(st.grad[off:off + 15], torch.full((15,), 2.0))  # .grad is a view of the flat buffer
     st.zero_grad()
-    assert float(leaf.grad.abs().sum()) == 0
+    (leaf * 2).sum().backward()
+    st.collect_grads()                      # ops without a gradient sink are copied into the flat buffer
+    off = dict((("/".join(p)), o) for p, o, _ in st.layout)["encoder_model/dense/kernel"]
+    assert torch.equal(st.grad[off:off + 15], torch.full((15,), 2.0))
+    assert leaf.grad.data_ptr() == leaf._gview.data_ptr()
+    st.zero_grad()
+    assert leaf.grad is None and float(st.grad.abs().sum()) == 0
 
 
 def test_checkpoint_roundtrip_pt_and_flax_msgpack(tmp_path):

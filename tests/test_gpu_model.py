@@ -280,3 +280,43 @@ def test_cli_train_checkpoint_and_dense_eval(tmp_path):
     importlib.reload(ldm.eval_bpd)
     ldm.eval_bpd.main(common + ["--config.data.dataset=npz:" + str(tmp_path / "test.npz"),
                                 "--checkpoint_directory=" + ckdirs[0], "--checkpoint=1", "--bpd_eval_method=sparse"])
+
+
+def test_gradient_sink_equals_autograd_accumulation():
+    """The backward kernels write parameter gradients straight into TrainState's flat buffer (`_gview` sink);
+    the result must equal ordinary autograd accumulation bit for bit, and .grad must alias the flat buffer."""
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    from mulan_amd.train_state import TrainState
+    cfg, _ = make_cfg()
+    vdm = M.make_vdm("mulan_velocity", cfg)
+    st = TrainState.create(apply_fn=vdm.apply, variables={"params": vdm.init(PRNGKey(3))}, device=torch.device("cuda"))
+    with torch.no_grad():   # un-zero the zero-initialised tensors so every gradient is non-trivial
+        st.flat.add_(0.01 * torch.randn(st.flat.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(0)))
+        st.params["score_model"]["conv_in"]["kernel"][:, :, 15, :] = 0
+    x = torch.randint(0, 256, (4, 32, 32, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
+    rngs = {"sample": PRNGKey(5), "dropout": PRNGKey(6)}
+
+    def grads(use_sink):
+        for leaf in st._leaves:
+            if not use_sink and hasattr(leaf, "_gview"):
+                leaf._saved_gview = leaf._gview
+                del leaf._gview
+        st.zero_grad() if use_sink else [setattr(l, "grad", None) for l in st._leaves]
+        out = vdm.apply(st.params, x, None, None, step=0, rngs=rngs, deterministic=False)
+        (out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()).backward()
+        if use_sink:
+            aliased = sum(int(l.grad is not None and l.grad.data_ptr() == l._gview.data_ptr()) for l in st._leaves)
+            st.collect_grads()
+            return st.grad.clone(), aliased
+        flat = torch.zeros_like(st.grad)
+        for leaf, (path, off, shape) in zip(st._leaves, st.layout):
+            if leaf.grad is not None:
+                flat[off:off + leaf.numel()] = leaf.grad.reshape(-1)
+            leaf._gview = leaf._saved_gview
+        return flat, 0
+
+    g_sink, aliased = grads(True)
+    g_ref, _ = grads(False)
+    assert torch.equal(g_sink, g_ref)
+    assert aliased >= 0.9 * len(st._leaves), (aliased, len(st._leaves))   # autograd adopted the flat views

@@ -51,10 +51,13 @@ def _worker(rank, world, port, q):
         st.zero_grad()
         red.prepare()
         loss(st.params, shard).backward()
+        st.collect_grads()
         red.finish()
         mean_grad = st.grad / world          # the optimizer kernel applies 1/world as grad_scale
         ref = TrainState.create(apply_fn=None, variables={"params": tree}, device="cpu")
+        ref.zero_grad()
         loss(ref.params, xg).backward()      # big-batch gradient on one process
+        ref.collect_grads()
         ok = ok and torch.allclose(mean_grad, ref.grad, atol=1e-6)
     m = parallel.allreduce_mean_scalars({"bpd": torch.tensor(float(rank + 1)), "var": 2.0 * (rank + 1)}, "cpu")
     ok = ok and abs(float(m["bpd"]) - 1.5) < 1e-6 and abs(float(m["var"]) - 3.0) < 1e-6
