@@ -201,6 +201,102 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
   }
 }
 
+// Single-pass backward: 512 threads own (sample, 32-channel slab); each thread keeps its 16 pixels' xhat and
+// activation-gradient float4s in registers (128 VGPRs), so x and dy are read exactly once: 2 reads + 1 write.
+__global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
+  constexpr int NPB = HW / 64;   // pixels per thread
+  __shared__ float red[2 * 8 * 8];
+  __shared__ float cred[2 * 8 * 32];
+  const int tid = threadIdx.x, quad = tid & 7, prow = tid >> 3;   // prow 0..63
+  const int b = blockIdx.x, Ct = p.C1 + p.C2;
+  const int c0 = blockIdx.y * 32;
+  const int cpg = Ct / p.G, qpg = cpg >> 2;
+  const float* src; float* dxp; int ld, cs;
+  if (c0 < p.C1) { src = p.x1; dxp = p.dx1; ld = p.C1; cs = c0; }
+  else { src = p.x2; dxp = p.dx2; ld = p.C2; cs = c0 - p.C1; }
+  src += (size_t)b * HW * ld + cs + quad * 4;
+  dxp += (size_t)b * HW * ld + cs + quad * 4;
+  const int c = c0 + quad * 4, g = c / cpg;
+  const float mean = p.mean[b * p.G + g], rstd = p.rstd[b * p.G + g];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  const float* dyp = p.dy + (size_t)b * HW * Ct + c;
+
+  f32x4 xh[NPB], gq[NPB];
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int px = prow + 64 * i;
+    xh[i] = *reinterpret_cast<const f32x4*>(src + (size_t)px * ld);
+    gq[i] = *reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct);
+  }
+  float s1 = 0.f, s2 = 0.f;
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int px = prow + 64 * i;
+    if (p.keep < 1.f) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + px) * Ct + c) >> 2;
+      drop4(gq[i], p.keep, p.seed, p.offset + idx4);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xhat = (xh[i][e] - mean) * rstd;
+      const float u = xhat * ga[e] + be[e];
+      const float gu = p.act ? gq[i][e] * silu_grad_f(u) : gq[i][e];
+      dg[e] += gu * xhat;
+      db[e] += gu;
+      const float dxh = gu * ga[e];
+      s1 += dxh;
+      s2 += dxh * xhat;
+      xh[i][e] = xhat;
+      gq[i][e] = dxh;
+    }
+  }
+  // reduce over the 64 prow lanes: inside the wave (lane bits 3..5), then across the 8 waves through LDS
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+    red[wave * 8 + lane] = s1;
+    red[64 + wave * 8 + lane] = s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cred[wave * 32 + lane * 4 + e] = dg[e]; cred[256 + wave * 32 + lane * 4 + e] = db[e]; }
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float a = 0.f, bb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += cred[w * 32 + tid]; bb += cred[256 + w * 32 + tid]; }
+    p.dgamma_part[(size_t)b * Ct + c0 + tid] = a;
+    p.dbeta_part[(size_t)b * Ct + c0 + tid] = bb;
+  }
+  const int g0 = (quad / qpg) * qpg;
+  float t1 = 0.f, t2 = 0.f;
+  for (int q = g0; q < g0 + qpg; ++q)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { t1 += red[w * 8 + q]; t2 += red[64 + w * 8 + q]; }
+  const float inv_n = 1.f / (float)(HW * cpg);
+  const float m1 = t1 * inv_n, m2 = t2 * inv_n;
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    const int px = prow + 64 * i;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = rstd * (gq[i][e] - m1 - xh[i][e] * m2);
+    float* dp = dxp + (size_t)px * ld;
+    if (p.accumulate) {
+      const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
+      o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3];
+    }
+    *reinterpret_cast<f32x4*>(dp) = o;
+  }
+}
+
 }  // namespace
 
 MULAN_API int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma,
@@ -227,6 +323,9 @@ MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float*
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
               B, G, act, keep, seed, offset, accumulate};
-  hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  if (g_mulan_tune[2] == 1)   // dev A/B: the two-pass 256-thread variant
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -103,6 +103,7 @@ class GradReducer:
         gv = getattr(t, "_gview", None)     # gradient that did not land in the flat buffer yet (no sink for this op)
         if gv is not None and t.grad is not None and t.grad.data_ptr() != gv.data_ptr():
             gv.copy_(t.grad)
+            t.grad = gv       # so TrainState.collect_grads() does not overwrite the reduced bucket later
         bi = self.leaf_bucket[id(t)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and not self.launched[bi]:
