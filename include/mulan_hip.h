@@ -52,6 +52,14 @@ size_t mulan_conv3x3_wgrad_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int H, int W, int C,
                         int N, int accumulate, mulan_stream_t stream);
 
+/* fp32-equivalent fast path on the bf16 matrix cores (6-pass split, = XLA's float32 / HIGHEST matmul precision that
+ * the reference requests in ldm/main.py:39).  wp = weights pre-split by mulan_conv3x3_pack_bf16x6 (flip = 1 packs the
+ * tap-flipped, channel-transposed weights of the input-gradient convolution).  Needs C % 16 == 0 and N % 128 == 0. */
+size_t mulan_conv3x3_pack_bf16x6_bytes(int C, int N);
+int mulan_conv3x3_pack_bf16x6(const float* w, void* wp, int C, int N, int flip, mulan_stream_t stream);
+int mulan_conv3x3_fwd_bf16x6(const float* x, const void* wp, const float* bias, const float* cbias, int cbias_mode,
+                             const float* res, float* y, int B, int H, int W, int C, int N, mulan_stream_t stream);
+
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),
  * q,k,v,proj_out and the attention products (model_vdm.py:676-685,775-796), dense0/dense1/cond_proj

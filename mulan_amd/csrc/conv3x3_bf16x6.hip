@@ -1,0 +1,288 @@
+// 3x3 convolution with fp32-equivalent products on the bf16 matrix cores ("bf16x6" = the 6-pass scheme XLA uses
+// for jax_default_matmul_precision=float32 / Precision.HIGHEST, which is what the reference requests: ldm/main.py:39).
+//
+// Every fp32 operand is split exactly into three bf16 pieces  v = v1 + v2 + v3  (8 + 8 + 8 mantissa bits) and
+//     a * b  ~=  a1 b1 + a1 b2 + a2 b1 + a1 b3 + a2 b2 + a3 b1          (terms below 2^-24 |a||b| dropped)
+// is accumulated in fp32 by six v_mfma_f32_32x32x16_bf16 per 16-deep k step: 6 x 32 cycles instead of the
+// 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same k, i.e. 2.67x fewer matrix-pipe cycles at fp32 accuracy
+// (small integers stay exact; error bound ~2^-23 sum|a||b|, the same order as an fp32 FMA chain).
+//
+// Same tiling as conv3x3_fwd_kernel (block = 4 image rows x 128 couts, wave = 2 rows x 64 couts, halo patch in
+// LDS, one stage per (16-channel chunk, tap)); the activations are split while they are staged into LDS, the
+// weights are pre-split by mulan_conv3x3_pack_bf16x6 into exactly the LDS tile layout [cout][plane][16 k].
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kW = 32, kPW = 34, CK = 16, TROWS = 4;
+constexpr int PIXB = 112;                       // bytes per patch pixel: 3 planes x 32 B + 16 pad ((PIXB/16) odd)
+constexpr int NB = 112;                         // bytes per cout row of a weight tile
+constexpr int PATCH_B = (TROWS + 2) * kPW * PIXB;   // 22848
+constexpr int BN = 128;
+constexpr int WT_B = BN * NB;                   // 14336
+constexpr int SMEM_B = 2 * PATCH_B + 2 * WT_B;  // 74368 (dynamic shared memory)
+
+struct ConvArgsB {
+  const float* x;            // [B,H,32,C] fp32
+  const unsigned char* wp;   // packed weights [9][C/16][N][3][16] bf16
+  const float* bias; const float* cbias; const float* res;
+  float* y;
+  int B, H, C, N, cbias_mode;
+};
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)v;
+  const float r1 = v - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+
+__global__ __launch_bounds__(256) void conv3x3_bf16x6_kernel(ConvArgsB p) {
+  constexpr int MT = 2, NT = 2, WN = 2;
+  constexpr int PV = 4;                          // float4 patch slots per thread (816 slots)
+  constexpr int WV = 3;                          // 16-byte weight pieces per thread (768 pieces)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* pbuf0 = smem;
+  unsigned char* wbuf0 = smem + 2 * PATCH_B;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_per_img = p.H / TROWS;
+  const int b = blockIdx.x / tiles_per_img;
+  const int h0 = (blockIdx.x % tiles_per_img) * TROWS;
+  const int n0 = blockIdx.y * BN;
+  const int C = p.C, N = p.N;
+  const int nchunks = C / CK;
+  const float* xb = p.x + (size_t)b * p.H * kW * C;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // chunk / stage invariant prefetch addressing
+  const float* pptr[PV];
+  int pdst[PV];
+  unsigned phalo = 0;
+#pragma unroll
+  for (int s = 0; s < PV; ++s) {
+    const int slot = tid + s * 256;
+    const int q = slot & 3, pix = slot >> 2;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int hh = h0 + prow - 1, ww = pcol - 1;
+    const bool inb = slot < (TROWS + 2) * kPW * 4;
+    const bool ok = inb && hh >= 0 && hh < p.H && ww >= 0 && ww < kW;
+    pptr[s] = ok ? xb + ((size_t)hh * kW + ww) * C + q * 4 : p.x;
+    pdst[s] = inb ? pix * PIXB + q * 8 : -1;
+    phalo |= (ok ? 1u : 0u) << s;
+  }
+  int wsrc[WV], wdst[WV];
+#pragma unroll
+  for (int s = 0; s < WV; ++s) {
+    const int part = tid + s * 256;              // 16-byte piece of the 128 x 96 B tile
+    const int n = part / 6, piece = part - n * 6;
+    wsrc[s] = part * 16;
+    wdst[s] = n * NB + piece * 16;
+  }
+  const size_t tile_stride = (size_t)N * 96;     // bytes between (tap, chunk) tiles of the packed weights
+  const unsigned char* wtile0 = p.wp + (size_t)n0 * 96;
+
+  f32x4 preg[PV];
+  f32x4 wreg[WV];
+  auto gload_patch = [&](int cc) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) preg[s] = *reinterpret_cast<const f32x4*>(pptr[s] + (((phalo >> s) & 1u) ? cc * CK : 0));
+  };
+  auto store_patch = [&](unsigned char* pb) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) {
+      if (pdst[s] < 0) continue;
+      f32x4 v = preg[s];
+      if (!((phalo >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 hi, mi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 h, m, l;
+        split3(v[e], h, m, l);
+        hi[e] = h; mi[e] = m; lo[e] = l;
+      }
+      *reinterpret_cast<bf16x4*>(pb + pdst[s]) = hi;
+      *reinterpret_cast<bf16x4*>(pb + pdst[s] + 32) = mi;
+      *reinterpret_cast<bf16x4*>(pb + pdst[s] + 64) = lo;
+    }
+  };
+  auto gload_w = [&](int cc, int tap) {
+    const unsigned char* t = wtile0 + ((size_t)tap * nchunks + cc) * tile_stride;
+#pragma unroll
+    for (int s = 0; s < WV; ++s) wreg[s] = *reinterpret_cast<const f32x4*>(t + wsrc[s]);
+  };
+  auto store_w = [&](unsigned char* wb) {
+#pragma unroll
+    for (int s = 0; s < WV; ++s) *reinterpret_cast<f32x4*>(wb + wdst[s]) = wreg[s];
+  };
+
+  gload_patch(0);
+  gload_w(0, 0);
+  store_patch(pbuf0);
+  store_w(wbuf0);
+  __syncthreads();
+
+  int step = 0;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    const unsigned char* pb = pbuf0 + (cc & 1) * PATCH_B;
+    const bool more_chunks = cc + 1 < nchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const unsigned char* wb = wbuf0 + (step & 1) * WT_B;
+      unsigned char* wb_next = wbuf0 + ((step + 1) & 1) * WT_B;
+      const bool has_next = (tap < 8) || more_chunks;
+
+      bf16x8 af[MT][3], bfr[NT][3];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int prow = wm * MT + mt + kh, pcol = li + kw;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[mt][pl] = *reinterpret_cast<const bf16x8*>(pb + (prow * kPW + pcol) * PIXB + pl * 32 + lh * 16);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(wb + ((wn * NT + nt) * 32 + li) * NB + pl * 32 + lh * 16);
+      // next stage's prefetch behind the LDS reads, in front of the MFMA cluster
+      if (has_next) {
+        if (tap < 8) gload_w(cc, tap + 1); else gload_w(cc + 1, 0);
+      }
+      if (tap == 0 && more_chunks) gload_patch(cc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // small terms first: a1 b3, a3 b1, a2 b2, a1 b2, a2 b1, a1 b1
+#pragma unroll
+      for (int term = 0; term < 6; ++term) {
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[term]], bfr[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) store_w(wb_next);
+      if (tap == 8 && more_chunks) store_patch(pbuf0 + ((cc + 1) & 1) * PATCH_B);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: transposed through LDS so every lane moves float4s (see conv3x3_fwd_kernel)
+  const float* __restrict__ res = p.res;
+  const float* __restrict__ cbp = p.cbias;
+  float* __restrict__ yout = p.y;
+  constexpr int TS = 64 + 4;
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * TS;
+  const int c4 = lane & 15, prl = lane >> 4;
+  const int nb = n0 + wn * 64 + c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+  if (p.cbias_mode == 1) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + (size_t)b * N + nb);
+    bias4[0] += c[0]; bias4[1] += c[1]; bias4[2] += c[2]; bias4[3] += c[3];
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = acc[mt][nt][r];
+    __syncthreads();
+    const int hh = h0 + wm * MT + mt;
+    const size_t rowbase = (((size_t)b * p.H + hh) * kW) * N + nb;
+    f32x4 add[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) add[it] = bias4;
+    if (p.cbias_mode == 2) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + rowbase + (size_t)(it * 4 + prl) * N);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+    if (res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(res + rowbase + (size_t)(it * 4 + prl) * N);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + (it * 4 + prl) * TS + c4 * 4);
+      const f32x4 o = {a[0] + add[it][0], a[1] + add[it][1], a[2] + add[it][2], a[3] + add[it][3]};
+      *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * N) = o;
+    }
+  }
+}
+
+// wp[t][cc][o][plane][k] = split3( Wl[t][cc*16 + k][o] ),  Wl = w (flip = 0) or the tap-flipped, channel-transposed
+// weights of the input-gradient convolution (flip = 1: Wl[t][k][o] = w[8-t][o][k], k over N, o over C).
+__global__ void conv3x3_pack_bf16x6_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int C, int N, int flip) {
+  const int Kin = flip ? N : C, Nout = flip ? C : N;
+  const size_t total = (size_t)9 * Kin * Nout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % 16);
+    size_t r = i / 16;
+    const int o = (int)(r % Nout); r /= Nout;
+    const int cc = (int)(r % (Kin / 16));
+    const int t = (int)(r / (Kin / 16));
+    const int kin = cc * 16 + k;
+    const float v = flip ? w[((size_t)(8 - t) * C + o) * N + kin] : w[((size_t)t * C + kin) * N + o];
+    __bf16 h, m, l;
+    split3(v, h, m, l);
+    __bf16* dst = wp + (((size_t)(t * (Kin / 16) + cc) * Nout + o) * 3) * 16 + k;
+    dst[0] = h; dst[16] = m; dst[32] = l;
+  }
+}
+
+}  // namespace
+
+MULAN_API size_t mulan_conv3x3_pack_bf16x6_bytes(int C, int N) { return (size_t)9 * C * N * 3 * 2; }
+
+MULAN_API int mulan_conv3x3_pack_bf16x6(const float* w, void* wp, int C, int N, int flip, hipStream_t stream) {
+  const int Kin = flip ? N : C;
+  if (Kin % 16 != 0 || C <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)9 * C * N;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(conv3x3_pack_bf16x6_kernel, dim3(blocks), dim3(256), 0, stream, w, static_cast<__bf16*>(wp), C, N,
+                     flip);
+  MULAN_CHECK_LAUNCH();
+}
+
+// Eligibility: W == 32, H % 4 == 0, C % 16 == 0, N % 128 == 0 (the ResBlock convolutions); everything else goes
+// through mulan_conv3x3_fwd.  `wp` is the packed weight of mulan_conv3x3_pack_bf16x6 for this direction.
+MULAN_API int mulan_conv3x3_fwd_bf16x6(const float* x, const void* wp, const float* bias, const float* cbias,
+                                       int cbias_mode, const float* res, float* y, int B, int H, int W, int C, int N,
+                                       hipStream_t stream) {
+  if (W != kW || H % TROWS != 0 || B <= 0 || C % CK != 0 || C <= 0 || N % BN != 0 || N <= 0)
+    return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x6_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  ConvArgsB a{x, static_cast<const unsigned char*>(wp), bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0};
+  dim3 grid(B * (H / TROWS), N / BN);
+  hipLaunchKernelGGL(conv3x3_bf16x6_kernel, grid, dim3(256), SMEM_B, stream, a);
+  MULAN_CHECK_LAUNCH();
+}

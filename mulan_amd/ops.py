@@ -16,6 +16,10 @@ H = W = 32
 HW = H * W
 D = HW * 3
 KERNEL_TIMER = None   # bench.py sets this to a list to time the dominant kernel with HIP events
+# "f32": exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x6": 6-pass bf16 split with fp32-equivalent products
+# (XLA's float32/HIGHEST matmul precision) for the eligible convolutions.  MULAN_CONV_MODE overrides.
+import os as _os
+CONV_MODE = _os.environ.get("MULAN_CONV_MODE", "f32")
 
 
 def _c(t):
@@ -37,22 +41,39 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
     mode = 0
     if cbias is not None:
         mode = 1 if cbias.dim() == 2 else 2
+    fast = CONV_MODE == "bf16x6" and C % 16 == 0 and N % 128 == 0
+
+    def launch():
+        if fast:
+            wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=x.device, dtype=torch.uint8)
+            call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 0, stream())
+            call("mulan_conv3x3_fwd_bf16x6", ptr(x), ptr(wp), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W,
+                 C, N, stream())
+        else:
+            call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N,
+                 stream())
     if KERNEL_TIMER is None:
-        call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N,
-             stream())
-    else:   # bench.py: HIP events on the launch stream around this one kernel
+        launch()
+    else:   # bench.py: HIP events on the launch stream around this one kernel (+ its weight pack in bf16x6 mode)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N,
-             stream())
+        launch()
         e.record()
         variant = "<128,2,2>" if N > 64 else ("<64,2,2>" if N > 32 else "<32,4,1>")
-        KERNEL_TIMER.append(("conv3x3_fwd_kernel" + variant, s, e, 2.0 * B * HW * 9 * C * N))
+        name = "conv3x3_bf16x6_kernel" if fast else "conv3x3_fwd_kernel" + variant
+        KERNEL_TIMER.append((name, s, e, 2.0 * B * HW * 9 * C * N))
     return y
 
 
 def conv3x3_dgrad_raw(dy, w):
     C, N = w.shape[2], w.shape[3]
+    if CONV_MODE == "bf16x6" and N % 16 == 0 and C % 128 == 0 and KERNEL_TIMER is None:
+        B = dy.shape[0]
+        dx = torch.empty((B, HW, C), device=dy.device, dtype=torch.float32)
+        wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=w.device, dtype=torch.uint8)
+        call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 1, stream())
+        call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C, stream())
+        return dx
     wT = torch.empty((3, 3, N, C), device=w.device, dtype=torch.float32)
     call("mulan_conv3x3_wflip", ptr(w), ptr(wT), C, N, stream())
     return conv3x3_raw(dy, wT)

@@ -31,8 +31,11 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="conv,wgrad,gn,gemm,misc")
     ap.add_argument("--tune", default="")
+    ap.add_argument("--conv-mode", default=None)
     a = ap.parse_args()
     ops.lib.load()
+    if a.conv_mode:
+        ops.CONV_MODE = a.conv_mode
     for kv in filter(None, a.tune.split(",")):
         k, v = kv.split("=")
         call("mulan_set_tuning", int(k), int(v))
