@@ -60,6 +60,10 @@ int mulan_conv3x3_pack_bf16x6(const float* w, void* wp, int C, int N, int flip, 
 int mulan_conv3x3_fwd_bf16x6(const float* x, const void* wp, const float* bias, const float* cbias, int cbias_mode,
                              const float* res, float* y, int B, int H, int W, int C, int N, mulan_stream_t stream);
 
+size_t mulan_conv3x3_wgrad_bf16x6_workspace(int B, int H, int W, int C, int N);
+int mulan_conv3x3_wgrad_bf16x6(const float* x, const float* dy, float* dw, float* workspace, int B, int H, int W,
+                               int C, int N, int accumulate, mulan_stream_t stream);
+
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),
  * q,k,v,proj_out and the attention products (model_vdm.py:676-685,775-796), dense0/dense1/cond_proj

@@ -253,6 +253,213 @@ __global__ void conv3x3_pack_bf16x6_kernel(const float* __restrict__ w, __bf16* 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW[t][ci][co] = sum_pixels x[p + shift_t][ci] * dy[p][co] with the same 6-pass split.  The contraction index is
+// the pixel, while both tensors are stored channel-contiguous, so the operands are fetched with the transposing LDS
+// read ds_read_b64_tr_b16 (a 4 k x 16 channel block per 16-lane group, delivered k-major): a tap shift is then a
+// whole-row address offset and every read stays 8-byte aligned.  LDS rows are 64 B (32 channels of one split plane),
+// which makes the two 16-lane groups of a half-wave cover all 64 banks exactly once.
+constexpr int WG_T = 64, WG_ROWS = 2;
+constexpr int XPIX = (WG_ROWS + 2) * kPW;                 // 136 halo-patch pixels
+constexpr int X_HALF = XPIX * 64, X_PLANE = 2 * X_HALF;   // bytes
+constexpr int DPIX = WG_ROWS * kW;                        // 64
+constexpr int D_HALF = DPIX * 64, D_PLANE = 2 * D_HALF;
+constexpr int WG_SMEM = 3 * X_PLANE + 3 * D_PLANE;        // 52224 + 24576 = 76800
+
+struct WgradArgsB {
+  const float* x; const float* dy; float* slab;
+  int B, H, C, N, S;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* base) {
+  // two 4-k blocks (k .. k+3 and k+4 .. k+7) -> the 8 k values of this lane's MFMA operand
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + 4 * 64));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_bf16x6_kernel(WgradArgsB p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;
+  unsigned char* ds = smem + 3 * X_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wci = wave >> 1, wco = wave & 1;
+  const int C = p.C, N = p.N;
+  const int c0 = blockIdx.y * WG_T, n0 = blockIdx.z * WG_T;
+  const int pairs_per_img = p.H / WG_ROWS;
+  const int total_pairs = p.B * pairs_per_img;
+  const int per_split = (total_pairs + p.S - 1) / p.S;
+  const int pair_begin = blockIdx.x * per_split;
+  const int pair_end = min(total_pairs, pair_begin + per_split);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  constexpr int XV = (XPIX * 16 + 255) / 256;   // 9 float4 slots / thread
+  constexpr int DV = (DPIX * 16) / 256;         // 4
+  f32x4 xreg[XV], dreg[DV];
+  int xoff[XV], doff[DV], xdst[XV], ddst[DV];
+  unsigned xstat = 0, xtop = 0, xbot = 0, dstat = 0, xmask = 0;
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int slot = tid + i * 256;
+    const int q = slot & 15, pix = slot >> 4;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int ww = pcol - 1, c = c0 + q * 4;
+    const bool inb = slot < XPIX * 16;
+    const bool ok = inb && ww >= 0 && ww < kW && c < C;
+    xoff[i] = ((prow - 1) * kW + ww) * C + c;
+    xdst[i] = inb ? (q >> 3) * X_HALF + pix * 64 + (q & 7) * 8 : -1;
+    xstat |= (ok ? 1u : 0u) << i;
+    xtop |= (prow == 0 ? 1u : 0u) << i;
+    xbot |= (prow == WG_ROWS + 1 ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < DV; ++i) {
+    const int slot = tid + i * 256;
+    const int q = slot & 15, pix = slot >> 4;
+    const int n = n0 + q * 4;
+    doff[i] = pix * N + n;
+    ddst[i] = (q >> 3) * D_HALF + pix * 64 + (q & 7) * 8;
+    dstat |= (n < N ? 1u : 0u) << i;
+  }
+  auto gload = [&](int pr) {
+    const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
+    const float* xrow = p.x + ((size_t)b * p.H + h0) * kW * C;
+    const float* dyb = p.dy + ((size_t)b * p.H + h0) * kW * N;
+    xmask = xstat & ~(h0 == 0 ? xtop : 0u) & ~(h0 + WG_ROWS >= p.H ? xbot : 0u);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) xreg[i] = *reinterpret_cast<const f32x4*>(((xmask >> i) & 1u) ? xrow + xoff[i] : p.x);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) dreg[i] = *reinterpret_cast<const f32x4*>(((dstat >> i) & 1u) ? dyb + doff[i] : p.dy);
+  };
+  auto split_store = [&](unsigned char* base, int plane_stride, int dst, f32x4 v) {
+    bf16x4 hi, mi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      __bf16 h, m, l;
+      split3(v[e], h, m, l);
+      hi[e] = h; mi[e] = m; lo[e] = l;
+    }
+    *reinterpret_cast<bf16x4*>(base + dst) = hi;
+    *reinterpret_cast<bf16x4*>(base + plane_stride + dst) = mi;
+    *reinterpret_cast<bf16x4*>(base + 2 * plane_stride + dst) = lo;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      if (xdst[i] < 0) continue;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      split_store(xs, X_PLANE, xdst[i], ((xmask >> i) & 1u) ? xreg[i] : z);
+    }
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      split_store(ds, D_PLANE, ddst[i], ((dstat >> i) & 1u) ? dreg[i] : z);
+    }
+  };
+
+  // lane part of every transposing read: row q of the 4-k block, columns 4p..4p+3 of this group's 16 channels,
+  // k half = lh  (MFMA operand element j <-> k = 8 lh + j)
+  const int grp_q = (lane & 15) >> 2, grp_p = lane & 3, cb16 = ((lane >> 4) & 1) * 16;
+  const int lane_off = (8 * lh + grp_q) * 64 + (cb16 + 4 * grp_p) * 2;
+  const unsigned char* xa = xs + wci * X_HALF + lane_off;
+  const unsigned char* db = ds + wco * D_HALF + lane_off;
+
+  if (pair_begin < pair_end) {
+    gload(pair_begin);
+    lstore();
+  }
+  __syncthreads();
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    const bool has_next = pr + 1 < pair_end;
+    if (has_next) gload(pr + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int ks = 0; ks < DPIX / 16; ++ks) {
+      const int rr = ks >> 1, w0 = (ks & 1) * 16;
+      bf16x8 bfr[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bfr[pl] = tr_read8(db + pl * D_PLANE + (rr * kW + w0) * 64);
+      bf16x8 af[2][3];
+      const unsigned char* xk = xa + (rr * kPW + w0) * 64;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[0][pl] = tr_read8(xk + pl * X_PLANE);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) {
+          const int kh = (t + 1) / 3, kw = (t + 1) % 3;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) af[(t + 1) & 1][pl] = tr_read8(xk + pl * X_PLANE + (kh * kPW + kw) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+          constexpr int PA[6] = {0, 2, 1, 0, 1, 0};
+          constexpr int PB[6] = {2, 0, 1, 1, 0, 0};
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t & 1][PA[term]], bfr[PB[term]], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (has_next) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
+  const int n = n0 + wco * 32 + li;
+  if (n < N) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wci * 32 + mfma32_row(r, lane);
+        if (c < C) slab[((size_t)t * C + c) * N + n] = acc[t][r];
+      }
+  }
+}
+
+__global__ void slab_reduce_b_kernel(const float* __restrict__ slab, float* __restrict__ out, int S, int E,
+                                     int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float s = 0.f;
+  int i = 0;
+  for (; i + 8 <= S; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(i + u) * E + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < S; ++i) s += slab[(size_t)i * E + e];
+  out[e] = accumulate ? out[e] + s : s;
+}
+
+int wgrad_splits_b(int B, int H, int C, int N) {
+  const int tiles = ((C + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
+  const int pairs = B * (H / WG_ROWS);
+  const int target = g_mulan_tune[1] > 0 ? g_mulan_tune[1] : 256;
+  int S = target / tiles;
+  if (S < 1) S = 1;
+  if (S > pairs) S = pairs;
+  while (S > 1 && pairs / S < 4) --S;
+  return S;
+}
+
 }  // namespace
 
 MULAN_API size_t mulan_conv3x3_pack_bf16x6_bytes(int C, int N) { return (size_t)9 * C * N * 3 * 2; }
@@ -284,5 +491,30 @@ MULAN_API int mulan_conv3x3_fwd_bf16x6(const float* x, const void* wp, const flo
   ConvArgsB a{x, static_cast<const unsigned char*>(wp), bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0};
   dim3 grid(B * (H / TROWS), N / BN);
   hipLaunchKernelGGL(conv3x3_bf16x6_kernel, grid, dim3(256), SMEM_B, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API size_t mulan_conv3x3_wgrad_bf16x6_workspace(int B, int H, int W, int C, int N) {
+  if (W != kW || H % WG_ROWS != 0) return 0;
+  return (size_t)wgrad_splits_b(B, H, C, N) * 9 * C * N * sizeof(float);
+}
+
+// dw[3,3,C,N] (+)= sum x (x) dy with the 6-pass split; needs C % 4 == 0, N % 4 == 0 and 16-byte aligned tensors.
+MULAN_API int mulan_conv3x3_wgrad_bf16x6(const float* x, const float* dy, float* dw, float* workspace, int B, int H,
+                                         int W, int C, int N, int accumulate, hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % 4 != 0 || N % 4 != 0) return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x6_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int S = wgrad_splits_b(B, H, C, N);
+  WgradArgsB a{x, dy, workspace, B, H, C, N, S};
+  dim3 grid(S, (C + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T);
+  hipLaunchKernelGGL(conv3x3_wgrad_bf16x6_kernel, grid, dim3(256), WG_SMEM, stream, a);
+  const int E = 9 * C * N;
+  hipLaunchKernelGGL(slab_reduce_b_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
   MULAN_CHECK_LAUNCH();
 }

@@ -91,10 +91,12 @@ def _fresh(view):
 
 def conv3x3_wgrad_raw(x, dy, out=None):
     B, C, N = x.shape[0], x.shape[-1], dy.shape[-1]
-    nbytes = lib.load().mulan_conv3x3_wgrad_workspace(B, H, W, C, N)
+    fast = CONV_MODE == "bf16x6" and C % 4 == 0 and N % 4 == 0
+    fn = "mulan_conv3x3_wgrad_bf16x6" if fast else "mulan_conv3x3_wgrad"
+    nbytes = getattr(lib.load(), fn + "_workspace")(B, H, W, C, N)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((3, 3, C, N), device=x.device, dtype=torch.float32)
-    call("mulan_conv3x3_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
+    call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
     return dw
 
 

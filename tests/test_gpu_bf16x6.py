@@ -51,6 +51,34 @@ def test_bf16x6_dgrad_exact_on_integers(ops, B, C, N):
     assert np.array_equal(dx.cpu().double().numpy().reshape(B, 32, 32, C), x.grad.numpy())
 
 
+@pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (3, 64, 64), (1, 16, 128), (2, 48, 96), (1, 128, 4)])
+def test_bf16x6_wgrad_exact_on_integers(ops, B, C, N):
+    rng = np.random.default_rng(C * 5 + N + B)
+    x = torch.tensor(rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64))
+    w = torch.tensor(rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64), requires_grad=True)
+    dy = torch.tensor(rng.integers(-2, 3, (B, 32, 32, N)).astype(np.float64))
+    tr.conv3x3(x, {"kernel": w}).backward(dy)
+    dw = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N))
+    assert np.array_equal(dw.cpu().double().numpy(), w.grad.numpy())
+
+
+def test_bf16x6_wgrad_accuracy(ops, monkeypatch):
+    rng = np.random.default_rng(1)
+    B, C, N = 4, 128, 128
+    x = rng.standard_normal((B, 32, 32, C)) * np.exp(rng.standard_normal((B, 32, 32, C)))
+    dy = rng.standard_normal((B, 32, 32, N)) * np.exp(rng.standard_normal((B, 32, 32, N)))
+    xt = torch.tensor(x.astype(np.float32).astype(np.float64))
+    wt = torch.zeros(3, 3, C, N, dtype=torch.float64, requires_grad=True)
+    tr.conv3x3(xt, {"kernel": wt}).backward(torch.tensor(dy.astype(np.float32).astype(np.float64)))
+    ref = wt.grad.numpy()
+    d6 = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N)).cpu().double().numpy()
+    monkeypatch.setattr(ops, "CONV_MODE", "f32")
+    d32 = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N)).cpu().double().numpy()
+    scale = np.abs(ref).max()
+    e6, e32 = np.abs(d6 - ref).max() / scale, np.abs(d32 - ref).max() / scale
+    assert e6 < 1e-5 and e32 < 1e-5 and e6 < 2 * e32 + 1e-6, (e6, e32)
+
+
 def test_bf16x6_accuracy_matches_fp32_kernel(ops, monkeypatch):
     """random data with a wide dynamic range: max error relative to sum_k |a_k b_k| for both kernels"""
     rng = np.random.default_rng(0)
