@@ -23,7 +23,7 @@ constexpr int NB = 112;                         // bytes per cout row of a weigh
 constexpr int PATCH_B = (TROWS + 2) * kPW * PIXB;   // 22848
 constexpr int BN = 128;
 constexpr int WT_B = BN * NB;                   // 14336
-constexpr int SMEM_B = 2 * PATCH_B + 2 * WT_B;  // 74368 (dynamic shared memory)
+constexpr int SMEM_B = PATCH_B + 3 * WT_B;      // 65856 (dynamic shared memory): 1 patch + 3-deep weight ring
 
 struct ConvArgsB {
   const float* x;            // [B,H,32,C] fp32
@@ -31,6 +31,7 @@ struct ConvArgsB {
   const float* bias; const float* cbias; const float* res;
   float* y;
   int B, H, C, N, cbias_mode;
+  unsigned long long* stamps;   // dev-only (mulan_set_debug_buffer)
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16x6_kernel(ConvArgsB p) {
   constexpr int WV = 3;                          // 16-byte weight pieces per thread (768 pieces)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* pbuf0 = smem;
-  unsigned char* wbuf0 = smem + 2 * PATCH_B;
+  unsigned char* wbuf0 = smem + PATCH_B;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -128,39 +129,55 @@ __global__ __launch_bounds__(256) void conv3x3_bf16x6_kernel(ConvArgsB p) {
     for (int s = 0; s < WV; ++s) *reinterpret_cast<f32x4*>(wb + wdst[s]) = wreg[s];
   };
 
+  // Software pipeline.  Weight tiles live in a 3-deep LDS ring: tile s+1 is complete (barrier of stage s-1) while
+  // stage s computes, so stage s+1's A and B fragments are read from LDS *during* stage s's 24 MFMAs and nothing
+  // waits on an LDS read in front of an MFMA cluster; tile s+2 is fetched from L2 meanwhile and stored into the slot
+  // that tile s-1 vacated.  The activation patch is single buffered: one extra barrier per 9 stages.
+  const int nsteps = nchunks * 9;
+  auto tile_of = [&](int s2, int& cc2, int& tap2) { cc2 = s2 / 9; tap2 = s2 - cc2 * 9; };
+  auto read_frags = [&](bf16x8 (&af)[MT][3], bf16x8 (&bfr)[NT][3], int tap, const unsigned char* wb) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int prow = wm * MT + mt + kh, pcol = li + kw;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        af[mt][pl] = *reinterpret_cast<const bf16x8*>(pbuf0 + (prow * kPW + pcol) * PIXB + pl * 32 + lh * 16);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(wb + ((wn * NT + nt) * 32 + li) * NB + pl * 32 + lh * 16);
+  };
+
+  const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
   gload_patch(0);
   gload_w(0, 0);
   store_patch(pbuf0);
   store_w(wbuf0);
+  if (nsteps > 1) {
+    gload_w(0, 1);
+    store_w(wbuf0 + WT_B);
+  }
   __syncthreads();
 
-  int step = 0;
+  bf16x8 afc[MT][3], bfc[NT][3], afn[MT][3], bfn[NT][3];
+  read_frags(afc, bfc, 0, wbuf0);
+  int step = 0, slot_next = 1, slot_fill = 2;          // ring slots of tile step+1 / step+2
+  if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
   for (int cc = 0; cc < nchunks; ++cc) {
-    const unsigned char* pb = pbuf0 + (cc & 1) * PATCH_B;
+    if (stamp && cc < 20) p.stamps[2 + cc] = __builtin_amdgcn_s_memtime();
     const bool more_chunks = cc + 1 < nchunks;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int kh = tap / 3, kw = tap - kh * 3;
-      const unsigned char* wb = wbuf0 + (step & 1) * WT_B;
-      unsigned char* wb_next = wbuf0 + ((step + 1) & 1) * WT_B;
-      const bool has_next = (tap < 8) || more_chunks;
-
-      bf16x8 af[MT][3], bfr[NT][3];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int prow = wm * MT + mt + kh, pcol = li + kw;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          af[mt][pl] = *reinterpret_cast<const bf16x8*>(pb + (prow * kPW + pcol) * PIXB + pl * 32 + lh * 16);
-      }
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          bfr[nt][pl] = *reinterpret_cast<const bf16x8*>(wb + ((wn * NT + nt) * 32 + li) * NB + pl * 32 + lh * 16);
-      // next stage's prefetch behind the LDS reads, in front of the MFMA cluster
-      if (has_next) {
-        if (tap < 8) gload_w(cc, tap + 1); else gload_w(cc + 1, 0);
+      const bool has_next = step + 1 < nsteps, has_fill = step + 2 < nsteps;
+      if (tap < 8) read_frags(afn, bfn, tap + 1, wbuf0 + slot_next * WT_B);   // next stage's operands, same patch
+      if (has_fill) {
+        int c2, t2;
+        tile_of(step + 2, c2, t2);
+        gload_w(c2, t2);
       }
       if (tap == 0 && more_chunks) gload_patch(cc + 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -174,15 +191,30 @@ __global__ __launch_bounds__(256) void conv3x3_bf16x6_kernel(ConvArgsB p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt][PA[term]], bfr[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afc[mt][PA[term]], bfc[nt][PB[term]], acc[mt][nt], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (has_next) store_w(wb_next);
-      if (tap == 8 && more_chunks) store_patch(pbuf0 + ((cc + 1) & 1) * PATCH_B);
+      if (has_fill) store_w(wbuf0 + slot_fill * WT_B);
       __syncthreads();
+      if (tap == 8 && more_chunks) {       // every wave has left this chunk's patch: replace it
+        store_patch(pbuf0);
+        __syncthreads();
+      }
+      if (tap == 8 && has_next) read_frags(afn, bfn, 0, wbuf0 + slot_next * WT_B);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) afc[mt][pl] = afn[mt][pl];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bfc[nt][pl] = bfn[nt][pl];
+      slot_next = slot_next == 2 ? 0 : slot_next + 1;
+      slot_fill = slot_fill == 2 ? 0 : slot_fill + 1;
     }
   }
 
+  if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
   // epilogue: transposed through LDS so every lane moves float4s (see conv3x3_fwd_kernel)
   const float* __restrict__ res = p.res;
   const float* __restrict__ cbp = p.cbias;
@@ -231,6 +263,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16x6_kernel(ConvArgsB p) {
       *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * N) = o;
     }
   }
+  if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 // wp[t][cc][o][plane][k] = split3( Wl[t][cc*16 + k][o] ),  Wl = w (flip = 0) or the tap-flipped, channel-transposed
@@ -488,7 +521,8 @@ MULAN_API int mulan_conv3x3_fwd_bf16x6(const float* x, const void* wp, const flo
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  ConvArgsB a{x, static_cast<const unsigned char*>(wp), bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0};
+  ConvArgsB a{x, static_cast<const unsigned char*>(wp), bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0,
+              g_mulan_debug_buffer};
   dim3 grid(B * (H / TROWS), N / BN);
   hipLaunchKernelGGL(conv3x3_bf16x6_kernel, grid, dim3(256), SMEM_B, stream, a);
   MULAN_CHECK_LAUNCH();

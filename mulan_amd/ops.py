@@ -19,7 +19,7 @@ KERNEL_TIMER = None   # bench.py sets this to a list to time the dominant kernel
 # "f32": exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x6": 6-pass bf16 split with fp32-equivalent products
 # (XLA's float32/HIGHEST matmul precision) for the eligible convolutions.  MULAN_CONV_MODE overrides.
 import os as _os
-CONV_MODE = _os.environ.get("MULAN_CONV_MODE", "f32")
+CONV_MODE = _os.environ.get("MULAN_CONV_MODE", "bf16x6")
 
 
 def _c(t):
@@ -43,10 +43,13 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
         mode = 1 if cbias.dim() == 2 else 2
     fast = CONV_MODE == "bf16x6" and C % 16 == 0 and N % 128 == 0
 
+    wp = None
+    if fast:
+        wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=x.device, dtype=torch.uint8)
+        call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 0, stream())
+
     def launch():
         if fast:
-            wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=x.device, dtype=torch.uint8)
-            call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 0, stream())
             call("mulan_conv3x3_fwd_bf16x6", ptr(x), ptr(wp), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W,
                  C, N, stream())
         else:
@@ -54,7 +57,7 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
                  stream())
     if KERNEL_TIMER is None:
         launch()
-    else:   # bench.py: HIP events on the launch stream around this one kernel (+ its weight pack in bf16x6 mode)
+    else:   # bench.py: HIP events on the launch stream around this one kernel
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         launch()
@@ -67,12 +70,19 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
 
 def conv3x3_dgrad_raw(dy, w):
     C, N = w.shape[2], w.shape[3]
-    if CONV_MODE == "bf16x6" and N % 16 == 0 and C % 128 == 0 and KERNEL_TIMER is None:
+    if CONV_MODE == "bf16x6" and N % 16 == 0 and C % 128 == 0:
         B = dy.shape[0]
         dx = torch.empty((B, HW, C), device=dy.device, dtype=torch.float32)
         wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=w.device, dtype=torch.uint8)
         call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 1, stream())
-        call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C, stream())
+        if KERNEL_TIMER is None:
+            call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C, stream())
+        else:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C, stream())
+            e.record()
+            KERNEL_TIMER.append(("conv3x3_bf16x6_kernel", s, e, 2.0 * B * HW * 9 * C * N))
         return dx
     wT = torch.empty((3, 3, N, C), device=w.device, dtype=torch.float32)
     call("mulan_conv3x3_wflip", ptr(w), ptr(wT), C, N, stream())
@@ -96,7 +106,15 @@ def conv3x3_wgrad_raw(x, dy, out=None):
     nbytes = getattr(lib.load(), fn + "_workspace")(B, H, W, C, N)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((3, 3, C, N), device=x.device, dtype=torch.float32)
-    call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
+    if KERNEL_TIMER is None:
+        call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
+    else:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
+        e.record()
+        KERNEL_TIMER.append((("conv3x3_wgrad_bf16x6_kernel" if fast else "conv3x3_wgrad_kernel") + "+slab_reduce", s, e,
+                             2.0 * B * HW * 9 * C * N))
     return dw
 
 

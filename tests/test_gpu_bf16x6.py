@@ -103,3 +103,10 @@ def test_bf16x6_whole_model_parity(ops):
     """MuLAN train-mode step through the bf16x6 convolutions: same parity bars as the fp32 path"""
     from tests.test_gpu_model import run_case
     run_case("mulan_velocity", "vdm", False, train=True)
+
+
+def test_f32_mfma_whole_model_parity(ops, monkeypatch):
+    """the same step with MULAN_CONV_MODE=f32 (exact-fp32 MFMA kernels)"""
+    from tests.test_gpu_model import run_case
+    monkeypatch.setattr(ops, "CONV_MODE", "f32")
+    run_case("mulan_epsilon", "vdm", False, train=True)

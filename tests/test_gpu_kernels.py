@@ -15,9 +15,14 @@ from oracle import torch_ref as tr
 
 @pytest.fixture(scope="module")
 def ops():
+    """This module pins the exact-fp32 MFMA convolution kernels; tests/test_gpu_bf16x6.py covers the default
+    6-pass bf16 split kernels against the same oracle."""
     from mulan_amd import ops as _ops
     _ops.lib.load()
-    return _ops
+    saved = _ops.CONV_MODE
+    _ops.CONV_MODE = "f32"
+    yield _ops
+    _ops.CONV_MODE = saved
 
 
 def dev(a, dtype=torch.float32):

@@ -106,16 +106,18 @@ def main():
 
 
 
-def stamps(batch, C=128, N=128, tune=""):
+def stamps(batch, C=128, N=128, tune="", mode=None):
     """dev: phase timing of block 0 of one conv3x3 launch from in-kernel s_memtime stamps (100 MHz ticks)."""
     ops.lib.load()
+    if mode:
+        ops.CONV_MODE = mode
     for kv in filter(None, tune.split(",")):
         k, v = kv.split("=")
         call("mulan_set_tuning", int(k), int(v))
     buf = torch.zeros(64, dtype=torch.int64, device="cuda")
     x, w = torch.randn(batch, 1024, C, device="cuda"), torch.randn(3, 3, C, N, device="cuda") * 0.05
     bias, cb, res = torch.randn(N, device="cuda"), torch.randn(batch, N, device="cuda"), torch.randn(batch, 1024, N, device="cuda")
-    for _ in range(3):
+    for _ in range(30):
         ops.conv3x3_raw(x, w, bias, cb, res)
     call("mulan_set_debug_buffer", ptr(buf))
     ops.conv3x3_raw(x, w, bias, cb, res)
@@ -124,7 +126,7 @@ def stamps(batch, C=128, N=128, tune=""):
     t = buf.cpu().tolist()
     nch = (C + 15) // 16
     rel = lambda i: (t[i] - t[0]) * 1.0       # shader cycles (s_memtime counts core clocks)
-    print(f"stamps B={batch} C={C} N={N} tune={tune!r}: prologue {rel(1):.0f} cyc; chunks " +
+    print(f"stamps B={batch} C={C} N={N} tune={tune!r} mode={ops.CONV_MODE}: prologue {rel(1):.0f} cyc; chunks " +
           " ".join(f"{(t[3 + i] - t[2 + i]):.0f}" for i in range(nch - 1)) +
           f"; last chunk {(t[22] - t[1 + nch]):.0f}; epilogue {(t[23] - t[22]):.0f}; total {rel(23):.0f} cyc "
           f"(pure MFMA per chunk = 18432 cyc per wave); in-kernel clock {(t[23] - t[0]) / max(1, (t[31] - t[30])) * 0.1:.3f} GHz")
@@ -132,9 +134,9 @@ def stamps(batch, C=128, N=128, tune=""):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "stamps":
-        for bsz in (32, 128):
-            for tn in ("", "0=3"):
-                stamps(bsz, tune=tn)
-        stamps(128, C=256)
+        for md in ("f32", "bf16x6"):
+            for bsz in (32, 128):
+                stamps(bsz, mode=md)
+            stamps(128, C=256, mode=md)
     else:
         main()
