@@ -220,7 +220,8 @@ def main():
                                f"step (fwd+bwd+all-reduce+AdamW/EMA), batch {B}/GPU",
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
         "model_tflops_per_gpu": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3, 2),
-        "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+        "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 /
+                                     (PEAK_BF16_MFMA_TFLOPS / 6.0 if ops.CONV_MODE == "bf16x6" else PEAK_F32_MFMA_TFLOPS), 4),
         "last_train_bpd": round(last_bpd, 4),
         "roofline": roof, "f32_mfma_mode": f32_mode, "cpu_baseline": cpu,
     }
