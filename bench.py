@@ -146,10 +146,13 @@ def main():
     # ---- dominant-kernel timing: HIP events (on the launch stream) around every convolution launch of one more step
     roof = None
     f32_mode = None
+    # (every rank runs the step -- it contains the gradient all-reduce -- but only rank 0 records events)
     if rank == 0:
         ops.KERNEL_TIMER = []
-        state, _ = exp.train_step(exp._train_rng, state, batches[-1])
-        torch.cuda.synchronize()
+    state, _ = exp.train_step(exp._train_rng, state, batches[-1])
+    torch.cuda.synchronize()
+    barrier()
+    if rank == 0:
         recs = ops.KERNEL_TIMER
         ops.KERNEL_TIMER = None
         per = {}
@@ -161,15 +164,16 @@ def main():
         if per:
             name, (tot_t, tot_f, n) = max(per.items(), key=lambda kv: kv[1][0])
             ach = tot_f / tot_t / 1e12
-            bf = "bf16x6" in name
-            # bf16x6: six bf16 MFMA passes per algorithmic product -> the scheme's ceiling in algorithmic FLOP/s is the
-            # dense bf16 MFMA peak / 6; exact-fp32 MFMA mode: the fp32 MFMA peak.
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if bf else PEAK_F32_MFMA_TFLOPS
+            passes = 6 if "bf16x6" in name else (3 if "f16x3" in name else 0)
+            bf = passes > 0
+            # split modes: `passes` 16-bit MFMA passes per algorithmic product -> the scheme's ceiling in algorithmic
+            # FLOP/s is the dense bf16/fp16 MFMA peak / passes; exact-fp32 MFMA mode: the fp32 MFMA peak.
+            peak = PEAK_BF16_MFMA_TFLOPS / passes if bf else PEAK_F32_MFMA_TFLOPS
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": a.traffic,
-                    "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / 6 passes (3-way bf16 split, fp32-equivalent products)"
-                                  if bf else "dense fp32 MFMA"),
-                    "executed_bf16_tflops": round(6 * ach, 1) if bf else None,
+                    "peak_note": (f"dense 16-bit MFMA 2500 TFLOP/s / {passes} passes (split operands, fp32-equivalent "
+                                  "products)" if bf else "dense fp32 MFMA"),
+                    "executed_mfma_tflops": round(passes * ach, 1) if bf else None,
                     "launches_per_step": n, "avg_launch_us": round(tot_t / n * 1e6, 1),
                     "avg_gflop_per_launch": round(tot_f / n / 1e9, 3),
                     "share_of_step": round(tot_t / (elapsed / a.steps), 3),
@@ -189,7 +193,7 @@ def main():
         dt = (time.perf_counter() - t1) / nref
         ops.CONV_MODE = saved
         f32_mode = {"value": round(B / dt, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "steps": nref,
-                    "note": "convolutions on v_mfma_f32_32x32x2_f32 (exact fp32 MFMA) instead of the 6-pass bf16 split"}
+                    "note": "convolutions on v_mfma_f32_32x32x2_f32 (exact fp32 MFMA) instead of the split-operand kernels"}
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -213,15 +217,19 @@ def main():
         "metric": "train images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "conv_mode": (ops.CONV_MODE + (": fp32 operands split into 3 bf16 pieces, 6 bf16 MFMA passes, fp32 accumulate "
-                                       "(= XLA float32/HIGHEST matmul precision requested by the reference, ldm/main.py:39)"
-                                       if ops.CONV_MODE == "bf16x6" else ": exact fp32 MFMA")),
+        "conv_mode": ops.CONV_MODE + {
+            "bf16x6": ": fp32 operands split into 3 bf16 pieces, 6 bf16 MFMA passes, fp32 accumulate",
+            "f16x3": ": fp32 operands scaled by a power of two and split into 2 fp16 pieces, 3 fp16 MFMA passes, fp32 "
+                     "accumulate (error vs fp64 equal to the fp32 MFMA kernel's; the float32 matmul precision the "
+                     "reference requests, ldm/main.py:39)",
+            "f32": ": exact fp32 MFMA"}.get(ops.CONV_MODE, ""),
         "config": {"workload": f"MuLAN ({a.vdm_type}) CIFAR-10 config ldm/configs/cifar10-conditioned.py, full train "
                                f"step (fwd+bwd+all-reduce+AdamW/EMA), batch {B}/GPU",
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
         "model_tflops_per_gpu": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3, 2),
         "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 /
-                                     (PEAK_BF16_MFMA_TFLOPS / 6.0 if ops.CONV_MODE == "bf16x6" else PEAK_F32_MFMA_TFLOPS), 4),
+                                     {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(
+                                         ops.CONV_MODE, PEAK_F32_MFMA_TFLOPS), 4),
         "last_train_bpd": round(last_bpd, 4),
         "roofline": roof, "f32_mfma_mode": f32_mode, "cpu_baseline": cpu,
     }

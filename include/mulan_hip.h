@@ -64,6 +64,22 @@ size_t mulan_conv3x3_wgrad_bf16x6_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_bf16x6(const float* x, const float* dy, float* dw, float* workspace, int B, int H, int W,
                                int C, int N, int accumulate, mulan_stream_t stream);
 
+/* fp32-equivalent fast path on the fp16 matrix cores (3-pass split of power-of-two-scaled operands into two fp16
+ * pieces each; same contract as above at half the matrix-core cycles).  mulan_absmax_rows gives the per-image
+ * maxima (fp32 bit patterns) from which the kernels derive the operand scales: out[r] = bits(max|x[r, 0:row_len]|).
+ * wp / wmax[1] come from mulan_conv3x3_pack_f16x3 (flip as above).  Needs C % 16 == 0 and N % 128 == 0. */
+int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, mulan_stream_t stream);
+size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N);
+int mulan_conv3x3_pack_f16x3(const float* w, void* wp, unsigned* wmax, int C, int N, int flip, mulan_stream_t stream);
+int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                            const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, int B,
+                            int H, int W, int C, int N, mulan_stream_t stream);
+
+size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
+int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,
+                              float* workspace, int B, int H, int W, int C, int N, int accumulate,
+                              mulan_stream_t stream);
+
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),
  * q,k,v,proj_out and the attention products (model_vdm.py:676-685,775-796), dense0/dense1/cond_proj

@@ -1,0 +1,635 @@
+// 3x3 convolution with fp32-equivalent products on the fp16 matrix cores ("f16x3").
+//
+// An fp32 operand v, scaled by a power of two s so that max|v s| lies in [2^13, 2^14), splits into two fp16 pieces
+//     v s = h + l,   h = fp16(v s),  l = fp16(v s - h)          (11 + 11 mantissa bits + the two rounding signs:
+// |v s - h - l| <= 2^-24 |v s| as long as l is a normal fp16 number, and <= 2^-25 absolute below that: fp16 subnormals
+// are honoured by the matrix cores, tools/f16_probe.hip), and
+//     a * b  ~=  a_h b_h + a_h b_l + a_l b_h                    (the dropped a_l b_l is <= 2^-24 |a b|)
+// is accumulated in fp32 by three v_mfma_f32_32x32x16_f16 per 16-deep k step: half the matrix-pipe cycles of the
+// 6-pass bf16 split (conv3x3_bf16x6.hip) and 5.3x fewer than v_mfma_f32_32x32x2_f32, at the same measured error
+// against fp64 as either (tools/f16_probe.hip, tests/test_gpu_f16x3.py).  The power-of-two scales are exact and
+// are divided out of the fp32 accumulators in the epilogue.  Activations / output gradients carry one scale per
+// image (every image is normalised on its own, so images of very different magnitude in one batch keep full
+// precision); weights carry one scale per tensor; the weight-gradient kernel, which sums over images, uses the
+// per-tensor maxima.  The reference asks XLA for float32 matmul precision (ldm/main.py:39); this is that contract.
+//
+// Tiling is the one of conv3x3_bf16x6_kernel: block = 4 image rows x 128 couts, wave = 2 rows x 64 couts, halo patch
+// in LDS, one stage per (16-channel chunk, tap), weights pre-split by mulan_conv3x3_pack_f16x3 into the LDS tile
+// layout [cout][plane][16 k], 3-deep weight ring.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kW = 32, kPW = 34, CK = 16, TROWS = 4;
+constexpr int PIXB = 80;                        // bytes per patch pixel: 2 planes x 32 B + 16 pad ((PIXB/16) odd)
+constexpr int NB = 80;                          // bytes per cout row of a weight tile
+constexpr int PATCH_B = (TROWS + 2) * kPW * PIXB;   // 16320
+constexpr int BN = 128;
+constexpr int WT_B = BN * NB;                   // 10240
+constexpr int SMEM_B = PATCH_B + 3 * WT_B;      // 47040 (dynamic shared memory): 1 patch + 3-deep weight ring
+
+// ---- power-of-two scales from an absolute maximum given as fp32 bits
+// s = 2^(140 - e) with e the (clamped) biased exponent of the maximum: max * s in [2^13, 2^14).  inv = 1 / s.
+__device__ __forceinline__ void scale_of(unsigned maxbits, float& s, float& inv) {
+  int e = (int)((maxbits >> 23) & 255u);
+  e = e < 14 ? 14 : (e > 254 ? 254 : e);
+  s = __uint_as_float((unsigned)(267 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
+
+__device__ __forceinline__ void split2(float vs, _Float16& h, _Float16& l) {
+  h = (_Float16)vs;
+  l = (_Float16)(vs - (float)h);
+}
+
+struct ConvArgsH {
+  const float* x;            // [B,H,32,C] fp32
+  const unsigned* xmax;      // [B] fp32 bits of max|x[b]|
+  const unsigned char* wp;   // packed weights [9][C/16][N][2][16] fp16 (scaled)
+  const unsigned* wmax;      // [1] fp32 bits of max|w|
+  const float* bias; const float* cbias; const float* res;
+  float* y;
+  int B, H, C, N, cbias_mode;
+  unsigned long long* stamps;   // dev-only (mulan_set_debug_buffer)
+};
+
+__global__ __launch_bounds__(256) void conv3x3_f16x3_kernel(ConvArgsH p) {
+  constexpr int MT = 2, NT = 2, WN = 2;
+  constexpr int PV = 4;                          // float4 patch slots per thread (816 slots)
+  constexpr int WV = 2;                          // 16-byte weight pieces per thread (512 pieces)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* pbuf0 = smem;
+  unsigned char* wbuf0 = smem + PATCH_B;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_per_img = p.H / TROWS;
+  const int b = blockIdx.x / tiles_per_img;
+  const int h0 = (blockIdx.x % tiles_per_img) * TROWS;
+  const int n0 = blockIdx.y * BN;
+  const int C = p.C, N = p.N;
+  const int nchunks = C / CK;
+  const float* xb = p.x + (size_t)b * p.H * kW * C;
+  float sx, inv_x, sw, inv_w;
+  scale_of(p.xmax[b], sx, inv_x);
+  scale_of(p.wmax[0], sw, inv_w);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // chunk / stage invariant prefetch addressing
+  const float* pptr[PV];
+  int pdst[PV];
+  unsigned phalo = 0;
+#pragma unroll
+  for (int s = 0; s < PV; ++s) {
+    const int slot = tid + s * 256;
+    const int q = slot & 3, pix = slot >> 2;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int hh = h0 + prow - 1, ww = pcol - 1;
+    const bool inb = slot < (TROWS + 2) * kPW * 4;
+    const bool ok = inb && hh >= 0 && hh < p.H && ww >= 0 && ww < kW;
+    pptr[s] = ok ? xb + ((size_t)hh * kW + ww) * C + q * 4 : p.x;
+    pdst[s] = inb ? pix * PIXB + q * 8 : -1;
+    phalo |= (ok ? 1u : 0u) << s;
+  }
+  int wsrc[WV], wdst[WV];
+#pragma unroll
+  for (int s = 0; s < WV; ++s) {
+    const int part = tid + s * 256;              // 16-byte piece of the 128 x 64 B tile
+    const int n = part >> 2, piece = part & 3;
+    wsrc[s] = part * 16;
+    wdst[s] = n * NB + piece * 16;
+  }
+  const size_t tile_stride = (size_t)N * 64;     // bytes between (tap, chunk) tiles of the packed weights
+  const unsigned char* wtile0 = p.wp + (size_t)n0 * 64;
+
+  f32x4 preg[PV];
+  f32x4 wreg[WV];
+  auto gload_patch = [&](int cc) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) preg[s] = *reinterpret_cast<const f32x4*>(pptr[s] + (((phalo >> s) & 1u) ? cc * CK : 0));
+  };
+  auto store_patch = [&](unsigned char* pb) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) {
+      if (pdst[s] < 0) continue;
+      f32x4 v = preg[s];
+      if (!((phalo >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split2(v[e] * sx, h, l);
+        hi[e] = h; lo[e] = l;
+      }
+      *reinterpret_cast<f16x4*>(pb + pdst[s]) = hi;
+      *reinterpret_cast<f16x4*>(pb + pdst[s] + 32) = lo;
+    }
+  };
+  auto gload_w = [&](int cc, int tap) {
+    const unsigned char* t = wtile0 + ((size_t)tap * nchunks + cc) * tile_stride;
+#pragma unroll
+    for (int s = 0; s < WV; ++s) wreg[s] = *reinterpret_cast<const f32x4*>(t + wsrc[s]);
+  };
+  auto store_w = [&](unsigned char* wb) {
+#pragma unroll
+    for (int s = 0; s < WV; ++s) *reinterpret_cast<f32x4*>(wb + wdst[s]) = wreg[s];
+  };
+
+  // Software pipeline: see conv3x3_bf16x6_kernel.  Tile s+1 is complete while stage s computes, so stage s+1's
+  // fragments are read from LDS during stage s's 12 MFMAs; tile s+2 is fetched from L2 meanwhile.
+  const int nsteps = nchunks * 9;
+  auto tile_of = [&](int s2, int& cc2, int& tap2) { cc2 = s2 / 9; tap2 = s2 - cc2 * 9; };
+  auto read_frags = [&](f16x8 (&af)[MT][2], f16x8 (&bfr)[NT][2], int tap, const unsigned char* wb) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int prow = wm * MT + mt + kh, pcol = li + kw;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        af[mt][pl] = *reinterpret_cast<const f16x8*>(pbuf0 + (prow * kPW + pcol) * PIXB + pl * 32 + lh * 16);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        bfr[nt][pl] = *reinterpret_cast<const f16x8*>(wb + ((wn * NT + nt) * 32 + li) * NB + pl * 32 + lh * 16);
+  };
+
+  const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
+  gload_patch(0);
+  gload_w(0, 0);
+  store_patch(pbuf0);
+  store_w(wbuf0);
+  if (nsteps > 1) {
+    gload_w(0, 1);
+    store_w(wbuf0 + WT_B);
+  }
+  __syncthreads();
+
+  f16x8 afc[MT][2], bfc[NT][2], afn[MT][2], bfn[NT][2];
+  read_frags(afc, bfc, 0, wbuf0);
+  int step = 0, slot_next = 1, slot_fill = 2;          // ring slots of tile step+1 / step+2
+  if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
+  for (int cc = 0; cc < nchunks; ++cc) {
+    if (stamp && cc < 20) p.stamps[2 + cc] = __builtin_amdgcn_s_memtime();
+    const bool more_chunks = cc + 1 < nchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const bool has_next = step + 1 < nsteps, has_fill = step + 2 < nsteps;
+      if (tap < 8) read_frags(afn, bfn, tap + 1, wbuf0 + slot_next * WT_B);   // next stage's operands, same patch
+      if (has_fill) {
+        int c2, t2;
+        tile_of(step + 2, c2, t2);
+        gload_w(c2, t2);
+      }
+      if (tap == 0 && more_chunks) gload_patch(cc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // small terms first: a_l b_h, a_h b_l, a_h b_h
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[mt][PA[term]], bfc[nt][PB[term]], acc[mt][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_fill) store_w(wbuf0 + slot_fill * WT_B);
+      __syncthreads();
+      if (tap == 8 && more_chunks) {       // every wave has left this chunk's patch: replace it
+        store_patch(pbuf0);
+        __syncthreads();
+      }
+      if (tap == 8 && has_next) read_frags(afn, bfn, 0, wbuf0 + slot_next * WT_B);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) afc[mt][pl] = afn[mt][pl];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bfc[nt][pl] = bfn[nt][pl];
+      slot_next = slot_next == 2 ? 0 : slot_next + 1;
+      slot_fill = slot_fill == 2 ? 0 : slot_fill + 1;
+    }
+  }
+
+  if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
+  // epilogue: transposed through LDS so every lane moves float4s (see conv3x3_fwd_kernel); scales divided out here
+  const float* __restrict__ res = p.res;
+  const float* __restrict__ cbp = p.cbias;
+  float* __restrict__ yout = p.y;
+  constexpr int TS = 64 + 4;
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * TS;
+  const int c4 = lane & 15, prl = lane >> 4;
+  const int nb = n0 + wn * 64 + c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+  if (p.cbias_mode == 1) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + (size_t)b * N + nb);
+    bias4[0] += c[0]; bias4[1] += c[1]; bias4[2] += c[2]; bias4[3] += c[3];
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = (acc[mt][nt][r] * inv_x) * inv_w;
+    __syncthreads();
+    const int hh = h0 + wm * MT + mt;
+    const size_t rowbase = (((size_t)b * p.H + hh) * kW) * N + nb;
+    f32x4 add[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) add[it] = bias4;
+    if (p.cbias_mode == 2) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + rowbase + (size_t)(it * 4 + prl) * N);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+    if (res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(res + rowbase + (size_t)(it * 4 + prl) * N);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + (it * 4 + prl) * TS + c4 * 4);
+      const f32x4 o = {a[0] + add[it][0], a[1] + add[it][1], a[2] + add[it][2], a[3] + add[it][3]};
+      *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * N) = o;
+    }
+  }
+  if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// out[r] = fp32 bits of max |x[r, :]| (out zeroed by the caller; non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, unsigned* __restrict__ out,
+                                                          size_t row_len4) {
+  __shared__ unsigned red[4];
+  const f32x4* row = reinterpret_cast<const f32x4*>(x) + (size_t)blockIdx.x * row_len4;
+  unsigned m = 0;
+  const size_t stride = (size_t)gridDim.y * 256;
+  size_t i = (size_t)blockIdx.y * 256 + threadIdx.x;
+  for (; i + 3 * stride < row_len4; i += 4 * stride) {
+    const f32x4 a = row[i], b = row[i + stride], c = row[i + 2 * stride], d = row[i + 3 * stride];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      m = max(m, __float_as_uint(a[e]) & 0x7fffffffu);
+      m = max(m, __float_as_uint(b[e]) & 0x7fffffffu);
+      m = max(m, __float_as_uint(c[e]) & 0x7fffffffu);
+      m = max(m, __float_as_uint(d[e]) & 0x7fffffffu);
+    }
+  }
+  for (; i < row_len4; i += stride) {
+    const f32x4 a = row[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(a[e]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out + blockIdx.x, max(max(red[0], red[1]), max(red[2], red[3])));
+}
+
+// wp[t][cc][o][plane][k] = split2( s_w * Wl[t][cc*16 + k][o] ),  Wl = w (flip = 0) or the tap-flipped,
+// channel-transposed weights of the input-gradient convolution (flip = 1: Wl[t][k][o] = w[8-t][o][k]).
+__global__ void conv3x3_pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp,
+                                          const unsigned* __restrict__ wmax, int C, int N, int flip) {
+  const int Kin = flip ? N : C, Nout = flip ? C : N;
+  const size_t total = (size_t)9 * Kin * Nout;
+  float sw, inv_w;
+  scale_of(wmax[0], sw, inv_w);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % 16);
+    size_t r = i / 16;
+    const int o = (int)(r % Nout); r /= Nout;
+    const int cc = (int)(r % (Kin / 16));
+    const int t = (int)(r / (Kin / 16));
+    const int kin = cc * 16 + k;
+    const float v = flip ? w[((size_t)(8 - t) * C + o) * N + kin] : w[((size_t)t * C + kin) * N + o];
+    _Float16 h, l;
+    split2(v * sw, h, l);
+    _Float16* dst = wp + (((size_t)(t * (Kin / 16) + cc) * Nout + o) * 2) * 16 + k;
+    dst[0] = h; dst[16] = l;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW[t][ci][co] = sum_pixels x[p + shift_t][ci] * dy[p][co] with the same 3-pass split; operands fetched with the
+// transposing LDS read ds_read_b64_tr_b16 exactly as in conv3x3_wgrad_bf16x6_kernel (two planes instead of three).
+constexpr int WG_T = 64, WG_ROWS = 2;
+constexpr int XPIX = (WG_ROWS + 2) * kPW;                 // 136 halo-patch pixels
+constexpr int X_HALF = XPIX * 64, X_PLANE = 2 * X_HALF;   // bytes
+constexpr int DPIX = WG_ROWS * kW;                        // 64
+constexpr int D_HALF = DPIX * 64, D_PLANE = 2 * D_HALF;
+constexpr int WG_SMEM = 2 * X_PLANE + 2 * D_PLANE;        // 34816 + 16384 = 51200
+
+struct WgradArgsH {
+  const float* x; const float* dy; float* slab;
+  const unsigned* xmax; const unsigned* dymax;    // [B] per-image maxima (the kernel takes the tensor maximum)
+  int B, H, C, N, S;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f16x8 tr_read8h(const unsigned char* base) {
+  // two 4-k blocks (k .. k+3 and k+4 .. k+7) -> the 8 k values of this lane's MFMA operand
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + 4 * 64));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(WgradArgsH p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* xs = smem;
+  unsigned char* ds = smem + 2 * X_PLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wci = wave >> 1, wco = wave & 1;
+  const int C = p.C, N = p.N;
+  const int c0 = blockIdx.y * WG_T, n0 = blockIdx.z * WG_T;
+  const int pairs_per_img = p.H / WG_ROWS;
+  const int total_pairs = p.B * pairs_per_img;
+  const int per_split = (total_pairs + p.S - 1) / p.S;
+  const int pair_begin = blockIdx.x * per_split;
+  const int pair_end = min(total_pairs, pair_begin + per_split);
+
+  // tensor maxima -> scales
+  float sx, inv_x, sg, inv_g;
+  {
+    unsigned mx = 0, mg = 0;
+    for (int i = tid; i < p.B; i += 256) { mx = max(mx, p.xmax[i]); mg = max(mg, p.dymax[i]); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+      mg = max(mg, (unsigned)__shfl_xor((int)mg, o, 64));
+    }
+    unsigned* red = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) { red[wave] = mx; red[4 + wave] = mg; }
+    __syncthreads();
+    mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    mg = max(max(red[4], red[5]), max(red[6], red[7]));
+    __syncthreads();
+    scale_of(mx, sx, inv_x);
+    scale_of(mg, sg, inv_g);
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  constexpr int XV = (XPIX * 16 + 255) / 256;   // 9 float4 slots / thread
+  constexpr int DV = (DPIX * 16) / 256;         // 4
+  f32x4 xreg[XV], dreg[DV];
+  int xoff[XV], doff[DV], xdst[XV], ddst[DV];
+  unsigned xstat = 0, xtop = 0, xbot = 0, dstat = 0, xmask = 0;
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    const int slot = tid + i * 256;
+    const int q = slot & 15, pix = slot >> 4;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int ww = pcol - 1, c = c0 + q * 4;
+    const bool inb = slot < XPIX * 16;
+    const bool ok = inb && ww >= 0 && ww < kW && c < C;
+    xoff[i] = ((prow - 1) * kW + ww) * C + c;
+    xdst[i] = inb ? (q >> 3) * X_HALF + pix * 64 + (q & 7) * 8 : -1;
+    xstat |= (ok ? 1u : 0u) << i;
+    xtop |= (prow == 0 ? 1u : 0u) << i;
+    xbot |= (prow == WG_ROWS + 1 ? 1u : 0u) << i;
+  }
+#pragma unroll
+  for (int i = 0; i < DV; ++i) {
+    const int slot = tid + i * 256;
+    const int q = slot & 15, pix = slot >> 4;
+    const int n = n0 + q * 4;
+    doff[i] = pix * N + n;
+    ddst[i] = (q >> 3) * D_HALF + pix * 64 + (q & 7) * 8;
+    dstat |= (n < N ? 1u : 0u) << i;
+  }
+  auto gload = [&](int pr) {
+    const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
+    const float* xrow = p.x + ((size_t)b * p.H + h0) * kW * C;
+    const float* dyb = p.dy + ((size_t)b * p.H + h0) * kW * N;
+    xmask = xstat & ~(h0 == 0 ? xtop : 0u) & ~(h0 + WG_ROWS >= p.H ? xbot : 0u);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) xreg[i] = *reinterpret_cast<const f32x4*>(((xmask >> i) & 1u) ? xrow + xoff[i] : p.x);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) dreg[i] = *reinterpret_cast<const f32x4*>(((dstat >> i) & 1u) ? dyb + doff[i] : p.dy);
+  };
+  auto split_store = [&](unsigned char* base, int plane_stride, int dst, f32x4 v, float s) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 h, l;
+      split2(v[e] * s, h, l);
+      hi[e] = h; lo[e] = l;
+    }
+    *reinterpret_cast<f16x4*>(base + dst) = hi;
+    *reinterpret_cast<f16x4*>(base + plane_stride + dst) = lo;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      if (xdst[i] < 0) continue;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      split_store(xs, X_PLANE, xdst[i], ((xmask >> i) & 1u) ? xreg[i] : z, sx);
+    }
+#pragma unroll
+    for (int i = 0; i < DV; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      split_store(ds, D_PLANE, ddst[i], ((dstat >> i) & 1u) ? dreg[i] : z, sg);
+    }
+  };
+
+  const int grp_q = (lane & 15) >> 2, grp_p = lane & 3, cb16 = ((lane >> 4) & 1) * 16;
+  const int lane_off = (8 * lh + grp_q) * 64 + (cb16 + 4 * grp_p) * 2;
+  const unsigned char* xa = xs + wci * X_HALF + lane_off;
+  const unsigned char* db = ds + wco * D_HALF + lane_off;
+
+  if (pair_begin < pair_end) {
+    gload(pair_begin);
+    lstore();
+  }
+  __syncthreads();
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    const bool has_next = pr + 1 < pair_end;
+    if (has_next) gload(pr + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int ks = 0; ks < DPIX / 16; ++ks) {
+      const int rr = ks >> 1, w0 = (ks & 1) * 16;
+      f16x8 bfr[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bfr[pl] = tr_read8h(db + pl * D_PLANE + (rr * kW + w0) * 64);
+      f16x8 af[2][2];
+      const unsigned char* xk = xa + (rr * kPW + w0) * 64;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[0][pl] = tr_read8h(xk + pl * X_PLANE);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) {
+          const int kh = (t + 1) / 3, kw = (t + 1) % 3;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) af[(t + 1) & 1][pl] = tr_read8h(xk + pl * X_PLANE + (kh * kPW + kw) * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][1], bfr[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][0], bfr[1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t & 1][0], bfr[0], acc[t], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (has_next) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
+  const int n = n0 + wco * 32 + li;
+  if (n < N) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wci * 32 + mfma32_row(r, lane);
+        if (c < C) slab[((size_t)t * C + c) * N + n] = (acc[t][r] * inv_x) * inv_g;
+      }
+  }
+}
+
+__global__ void slab_reduce_h_kernel(const float* __restrict__ slab, float* __restrict__ out, int S, int E,
+                                     int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float s = 0.f;
+  int i = 0;
+  for (; i + 8 <= S; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(i + u) * E + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; i < S; ++i) s += slab[(size_t)i * E + e];
+  out[e] = accumulate ? out[e] + s : s;
+}
+
+int wgrad_splits_h(int B, int H, int C, int N) {
+  const int tiles = ((C + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
+  const int pairs = B * (H / WG_ROWS);
+  const int target = g_mulan_tune[1] > 0 ? g_mulan_tune[1] : 256;
+  int S = target / tiles;
+  if (S < 1) S = 1;
+  if (S > pairs) S = pairs;
+  while (S > 1 && pairs / S < 4) --S;
+  return S;
+}
+
+}  // namespace
+
+// out[r] = fp32 bit pattern of max |x[r, 0:row_len]| for r < rows  (row_len % 4 == 0, x 16-byte aligned).
+// The per-image maxima feed the power-of-two operand scales of the f16x3 kernels below.
+MULAN_API int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, hipStream_t stream) {
+  if (rows <= 0 || row_len == 0 || row_len % 4 != 0) return (int)hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)rows * sizeof(unsigned), stream);
+  if (e != hipSuccess) return (int)e;
+  const size_t len4 = row_len / 4;
+  int chunks = (int)((len4 + 256 * 8 - 1) / (256 * 8));          // >= 8 float4 per thread
+  const int want = (2048 + rows - 1) / rows;
+  if (chunks > want) chunks = want;
+  if (chunks < 1) chunks = 1;
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3(rows, chunks), dim3(256), 0, stream, x, out, len4);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N) { return (size_t)9 * C * N * 2 * 2; }
+
+// Packs (and scales, splits) the weights for mulan_conv3x3_fwd_f16x3; wmax[1] receives the fp32 bits of max|w|.
+MULAN_API int mulan_conv3x3_pack_f16x3(const float* w, void* wp, unsigned* wmax, int C, int N, int flip,
+                                       hipStream_t stream) {
+  const int Kin = flip ? N : C;
+  if (Kin % 16 != 0 || C <= 0 || N <= 0 || ((size_t)9 * C * N) % 4 != 0) return (int)hipErrorInvalidValue;
+  const int rc = mulan_absmax_rows(w, wmax, 1, (size_t)9 * C * N, stream);
+  if (rc != 0) return rc;
+  const size_t total = (size_t)9 * C * N;
+  const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(conv3x3_pack_f16x3_kernel, dim3(blocks), dim3(256), 0, stream, w, static_cast<_Float16*>(wp), wmax,
+                     C, N, flip);
+  MULAN_CHECK_LAUNCH();
+}
+
+// Eligibility: W == 32, H % 4 == 0, C % 16 == 0, N % 128 == 0 (the ResBlock convolutions); everything else goes
+// through mulan_conv3x3_fwd.  xmax = mulan_absmax_rows(x, B rows); wp / wmax from mulan_conv3x3_pack_f16x3.
+MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                      const float* bias, const float* cbias, int cbias_mode, const float* res,
+                                      float* y, int B, int H, int W, int C, int N, hipStream_t stream) {
+  if (W != kW || H % TROWS != 0 || B <= 0 || C % CK != 0 || C <= 0 || N % BN != 0 || N <= 0 || !xmax || !wmax)
+    return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_B);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  ConvArgsH a{x, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
+              cbias ? cbias_mode : 0, g_mulan_debug_buffer};
+  dim3 grid(B * (H / TROWS), N / BN);
+  hipLaunchKernelGGL(conv3x3_f16x3_kernel, grid, dim3(256), SMEM_B, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N) {
+  if (W != kW || H % WG_ROWS != 0) return 0;
+  return (size_t)wgrad_splits_h(B, H, C, N) * 9 * C * N * sizeof(float);
+}
+
+// dw[3,3,C,N] (+)= sum x (x) dy with the 3-pass fp16 split; xmax / dymax are the per-image maxima [B] of x and dy.
+MULAN_API int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax,
+                                        float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
+                                        hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % 4 != 0 || N % 4 != 0 || !xmax || !dymax)
+    return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int S = wgrad_splits_h(B, H, C, N);
+  WgradArgsH a{x, dy, workspace, xmax, dymax, B, H, C, N, S};
+  dim3 grid(S, (C + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T);
+  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel, grid, dim3(256), WG_SMEM, stream, a);
+  const int E = 9 * C * N;
+  hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
+  MULAN_CHECK_LAUNCH();
+}

@@ -16,10 +16,11 @@ H = W = 32
 HW = H * W
 D = HW * 3
 KERNEL_TIMER = None   # bench.py sets this to a list to time the dominant kernel with HIP events
-# "f32": exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  "bf16x6": 6-pass bf16 split with fp32-equivalent products
+# "f32": exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).  "f16x3": 3-pass fp16 split (two scaled fp16 pieces per fp32 operand)
+# with fp32-equivalent products.  "bf16x6": 6-pass bf16 split with fp32-equivalent products
 # (XLA's float32/HIGHEST matmul precision) for the eligible convolutions.  MULAN_CONV_MODE overrides.
 import os as _os
-CONV_MODE = _os.environ.get("MULAN_CONV_MODE", "bf16x6")
+CONV_MODE = _os.environ.get("MULAN_CONV_MODE", "f16x3")
 
 
 def _c(t):
@@ -32,8 +33,41 @@ def _chk(t, name="tensor"):
 
 
 # ----------------------------------------------------------------------------- raw launches
-def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
-    """x [B,1024,C], w [3,3,C,N] -> [B,1024,N]"""
+def _timed(name, flops, launch):
+    """runs launch(); under bench.py's KERNEL_TIMER brackets it with HIP events on the launch stream"""
+    if KERNEL_TIMER is None:
+        launch()
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    launch()
+    e.record()
+    KERNEL_TIMER.append((name, s, e, flops))
+
+
+def absmax_rows(x):
+    """[B] uint32: fp32 bit patterns of max|x[b]| -- the per-image operand scales of the f16x3 kernels"""
+    B = x.shape[0]
+    out = torch.empty(B, device=x.device, dtype=torch.int32)
+    call("mulan_absmax_rows", ptr(x), ptr(out), B, x.numel() // B, stream())
+    return out
+
+
+def _pack_weights(w, C, N, flip):
+    """weights pre-split into the LDS tile layout of the fast convolution kernels; returns (wp, wmax or None)"""
+    L = lib.load()
+    if CONV_MODE == "f16x3":
+        wp = torch.empty(L.mulan_conv3x3_pack_f16x3_bytes(C, N), device=w.device, dtype=torch.uint8)
+        wmax = torch.empty(1, device=w.device, dtype=torch.int32)
+        call("mulan_conv3x3_pack_f16x3", ptr(w), ptr(wp), ptr(wmax), C, N, flip, stream())
+        return wp, wmax
+    wp = torch.empty(L.mulan_conv3x3_pack_bf16x6_bytes(C, N), device=w.device, dtype=torch.uint8)
+    call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, flip, stream())
+    return wp, None
+
+
+def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None):
+    """x [B,1024,C], w [3,3,C,N] -> [B,1024,N]   (xmax: absmax_rows(x) if the caller already has it, f16x3 mode)"""
     _chk(x, "conv input")
     B, C, N = x.shape[0], x.shape[-1], w.shape[-1]
     assert w.shape[:3] == (3, 3, C), (w.shape, C)
@@ -41,48 +75,45 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None):
     mode = 0
     if cbias is not None:
         mode = 1 if cbias.dim() == 2 else 2
-    fast = CONV_MODE == "bf16x6" and C % 16 == 0 and N % 128 == 0
-
-    wp = None
-    if fast:
-        wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=x.device, dtype=torch.uint8)
-        call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 0, stream())
-
-    def launch():
-        if fast:
-            call("mulan_conv3x3_fwd_bf16x6", ptr(x), ptr(wp), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W,
-                 C, N, stream())
-        else:
-            call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W, C, N,
-                 stream())
-    if KERNEL_TIMER is None:
-        launch()
-    else:   # bench.py: HIP events on the launch stream around this one kernel
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        launch()
-        e.record()
+    fast = CONV_MODE in ("bf16x6", "f16x3") and C % 16 == 0 and N % 128 == 0
+    flops = 2.0 * B * HW * 9 * C * N
+    if not fast:
         variant = "<128,2,2>" if N > 64 else ("<64,2,2>" if N > 32 else "<32,4,1>")
-        name = "conv3x3_bf16x6_kernel" if fast else "conv3x3_fwd_kernel" + variant
-        KERNEL_TIMER.append((name, s, e, 2.0 * B * HW * 9 * C * N))
+        _timed("conv3x3_fwd_kernel" + variant, flops,
+               lambda: call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W,
+                            C, N, stream()))
+        return y
+    wp, wmax = _pack_weights(w, C, N, 0)
+    if CONV_MODE == "f16x3":
+        if xmax is None:
+            xmax = absmax_rows(x)
+        _timed("conv3x3_f16x3_kernel", flops,
+               lambda: call("mulan_conv3x3_fwd_f16x3", ptr(x), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cbias), mode,
+                            ptr(res), ptr(y), B, H, W, C, N, stream()))
+    else:
+        _timed("conv3x3_bf16x6_kernel", flops,
+               lambda: call("mulan_conv3x3_fwd_bf16x6", ptr(x), ptr(wp), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y),
+                            B, H, W, C, N, stream()))
     return y
 
 
-def conv3x3_dgrad_raw(dy, w):
+def conv3x3_dgrad_raw(dy, w, dymax=None):
     C, N = w.shape[2], w.shape[3]
-    if CONV_MODE == "bf16x6" and N % 16 == 0 and C % 128 == 0:
+    if CONV_MODE in ("bf16x6", "f16x3") and N % 16 == 0 and C % 128 == 0:
         B = dy.shape[0]
         dx = torch.empty((B, HW, C), device=dy.device, dtype=torch.float32)
-        wp = torch.empty(lib.load().mulan_conv3x3_pack_bf16x6_bytes(C, N), device=w.device, dtype=torch.uint8)
-        call("mulan_conv3x3_pack_bf16x6", ptr(w), ptr(wp), C, N, 1, stream())
-        if KERNEL_TIMER is None:
-            call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C, stream())
+        wp, wmax = _pack_weights(w, C, N, 1)
+        flops = 2.0 * B * HW * 9 * C * N
+        if CONV_MODE == "f16x3":
+            if dymax is None:
+                dymax = absmax_rows(dy)
+            _timed("conv3x3_f16x3_kernel", flops,
+                   lambda: call("mulan_conv3x3_fwd_f16x3", ptr(dy), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
+                                ptr(dx), B, H, W, N, C, stream()))
         else:
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C, stream())
-            e.record()
-            KERNEL_TIMER.append(("conv3x3_bf16x6_kernel", s, e, 2.0 * B * HW * 9 * C * N))
+            _timed("conv3x3_bf16x6_kernel", flops,
+                   lambda: call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C,
+                                stream()))
         return dx
     wT = torch.empty((3, 3, N, C), device=w.device, dtype=torch.float32)
     call("mulan_conv3x3_wflip", ptr(w), ptr(wT), C, N, stream())
@@ -99,22 +130,23 @@ def _fresh(view):
     return view.view(view.shape)
 
 
-def conv3x3_wgrad_raw(x, dy, out=None):
+def conv3x3_wgrad_raw(x, dy, out=None, xmax=None, dymax=None):
     B, C, N = x.shape[0], x.shape[-1], dy.shape[-1]
-    fast = CONV_MODE == "bf16x6" and C % 4 == 0 and N % 4 == 0
-    fn = "mulan_conv3x3_wgrad_bf16x6" if fast else "mulan_conv3x3_wgrad"
+    fast = CONV_MODE in ("bf16x6", "f16x3") and C % 4 == 0 and N % 4 == 0
+    kind = CONV_MODE if fast else ""
+    fn = "mulan_conv3x3_wgrad" + ("_" + kind if fast else "")
     nbytes = getattr(lib.load(), fn + "_workspace")(B, H, W, C, N)
     ws = torch.empty(nbytes // 4, device=x.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((3, 3, C, N), device=x.device, dtype=torch.float32)
-    if KERNEL_TIMER is None:
-        call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
+    name = "conv3x3_wgrad" + ("_" + kind if fast else "") + "_kernel+slab_reduce"
+    flops = 2.0 * B * HW * 9 * C * N
+    if kind == "f16x3":
+        xmax = absmax_rows(x) if xmax is None else xmax
+        dymax = absmax_rows(dy) if dymax is None else dymax
+        _timed(name, flops, lambda: call(fn, ptr(x), ptr(xmax), ptr(dy), ptr(dymax), ptr(dw), ptr(ws), B, H, W, C, N, 0,
+                                         stream()))
     else:
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream())
-        e.record()
-        KERNEL_TIMER.append((("conv3x3_wgrad_bf16x6_kernel" if fast else "conv3x3_wgrad_kernel") + "+slab_reduce", s, e,
-                             2.0 * B * HW * 9 * C * N))
+        _timed(name, flops, lambda: call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream()))
     return dw
 
 
@@ -162,8 +194,11 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, cbias, res):
         x, w = _c(x), _c(w)
-        y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res))
+        f16 = CONV_MODE == "f16x3" and x.shape[-1] % 4 == 0        # per-image maxima: shared by fwd and wgrad
+        xmax = absmax_rows(x) if f16 else None
+        y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax)
         ctx.save_for_backward(x, w)
+        ctx.xmax = xmax
         ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
         ctx.gv = (_gv(w), _gv(bias))
         return y
@@ -176,10 +211,11 @@ class Conv3x3Fn(torch.autograd.Function):
         has_bias, cb_dim, has_res = ctx.has
         gvw, gvb = ctx.gv
         B, N = dy.shape[0], dy.shape[-1]
-        dx = conv3x3_dgrad_raw(dy, w) if ctx.needs_input_grad[0] else None
+        dymax = absmax_rows(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
+        dx = conv3x3_dgrad_raw(dy, w, dymax=dymax) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
-            dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None)
+            dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None, xmax=ctx.xmax, dymax=dymax)
         dbias = dcb = None
         per_sample = None
         if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):

@@ -18,6 +18,9 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "MULAN_FORCE_DEVICE" in os.environ:      # test hook: several ranks share one GPU (needs MULAN_DIST_BACKEND=gloo)
+        local = int(os.environ["MULAN_FORCE_DEVICE"])
+    backend = backend or os.environ.get("MULAN_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -1,0 +1,151 @@
+"""The 3-pass fp16 split convolution (two power-of-two-scaled fp16 pieces per fp32 operand; fp32-equivalent products on
+the fp16 matrix cores) against the same oracle and tolerances as the exact-fp32 MFMA kernel: bit-exact on integer data,
+on random data an error vs float64 of the same order as the fp32 kernel's own (2^-23-ish relative to sum |a||b|), and
+no loss for images of very different magnitude inside one batch (per-image scales)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mulan_np as onp
+from oracle import torch_ref as tr
+
+
+@pytest.fixture()
+def ops(monkeypatch):
+    from mulan_amd import ops as _ops
+    _ops.lib.load()
+    monkeypatch.setattr(_ops, "CONV_MODE", "f16x3")
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).float().cuda()
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (1, 128, 256), (1, 16, 128), (3, 48, 128)])
+def test_f16x3_conv_exact_on_integers(ops, B, C, N):
+    rng = np.random.default_rng(B + C + N)
+    x = rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64)
+    w = rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64)
+    bias, cb = rng.integers(-3, 4, N).astype(np.float64), rng.integers(-3, 4, (B, N)).astype(np.float64)
+    res = rng.integers(-3, 4, (B, 32, 32, N)).astype(np.float64)
+    ref = onp.conv3x3(x, w, bias) + cb[:, None, None, :] + res
+    y = ops.conv3x3_raw(dev(x).view(B, 1024, C), dev(w), dev(bias), dev(cb), dev(res).view(B, 1024, N))
+    assert np.array_equal(y.cpu().double().numpy().reshape(ref.shape), ref)
+    cb2 = rng.integers(-3, 4, (B, 32, 32, N)).astype(np.float64)
+    y2 = ops.conv3x3_raw(dev(x).view(B, 1024, C), dev(w), None, dev(cb2).view(B, 1024, N), None)
+    assert np.array_equal(y2.cpu().double().numpy().reshape(ref.shape), onp.conv3x3(x, w) + cb2)
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (1, 128, 256)])
+def test_f16x3_dgrad_exact_on_integers(ops, B, C, N):
+    rng = np.random.default_rng(C * 3 + N)
+    x = torch.tensor(rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64), requires_grad=True)
+    w = torch.tensor(rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64))
+    dy = torch.tensor(rng.integers(-2, 3, (B, 32, 32, N)).astype(np.float64))
+    tr.conv3x3(x, {"kernel": w}).backward(dy)
+    dx = ops.conv3x3_dgrad_raw(dev(dy).view(B, 1024, N), dev(w))
+    assert np.array_equal(dx.cpu().double().numpy().reshape(B, 32, 32, C), x.grad.numpy())
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (3, 64, 64), (1, 16, 128), (2, 48, 96), (1, 128, 4)])
+def test_f16x3_wgrad_exact_on_integers(ops, B, C, N):
+    rng = np.random.default_rng(C * 5 + N + B)
+    x = torch.tensor(rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64))
+    w = torch.tensor(rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64), requires_grad=True)
+    dy = torch.tensor(rng.integers(-2, 3, (B, 32, 32, N)).astype(np.float64))
+    tr.conv3x3(x, {"kernel": w}).backward(dy)
+    dw = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N))
+    assert np.array_equal(dw.cpu().double().numpy(), w.grad.numpy())
+
+
+def test_f16x3_wgrad_accuracy(ops, monkeypatch):
+    rng = np.random.default_rng(1)
+    B, C, N = 4, 128, 128
+    x = rng.standard_normal((B, 32, 32, C)) * np.exp(rng.standard_normal((B, 32, 32, C)))
+    dy = rng.standard_normal((B, 32, 32, N)) * np.exp(rng.standard_normal((B, 32, 32, N)))
+    xt = torch.tensor(x.astype(np.float32).astype(np.float64))
+    wt = torch.zeros(3, 3, C, N, dtype=torch.float64, requires_grad=True)
+    tr.conv3x3(xt, {"kernel": wt}).backward(torch.tensor(dy.astype(np.float32).astype(np.float64)))
+    ref = wt.grad.numpy()
+    d6 = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N)).cpu().double().numpy()
+    monkeypatch.setattr(ops, "CONV_MODE", "f32")
+    d32 = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N)).cpu().double().numpy()
+    scale = np.abs(ref).max()
+    e6, e32 = np.abs(d6 - ref).max() / scale, np.abs(d32 - ref).max() / scale
+    assert e6 < 1e-5 and e32 < 1e-5 and e6 < 2 * e32 + 1e-6, (e6, e32)
+
+
+def test_f16x3_accuracy_matches_fp32_kernel(ops, monkeypatch):
+    """random data with a wide dynamic range: max error relative to sum_k |a_k b_k| for both kernels"""
+    rng = np.random.default_rng(0)
+    B, C, N = 2, 128, 128
+    x = rng.standard_normal((B, 32, 32, C)) * np.exp(rng.standard_normal((B, 32, 32, C)))
+    w = rng.standard_normal((3, 3, C, N)) * np.exp(rng.standard_normal((3, 3, C, N))) / math.sqrt(9 * C)
+    ref = onp.conv3x3(x, w)
+    mag = onp.conv3x3(np.abs(x), np.abs(w))             # sum |a||b| per output
+    y6 = ops.conv3x3_raw(dev(x).view(B, 1024, C), dev(w)).cpu().double().numpy().reshape(ref.shape)
+    monkeypatch.setattr(ops, "CONV_MODE", "f32")
+    y32 = ops.conv3x3_raw(dev(x).view(B, 1024, C), dev(w)).cpu().double().numpy().reshape(ref.shape)
+    # inputs were rounded to fp32 on the way in: compare against the float64 conv of the rounded inputs
+    ref = onp.conv3x3(x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64))
+    e6 = float((np.abs(y6 - ref) / mag).max())
+    e32 = float((np.abs(y32 - ref) / mag).max())
+    # K = 1152 products accumulated in fp32: both kernels sit at ~1e-6 of sum|a||b|; the split must not be worse
+    assert e32 < 3e-6 and e6 < 3e-6 and e6 < 1.5 * e32 + 2e-7, (e6, e32)
+    assert float(np.abs(y6 - ref).max() / np.abs(ref).max()) < 1e-5   # the bar of test_conv3x3_float_tolerance
+
+
+def test_f16x3_whole_model_parity(ops):
+    """MuLAN train-mode step through the f16x3 convolutions: same parity bars as the fp32 path"""
+    from tests.test_gpu_model import run_case
+    run_case("mulan_velocity", "vdm", False, train=True)
+
+
+def test_absmax_rows(ops):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((5, 1024, 48)).astype(np.float32)
+    x[1] *= 1e-20
+    x[2] = 0.0
+    x[3, 1023, 47] = -77.0
+    x[4, 0, 0] = 1e30
+    got = ops.absmax_rows(dev(x)).cpu().numpy().view(np.float32)
+    assert np.array_equal(got, np.abs(x).reshape(5, -1).max(1))
+
+
+def test_f16x3_per_image_dynamic_range(ops):
+    """images whose magnitudes differ by 10^14 in one batch: every image keeps fp32-level accuracy (fwd and dgrad)"""
+    rng = np.random.default_rng(11)
+    B, C, N = 4, 128, 128
+    x = rng.standard_normal((B, 32, 32, C))
+    x *= np.array([1e-8, 1.0, 1e6, 3e-3])[:, None, None, None]
+    w = rng.standard_normal((3, 3, C, N)) / math.sqrt(9 * C)
+    x32, w32 = x.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64)
+    ref, mag = onp.conv3x3(x32, w32), onp.conv3x3(np.abs(x32), np.abs(w32))
+    y = ops.conv3x3_raw(dev(x).view(B, 1024, C), dev(w)).cpu().double().numpy().reshape(ref.shape)
+    for b in range(B):
+        assert float((np.abs(y[b] - ref[b]) / mag[b]).max()) < 3e-6, b
+    wt = torch.tensor(w32)
+    xt = torch.tensor(x32, requires_grad=True)
+    dy = torch.tensor(np.ascontiguousarray(np.broadcast_to(x32[..., :1], x32.shape)))   # same per-image magnitudes
+    tr.conv3x3(xt, {"kernel": wt}).backward(dy)
+    dx = ops.conv3x3_dgrad_raw(dev(dy.numpy()).view(B, 1024, N), dev(w)).cpu().double().numpy().reshape(x.shape)
+    for b in range(B):
+        err = np.abs(dx[b] - xt.grad[b].numpy()).max() / np.abs(xt.grad[b].numpy()).max()
+        assert err < 1e-5, (b, err)
+
+
+def test_f16x3_zero_operands(ops):
+    """all-zero weights (the reference zero-initialises the second ResBlock convolution) and all-zero inputs"""
+    B, C, N = 2, 128, 128
+    x = torch.randn(B, 1024, C, device="cuda")
+    z = ops.conv3x3_raw(x, torch.zeros(3, 3, C, N, device="cuda"))
+    assert torch.count_nonzero(z) == 0
+    z = ops.conv3x3_raw(torch.zeros_like(x), torch.randn(3, 3, C, N, device="cuda"))
+    assert torch.count_nonzero(z) == 0
+    z = ops.conv3x3_wgrad_raw(torch.zeros_like(x), torch.randn(B, 1024, N, device="cuda"))
+    assert torch.count_nonzero(z) == 0

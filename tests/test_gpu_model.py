@@ -320,3 +320,30 @@ def test_gradient_sink_equals_autograd_accumulation():
     g_ref, _ = grads(False)
     assert torch.equal(g_sink, g_ref)
     assert aliased >= 0.9 * len(st._leaves), (aliased, len(st._leaves))   # autograd adopted the flat views
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's N > 1 control flow (sharded batches, bucketed side-stream all-reduce, barriers, max-over-ranks timing,
+    rank-0 JSON) with two ranks on the one GPU of this box.  RCCL refuses two ranks per device, so the collective
+    backend is gloo over the device tensors here; the calls are the same torch.distributed ones."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {**os.environ, "MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8"],
+                       capture_output=True, text=True, timeout=840, env=env, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["roofline"] is not None and out["cpu_baseline"] is None

@@ -134,7 +134,7 @@ def stamps(batch, C=128, N=128, tune="", mode=None):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "stamps":
-        for md in ("f32", "bf16x6"):
+        for md in ("bf16x6", "f16x3"):
             for bsz in (32, 128):
                 stamps(bsz, mode=md)
             stamps(128, C=256, mode=md)
