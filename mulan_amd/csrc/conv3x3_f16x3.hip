@@ -281,6 +281,218 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_kernel(ConvArgsH p) {
   if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+// ---- "big tile" variant: block = 8 image rows x 128 couts, wave = 4 rows x 64 couts (4 x 2 MFMA tiles, 128
+// accumulator registers, one wave per SIMD).  The weight fragments are read straight from the packed global tensor
+// (L2/L1 resident, two stages ahead, no LDS copy and no per-stage barrier); only the activation patch goes through
+// LDS, double buffered, with one barrier per 16-channel chunk.  LDS traffic per MFMA is half that of the 2 x 2
+// variant above, which is LDS-bandwidth bound with three passes per product.
+constexpr int TR2 = 8;
+constexpr int PATCH2_B = (TR2 + 2) * kPW * PIXB;     // 27200
+constexpr int SMEM2_B = 2 * PATCH2_B + 64;           // 54464 (+ dummy store target)
+
+__global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
+  constexpr int MT = 4, NT = 2;
+  constexpr int PV = 6;                          // float4 patch slots per thread (1360 slots)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_per_img = p.H / TR2;
+  const int b = blockIdx.x / tiles_per_img;
+  const int h0 = (blockIdx.x % tiles_per_img) * TR2;
+  const int n0 = blockIdx.y * BN;
+  const int C = p.C, N = p.N;
+  const int nchunks = C / CK;
+  const float* xb = p.x + (size_t)b * p.H * kW * C;
+  float sx, inv_x, sw, inv_w;
+  scale_of(p.xmax[b], sx, inv_x);
+  scale_of(p.wmax[0], sw, inv_w);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* pptr[PV];
+  int pdst[PV];
+  unsigned phalo = 0;
+#pragma unroll
+  for (int s = 0; s < PV; ++s) {
+    const int slot = tid + s * 256;
+    const int q = slot & 3, pix = slot >> 2;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int hh = h0 + prow - 1, ww = pcol - 1;
+    const bool inb = slot < (TR2 + 2) * kPW * 4;
+    const bool ok = inb && hh >= 0 && hh < p.H && ww >= 0 && ww < kW;
+    pptr[s] = ok ? xb + ((size_t)hh * kW + ww) * C + q * 4 : p.x;
+    pdst[s] = inb ? pix * PIXB + q * 8 : -1;
+    phalo |= (ok ? 1u : 0u) << s;
+  }
+  f32x4 preg[PV];
+  auto gload_patch = [&](int cc) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) preg[s] = *reinterpret_cast<const f32x4*>(pptr[s] + (((phalo >> s) & 1u) ? cc * CK : 0));
+  };
+  // branch free (the loop body must stay one basic block so that this work can be scheduled between the MFMAs):
+  // slots beyond the patch, and every slot when `live` is false, land in a dummy area behind the two patches
+  auto store_slot = [&](unsigned char* pb, int s, bool live) {
+    f32x4 v = preg[s];
+    if (!((phalo >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 h, l;
+      split2(v[e] * sx, h, l);
+      hi[e] = h; lo[e] = l;
+    }
+    unsigned char* d = (live && pdst[s] >= 0) ? pb + pdst[s] : smem + 2 * PATCH2_B;
+    *reinterpret_cast<f16x4*>(d) = hi;
+    *reinterpret_cast<f16x4*>(d + 32) = lo;
+  };
+  auto store_patch = [&](unsigned char* pb) {
+#pragma unroll
+    for (int s = 0; s < PV; ++s) store_slot(pb, s, true);
+  };
+  // weight fragments: packed [tap][chunk][cout][plane][16 k] fp16; this lane's 8 k of cout (n0 + wn*64 + nt*32 + li)
+  const size_t tile_stride = (size_t)N * 64;
+  const unsigned char* bbase = p.wp + (size_t)(n0 + wn * 64 + li) * 64 + lh * 16;
+  auto gload_b = [&](f16x8 (&bs)[NT][2], int cc, int tap) {
+    const unsigned char* t = bbase + ((size_t)tap * nchunks + cc) * tile_stride;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bs[nt][pl] = *reinterpret_cast<const f16x8*>(t + nt * 2048 + pl * 32);
+  };
+  auto read_a = [&](f16x8 (&af)[MT][2], const unsigned char* pb, int tap) {
+    const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int prow = wm * MT + mt + kh, pcol = li + kw;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        af[mt][pl] = *reinterpret_cast<const f16x8*>(pb + (prow * kPW + pcol) * PIXB + pl * 32 + lh * 16);
+    }
+  };
+
+  const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+  if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
+  f16x8 bq[3][NT][2];
+  f16x8 afc[MT][2], afn[MT][2];
+  gload_patch(0);
+  gload_b(bq[0], 0, 0);
+  gload_b(bq[1], 0, 1);                            // nchunks * 9 >= 9 stages
+  store_patch(smem);
+  __syncthreads();
+  read_a(afc, smem, 0);
+  if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
+
+  for (int cc = 0; cc < nchunks; ++cc) {
+    if (stamp && cc < 20) p.stamps[2 + cc] = __builtin_amdgcn_s_memtime();
+    const unsigned char* pcur = smem + (cc & 1) * PATCH2_B;
+    unsigned char* pnxt = smem + ((cc + 1) & 1) * PATCH2_B;
+    const bool more = cc + 1 < nchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap == 8) __syncthreads();               // next chunk's patch (stored at taps 2..7) is complete
+      read_a(afn, tap < 8 ? pcur : pnxt, tap < 8 ? tap + 1 : 0);
+      {                                            // past the last tile: a harmless reload of the last chunk
+        const int t2 = tap + 2 >= 9 ? tap + 2 - 9 : tap + 2;
+        const int c2 = tap + 2 >= 9 ? cc + 1 : cc;
+        gload_b(bq[(tap + 2) % 3], c2 < nchunks ? c2 : nchunks - 1, t2);
+      }
+      if (tap == 0) gload_patch(more ? cc + 1 : cc);
+      // the next patch is split and stored one float4 slot per stage (taps 2..7), inside the MFMA shadow
+      if (tap >= 2 && tap < 2 + PV) store_slot(pnxt, tap - 2, more);
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afc[mt][PA[term]], bq[tap % 3][nt][PB[term]], acc[mt][nt],
+                                                                 0, 0, 0);
+      }
+      // issue order inside the stage: one MFMA at a time, with the next stage's LDS reads / global loads and the
+      // VALU + LDS-write work of the patch slot spread over the MFMA shadows
+#pragma unroll
+      for (int g = 0; g < 24; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (g < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        else if (g < 18) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        if (g >= 12) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) afc[mt][pl] = afn[mt][pl];
+    }
+  }
+
+  if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
+  // epilogue: per image row, transposed through LDS so every lane moves float4s; scales divided out here
+  const float* __restrict__ res = p.res;
+  const float* __restrict__ cbp = p.cbias;
+  float* __restrict__ yout = p.y;
+  constexpr int TS = 64 + 4;
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * TS;
+  const int c4 = lane & 15, prl = lane >> 4;
+  const int nb = n0 + wn * 64 + c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + nb);
+  if (p.cbias_mode == 1) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + (size_t)b * N + nb);
+    bias4[0] += c[0]; bias4[1] += c[1]; bias4[2] += c[2]; bias4[3] += c[3];
+  }
+  // (issuing the residual / per-pixel bias loads of all four rows up front was measured slower: the epilogue is bound
+  // by the memory system's throughput -- every CU is in its epilogue at the same time -- not by load latency)
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = (acc[mt][nt][r] * inv_x) * inv_w;
+    const size_t rowbase = (((size_t)b * p.H + h0 + wm * MT + mt) * kW) * N + nb;
+    f32x4 add[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) add[it] = bias4;
+    if (p.cbias_mode == 2) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + rowbase + (size_t)(it * 4 + prl) * N);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+    if (res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(res + rowbase + (size_t)(it * 4 + prl) * N);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+    // the staging tile is private to this wave: only wave-level ordering is needed
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's ds_writes have landed
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + (it * 4 + prl) * TS + c4 * 4);
+      const f32x4 o = {a[0] + add[it][0], a[1] + add[it][1], a[2] + add[it][2], a[3] + add[it][3]};
+      *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * N) = o;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+}
+
 // out[r] = fp32 bits of max |x[r, :]| (out zeroed by the caller; non-negative floats order like their bit patterns)
 __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, unsigned* __restrict__ out,
                                                           size_t row_len4) {
@@ -602,6 +814,17 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
   }
   ConvArgsH a{x, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
               cbias ? cbias_mode : 0, g_mulan_debug_buffer};
+  if (H % TR2 == 0 && g_mulan_tune[3] != 1) {     // tune[3] = 1: dev A/B switch back to the 2 x 2-tile variant
+    static bool configured2 = false;
+    if (!configured2) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v2_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM2_B);
+      if (e != hipSuccess) return (int)e;
+      configured2 = true;
+    }
+    hipLaunchKernelGGL(conv3x3_f16x3_v2_kernel, dim3(B * (H / TR2), N / BN), dim3(256), SMEM2_B, stream, a);
+    MULAN_CHECK_LAUNCH();
+  }
   dim3 grid(B * (H / TROWS), N / BN);
   hipLaunchKernelGGL(conv3x3_f16x3_kernel, grid, dim3(256), SMEM_B, stream, a);
   MULAN_CHECK_LAUNCH();
