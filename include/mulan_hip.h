@@ -72,13 +72,24 @@ int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, m
 size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N);
 int mulan_conv3x3_pack_f16x3(const float* w, void* wp, unsigned* wmax, int C, int N, int flip, mulan_stream_t stream);
 int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
-                            const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, int B,
-                            int H, int W, int C, int N, mulan_stream_t stream);
+                            const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, void* xs,
+                            int B, int H, int W, int C, int N, mulan_stream_t stream);
 
 size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,
                               float* workspace, int B, int H, int W, int C, int N, int accumulate,
                               mulan_stream_t stream);
+
+/* The convolution above can hand its split operand on: xs (optional, mulan_conv3x3_planes_bytes) receives the two
+ * scaled fp16 planes of x as [B][C/16][H*W][plane][16].  The weight gradient below consumes the planes of the forward
+ * input (xs, from the forward call) and of the output gradient (dys, from the input-gradient call, i.e. the same
+ * kernel run on dy with flip = 1 weights), so the fp32 -> 2 x fp16 split is done once per tensor.  xmax / dymax are
+ * the per-image maxima the planes were scaled with.  Needs C % 128 == 0 and N % 128 == 0. */
+size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C);
+size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N);
+int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
+                                     float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
+                                     mulan_stream_t stream);
 
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),

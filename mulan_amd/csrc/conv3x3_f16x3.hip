@@ -54,7 +54,12 @@ struct ConvArgsH {
   float* y;
   int B, H, C, N, cbias_mode;
   unsigned long long* stamps;   // dev-only (mulan_set_debug_buffer)
+  unsigned char* xs;            // optional by-product: the split planes of x, [B][C/16][H*W][plane][16] fp16
 };
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBufWord3 = 0x00020000;           // raw buffer resource (no swizzle); out-of-range lanes are dropped / read 0
 
 __global__ __launch_bounds__(256) void conv3x3_f16x3_kernel(ConvArgsH p) {
   constexpr int MT = 2, NT = 2, WN = 2;
@@ -319,6 +324,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
 
   const float* pptr[PV];
   int pdst[PV];
+  unsigned pemit[PV];
   unsigned phalo = 0;
 #pragma unroll
   for (int s = 0; s < PV; ++s) {
@@ -331,7 +337,13 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
     pptr[s] = ok ? xb + ((size_t)hh * kW + ww) * C + q * 4 : p.x;
     pdst[s] = inb ? pix * PIXB + q * 8 : -1;
     phalo |= (ok ? 1u : 0u) << s;
+    // byte offset of this slot's hi quad inside (image b, chunk 0) of the plane tensor; interior pixels only
+    const bool interior = inb && prow >= 1 && prow <= TR2 && ww >= 0 && ww < kW;
+    pemit[s] = interior ? (unsigned)(((hh * kW + ww) * 2) * 32 + q * 8) : 0xffffffffu;
   }
+  // plane output window of this block: image b (nothing for the other cout blocks, or when not requested)
+  const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.xs + (size_t)b * nchunks * 65536, 0, (p.xs && blockIdx.y == 0) ? nchunks * 65536 : 0, kBufWord3);
   f32x4 preg[PV];
   auto gload_patch = [&](int cc) {
 #pragma unroll
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   };
   // branch free (the loop body must stay one basic block so that this work can be scheduled between the MFMAs):
   // slots beyond the patch, and every slot when `live` is false, land in a dummy area behind the two patches
-  auto store_slot = [&](unsigned char* pb, int s, bool live) {
+  auto store_slot = [&](unsigned char* pb, int s, bool live, int cc) {
     f32x4 v = preg[s];
     if (!((phalo >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
     f16x4 hi, lo;
@@ -352,10 +364,14 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
     unsigned char* d = (live && pdst[s] >= 0) ? pb + pdst[s] : smem + 2 * PATCH2_B;
     *reinterpret_cast<f16x4*>(d) = hi;
     *reinterpret_cast<f16x4*>(d + 32) = lo;
+    // the same two quads go to the plane tensor (consumed by the weight-gradient kernel)
+    const unsigned eo = (live && pemit[s] != 0xffffffffu) ? pemit[s] + (unsigned)cc * 65536u : 0xffffffffu;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), xs_rsrc, eo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo == 0xffffffffu ? eo : eo + 32, 0, 0);
   };
-  auto store_patch = [&](unsigned char* pb) {
+  auto store_patch = [&](unsigned char* pb, int cc) {
 #pragma unroll
-    for (int s = 0; s < PV; ++s) store_slot(pb, s, true);
+    for (int s = 0; s < PV; ++s) store_slot(pb, s, true, cc);
   };
   // weight fragments: packed [tap][chunk][cout][plane][16 k] fp16; this lane's 8 k of cout (n0 + wn*64 + nt*32 + li)
   const size_t tile_stride = (size_t)N * 64;
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   gload_patch(0);
   gload_b(bq[0], 0, 0);
   gload_b(bq[1], 0, 1);                            // nchunks * 9 >= 9 stages
-  store_patch(smem);
+  store_patch(smem, 0);
   __syncthreads();
   read_a(afc, smem, 0);
   if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
@@ -406,7 +422,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
       }
       if (tap == 0) gload_patch(more ? cc + 1 : cc);
       // the next patch is split and stored one float4 slot per stage (taps 2..7), inside the MFMA shadow
-      if (tap >= 2 && tap < 2 + PV) store_slot(pnxt, tap - 2, more);
+      if (tap >= 2 && tap < 2 + PV) store_slot(pnxt, tap - 2, more, cc + 1);
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
         constexpr int PA[3] = {1, 0, 0};
@@ -737,6 +753,261 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(WgradArgsH p) 
   }
 }
 
+// ---- plane-fed, row-split weight-gradient kernel.
+// Inputs are the split planes that the forward / input-gradient convolutions write as a by-product
+// ([B][C/16][H*W][plane][16] fp16, scaled per image), so staging is a plain copy: the fp32 -> 2 x fp16 split is done
+// once per tensor instead of once per consuming block, and nothing competes with the MFMAs for the VALU.  The
+// accumulators live in the units of the image being multiplied (s_x[b] s_dy[b]): when the pixel range crosses into the
+// next image they are multiplied by the exact power of two between the two images' scales (in place, on the accumulator
+// registers).
+// A block owns one kernel row kh (3 taps) of a 128 ci x 128 co tile, a wave 64 ci x 64 co x 3 taps (192 accumulator
+// registers, one wave per SIMD): every transposed x fragment feeds two co tiles and every dy fragment six MFMAs,
+// ~45 % of the LDS traffic per MFMA of the 9-tap kernel above, and no vertical halo.  The three kh blocks of one pixel
+// range run on the same XCD (same blockIdx.x, S % 8 == 0): the planes come from HBM once and from L2 twice.
+// Three row pairs are in flight: pair p is multiplied out of LDS buffer (p & 1), pair p + 1 sits in registers and is
+// copied into the other buffer, pair p + 2 is being fetched (a whole iteration of latency budget); one barrier / pair.
+constexpr int WG3_T = 128;
+constexpr int X3PIX = WG_ROWS * kPW;                          // 68 pixels: 2 rows x (32 + 2 halo columns)
+constexpr int X3_HALF = X3PIX * 64 + 64, X3_PLANE = 4 * X3_HALF + 32;   // +64: the 4 halves of a pixel start 16 banks
+constexpr int D3_HALF = DPIX * 64 + 64, D3_PLANE = 4 * D3_HALF + 32;    // apart; +32: plane 1 sits 8 banks further
+constexpr int WG3_BUF = 2 * X3_PLANE + 2 * D3_PLANE;          // 35392 + 33344 = 68736
+constexpr int WG3_SMEM = 2 * WG3_BUF;                         // 137472
+
+struct WgradArgsP {
+  const unsigned char* xs; const unsigned char* dys;   // split planes of x [B][C/16][HW][2][16], dy [B][N/16][HW][2][16]
+  const unsigned* xmax; const unsigned* dymax;         // [B] per-image maxima the planes were scaled with
+  float* slab;
+  int B, H, C, N, S;
+  unsigned long long* stamps;                          // dev-only (mulan_set_debug_buffer)
+};
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+
+__device__ __forceinline__ int clamped_exp(unsigned maxbits) {
+  const int e = (int)((maxbits >> 23) & 255u);
+  return e < 14 ? 14 : (e > 254 ? 254 : e);
+}
+
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradArgsP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wci = wave >> 1, wco = wave & 1;
+  const int C = p.C, N = p.N;
+  const int kh = blockIdx.y;
+  const int ntn = N / WG3_T;
+  const int c0 = (blockIdx.z / ntn) * WG3_T, n0 = (blockIdx.z % ntn) * WG3_T;
+  const int nchc = C / 16, nchn = N / 16;
+  const int pairs_per_img = p.H / WG_ROWS;
+  const int total_pairs = p.B * pairs_per_img;
+  const int pair_begin = (int)((long long)blockIdx.x * total_pairs / p.S);
+  const int pair_end = (int)((long long)(blockIdx.x + 1) * total_pairs / p.S);
+
+  f32x16 acc[3][2][2];      // [kw][ci tile][co tile]
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+
+  // staging units of 16 bytes (8 channels of one plane of one pixel): unit e = tid + 256 i,
+  //   e & 3 -> (plane, channel half),  e >> 2 = chunk * pixels + pixel   (consecutive lanes: consecutive 64-B records)
+  constexpr int XV = (X3PIX * 32 + 255) / 256;  // 9 (2176 units)
+  constexpr int DV = (DPIX * 32) / 256;         // 8 (2048 units)
+  i32x4 xreg[XV], dreg[DV];
+  const __amdgpu_buffer_rsrc_t xs_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.xs), 0, p.B * nchc * 65536, kBufWord3);
+  const __amdgpu_buffer_rsrc_t ds_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.dys), 0, p.B * nchn * 65536, kBufWord3);
+  const int u = tid & 3, upl = u >> 1, uh = u & 1;
+  auto gload_x1 = [&](int pr, int i) {
+    const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
+    const int t = (tid >> 2) + 64 * i;
+    const int cc = t / X3PIX, pix = t - cc * X3PIX;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int hh = h0 + kh - 1 + prow;
+    const bool ok = t < 8 * X3PIX && pcol >= 1 && pcol <= kW && hh >= 0 && hh < p.H;
+    const unsigned off = (unsigned)((((b * nchc + (c0 >> 4) + cc) * 1024 + hh * kW + pcol - 1) * 2 + upl) * 32 + uh * 16);
+    xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xs_rsrc, ok ? off : 0xffffffffu, 0, 0);
+  };
+  auto gload_d1 = [&](int pr, int i) {
+    const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
+    const int t = (tid >> 2) + 64 * i;
+    const int cc = t >> 6, pix = t & 63;
+    const unsigned off = (unsigned)((((b * nchn + (n0 >> 4) + cc) * 1024 + h0 * kW + pix) * 2 + upl) * 32 + uh * 16);
+    dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(ds_rsrc, off, 0, 0);
+  };
+  // branch free (the loop body must stay one basic block): the 128 units past the x tile land in a dummy area
+  auto store_x = [&](unsigned char* buf, int i) {
+    const int t = (tid >> 2) + 64 * i;
+    const int cc = t / X3PIX, pix = t - cc * X3PIX;
+    const int dst = upl * X3_PLANE + (cc >> 1) * X3_HALF + pix * 64 + (cc & 1) * 32 + uh * 16;
+    *reinterpret_cast<i32x4*>(t < 8 * X3PIX ? buf + dst : smem + 2 * WG3_BUF) = xreg[i];
+  };
+  auto store_d = [&](unsigned char* buf, int i) {
+    const int t = (tid >> 2) + 64 * i;
+    const int cc = t >> 6, pix = t & 63;
+    const int dst = 2 * X3_PLANE + upl * D3_PLANE + (cc >> 1) * D3_HALF + pix * 64 + (cc & 1) * 32 + uh * 16;
+    *reinterpret_cast<i32x4*>(buf + dst) = dreg[i];
+  };
+
+  // lane part of every transposing read (see conv3x3_wgrad_bf16x6_kernel)
+  const int grp_q = (lane & 15) >> 2, grp_p = lane & 3, cb16 = ((lane >> 4) & 1) * 16;
+  const int lane_off = (8 * lh + grp_q) * 64 + (cb16 + 4 * grp_p) * 2;
+  const int xa_off = (wci * 2) * X3_HALF + lane_off;
+  const int db_off = 2 * X3_PLANE + (wco * 2) * D3_HALF + lane_off;
+
+  const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
+  const int last = pair_end - 1;
+  int b_acc = pair_begin < pair_end ? pair_begin / pairs_per_img : 0;   // image whose scales the accumulators carry
+  if (pair_begin < pair_end) {
+    const int p1 = min(pair_begin + 1, last);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) gload_x1(pair_begin, i);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) gload_d1(pair_begin, i);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) store_x(smem, i);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) store_d(smem, i);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) gload_x1(p1, i);
+#pragma unroll
+    for (int i = 0; i < DV; ++i) gload_d1(p1, i);
+  }
+  __syncthreads();
+  if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    if (stamp && pr - pair_begin < 20) p.stamps[2 + pr - pair_begin] = __builtin_amdgcn_s_memtime();
+    const int cur = (pr - pair_begin) & 1;
+    const unsigned char* bc = smem + cur * WG3_BUF;
+    unsigned char* bn = smem + (cur ^ 1) * WG3_BUF;
+    const int pr2 = min(pr + 2, last);                 // past the end: a harmless re-read of the last pair
+    const int b_now = pr / pairs_per_img;
+    if (b_now != b_acc) {                              // crossed into the next image: move the accumulators to its units
+      const int d = (clamped_exp(p.xmax[b_acc]) - clamped_exp(p.xmax[b_now])) +
+                    (clamped_exp(p.dymax[b_acc]) - clamped_exp(p.dymax[b_now]));
+      // acc *= 2^d in place on the accumulator registers (kept in the "a" class so that the register allocation of
+      // the main loop is not disturbed by this rare path); four registers per block so the moves interleave
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+              float t0, t1, t2, t3;
+              asm volatile(
+                  "v_accvgpr_read_b32 %4, %0\n\tv_accvgpr_read_b32 %5, %1\n\t"
+                  "v_accvgpr_read_b32 %6, %2\n\tv_accvgpr_read_b32 %7, %3\n\ts_nop 0\n\t"
+                  "v_ldexp_f32 %4, %4, %8\n\tv_ldexp_f32 %5, %5, %8\n\tv_ldexp_f32 %6, %6, %8\n\tv_ldexp_f32 %7, %7, %8\n\t"
+                  "s_nop 1\n\t"
+                  "v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\t"
+                  "v_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                  : "+a"(acc[t][i][j][r]), "+a"(acc[t][i][j][r + 1]), "+a"(acc[t][i][j][r + 2]), "+a"(acc[t][i][j][r + 3]),
+                    "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                  : "v"(d));
+            }
+      b_acc = b_now;
+    }
+    const unsigned char* xa = bc + xa_off;
+    const unsigned char* db = bc + db_off;
+    f16x8 af[2][2][2], bfr[2][2][2];                   // [buffer][tile][plane]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bfr[0][j][pl] = tr_read8h(db + pl * D3_PLANE + j * D3_HALF);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) af[0][i][pl] = tr_read8h(xa + pl * X3_PLANE + i * X3_HALF);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {                     // q = ks * 3 + kw; k step ks = 16 pixels of row rr = ks >> 1
+      const int ks = q / 3, kw = q - ks * 3;
+      if (q + 1 < 12) {                                // next stage's x fragments
+        const int ks1 = (q + 1) / 3, kw1 = (q + 1) - ks1 * 3;
+        const int rr = ks1 >> 1, w0 = (ks1 & 1) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            af[(q + 1) & 1][i][pl] = tr_read8h(xa + pl * X3_PLANE + i * X3_HALF + (rr * kPW + w0 + kw1) * 64);
+      }
+      if (kw == 1 && ks + 1 < 4) {                     // next k step's dy fragments
+        const int rr = (ks + 1) >> 1, w0 = ((ks + 1) & 1) * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            bfr[(ks + 1) & 1][j][pl] = tr_read8h(db + pl * D3_PLANE + j * D3_HALF + (rr * kW + w0) * 64);
+      }
+      // staging: x unit q in stages 0..8, dy unit q - 4 in stages 4..11; each register is refilled at once with the
+      // same unit of pair p + 2
+      if (q < XV) { store_x(bn, q); gload_x1(pr2, q); }
+      if (q >= 4) { store_d(bn, q - 4); gload_d1(pr2, q - 4); }
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[kw][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]],
+                                                                   acc[kw][i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if ((g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
+  float sdummy, inv_x, inv_g;
+  scale_of(p.xmax[b_acc], sdummy, inv_x);
+  scale_of(p.dymax[b_acc], sdummy, inv_g);
+  float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wco * 64 + j * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = c0 + wci * 64 + i * 32 + mfma32_row(r, lane);
+          slab[((size_t)(kh * 3 + kw) * C + c) * N + n] = (acc[kw][i][j][r] * inv_x) * inv_g;
+        }
+      }
+  if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+int wgrad_splits_p(int B, int H, int C, int N) {   // 3 kh blocks per (tile, pixel range); S % 8 == 0 keeps them on one XCD
+  const int tiles = (C / WG3_T) * (N / WG3_T);
+  const int pairs = B * (H / WG_ROWS);
+  const int target = g_mulan_tune[1] > 0 ? g_mulan_tune[1] : 240;
+  int S = target / (3 * tiles);
+  if (S >= 8) S &= ~7;
+  if (S < 1) S = 1;
+  if (S > pairs) S = pairs;
+  return S;
+}
+
 __global__ void slab_reduce_h_kernel(const float* __restrict__ slab, float* __restrict__ out, int S, int E,
                                      int accumulate) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -800,9 +1071,13 @@ MULAN_API int mulan_conv3x3_pack_f16x3(const float* w, void* wp, unsigned* wmax,
 
 // Eligibility: W == 32, H % 4 == 0, C % 16 == 0, N % 128 == 0 (the ResBlock convolutions); everything else goes
 // through mulan_conv3x3_fwd.  xmax = mulan_absmax_rows(x, B rows); wp / wmax from mulan_conv3x3_pack_f16x3.
+MULAN_API size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C) { return (size_t)B * H * W * C * 4; }
+
+// xs (optional, mulan_conv3x3_planes_bytes): receives the split planes of x, the input format of
+// mulan_conv3x3_wgrad_f16x3_planes.
 MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
                                       const float* bias, const float* cbias, int cbias_mode, const float* res,
-                                      float* y, int B, int H, int W, int C, int N, hipStream_t stream) {
+                                      float* y, void* xs, int B, int H, int W, int C, int N, hipStream_t stream) {
   if (W != kW || H % TROWS != 0 || B <= 0 || C % CK != 0 || C <= 0 || N % BN != 0 || N <= 0 || !xmax || !wmax)
     return (int)hipErrorInvalidValue;
   static bool configured = false;
@@ -813,7 +1088,8 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
     configured = true;
   }
   ConvArgsH a{x, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
-              cbias ? cbias_mode : 0, g_mulan_debug_buffer};
+              cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(xs)};
+  if (xs && (H % TR2 != 0 || (size_t)B * H * W * C * 4 >= 0x80000000ull)) return (int)hipErrorInvalidValue;
   if (H % TR2 == 0 && g_mulan_tune[3] != 1) {     // tune[3] = 1: dev A/B switch back to the 2 x 2-tile variant
     static bool configured2 = false;
     if (!configured2) {
@@ -852,6 +1128,36 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, co
   WgradArgsH a{x, dy, workspace, xmax, dymax, B, H, C, N, S};
   dim3 grid(S, (C + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T);
   hipLaunchKernelGGL(conv3x3_wgrad_f16x3_kernel, grid, dim3(256), WG_SMEM, stream, a);
+  const int E = 9 * C * N;
+  hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N) {
+  if (W != kW || H % WG_ROWS != 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
+  return (size_t)wgrad_splits_p(B, H, C, N) * 9 * C * N * sizeof(float);
+}
+
+// dw[3,3,C,N] (+)= sum x (x) dy from the split planes written by mulan_conv3x3_fwd_f16x3 (xs: of the forward input,
+// dys: of the output gradient, written by the input-gradient convolution); needs C % 128 == 0 and N % 128 == 0.
+MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys,
+                                               const unsigned* dymax, float* dw, float* workspace, int B, int H, int W,
+                                               int C, int N, int accumulate, hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0 || !xs || !dys || !xmax || !dymax ||
+      (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
+    return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int S = wgrad_splits_p(B, H, C, N);
+  WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
+               B, H, C, N, S, g_mulan_debug_buffer};
+  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel, dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256), WG3_SMEM + 64,
+                     stream, a);
   const int E = 9 * C * N;
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
   MULAN_CHECK_LAUNCH();

@@ -66,8 +66,14 @@ def _pack_weights(w, C, N, flip):
     return wp, None
 
 
-def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None):
-    """x [B,1024,C], w [3,3,C,N] -> [B,1024,N]   (xmax: absmax_rows(x) if the caller already has it, f16x3 mode)"""
+def planes_eligible(C, N):
+    """the plane-fed weight-gradient kernel (f16x3 mode) covers 128-multiples of channels"""
+    return CONV_MODE == "f16x3" and C % 128 == 0 and N % 128 == 0
+
+
+def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False):
+    """x [B,1024,C], w [3,3,C,N] -> [B,1024,N]   (xmax: absmax_rows(x) if the caller already has it, f16x3 mode).
+    planes=True (f16x3 mode): returns (y, xs) with xs the split fp16 planes of x for conv3x3_wgrad_planes_raw."""
     _chk(x, "conv input")
     B, C, N = x.shape[0], x.shape[-1], w.shape[-1]
     assert w.shape[:3] == (3, 3, C), (w.shape, C)
@@ -83,13 +89,17 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None):
                lambda: call("mulan_conv3x3_fwd", ptr(x), ptr(w), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y), B, H, W,
                             C, N, stream()))
         return y
+    assert fast or not planes
     wp, wmax = _pack_weights(w, C, N, 0)
     if CONV_MODE == "f16x3":
         if xmax is None:
             xmax = absmax_rows(x)
+        xs = torch.empty(B * HW * C * 4, device=x.device, dtype=torch.uint8) if planes else None
         _timed("conv3x3_f16x3_kernel", flops,
                lambda: call("mulan_conv3x3_fwd_f16x3", ptr(x), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cbias), mode,
-                            ptr(res), ptr(y), B, H, W, C, N, stream()))
+                            ptr(res), ptr(y), ptr(xs), B, H, W, C, N, stream()))
+        if planes:
+            return y, xs
     else:
         _timed("conv3x3_bf16x6_kernel", flops,
                lambda: call("mulan_conv3x3_fwd_bf16x6", ptr(x), ptr(wp), ptr(bias), ptr(cbias), mode, ptr(res), ptr(y),
@@ -97,7 +107,8 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None):
     return y
 
 
-def conv3x3_dgrad_raw(dy, w, dymax=None):
+def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False):
+    """dx = conv3x3(dy, flipped w).  planes=True (f16x3 mode): returns (dx, dys), dys = the split planes of dy."""
     C, N = w.shape[2], w.shape[3]
     if CONV_MODE in ("bf16x6", "f16x3") and N % 16 == 0 and C % 128 == 0:
         B = dy.shape[0]
@@ -107,9 +118,12 @@ def conv3x3_dgrad_raw(dy, w, dymax=None):
         if CONV_MODE == "f16x3":
             if dymax is None:
                 dymax = absmax_rows(dy)
+            dys = torch.empty(B * HW * N * 4, device=dy.device, dtype=torch.uint8) if planes else None
             _timed("conv3x3_f16x3_kernel", flops,
                    lambda: call("mulan_conv3x3_fwd_f16x3", ptr(dy), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
-                                ptr(dx), B, H, W, N, C, stream()))
+                                ptr(dx), ptr(dys), B, H, W, N, C, stream()))
+            if planes:
+                return dx, dys
         else:
             _timed("conv3x3_bf16x6_kernel", flops,
                    lambda: call("mulan_conv3x3_fwd_bf16x6", ptr(dy), ptr(wp), None, None, 0, None, ptr(dx), B, H, W, N, C,
@@ -147,6 +161,17 @@ def conv3x3_wgrad_raw(x, dy, out=None, xmax=None, dymax=None):
                                          stream()))
     else:
         _timed(name, flops, lambda: call(fn, ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, N, 0, stream()))
+    return dw
+
+
+def conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, B, C, N, out=None):
+    """dw from the split planes of x (written by the forward conv) and of dy (written by the input-gradient conv)"""
+    nbytes = lib.load().mulan_conv3x3_wgrad_f16x3_planes_workspace(B, H, W, C, N)
+    ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((3, 3, C, N), device=xs.device, dtype=torch.float32)
+    _timed("conv3x3_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * 9 * C * N,
+           lambda: call("mulan_conv3x3_wgrad_f16x3_planes", ptr(xs), ptr(xmax), ptr(dys), ptr(dymax), ptr(dw), ptr(ws), B,
+                        H, W, C, N, 0, stream()))
     return dw
 
 
@@ -196,8 +221,15 @@ class Conv3x3Fn(torch.autograd.Function):
         x, w = _c(x), _c(w)
         f16 = CONV_MODE == "f16x3" and x.shape[-1] % 4 == 0        # per-image maxima: shared by fwd and wgrad
         xmax = absmax_rows(x) if f16 else None
-        y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax)
-        ctx.save_for_backward(x, w)
+        # the forward kernel hands its split input planes to the weight-gradient kernel: saved instead of x (same bytes)
+        ctx.planes = planes_eligible(x.shape[-1], w.shape[-1]) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+        if ctx.planes:
+            y, xs = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax, planes=True)
+            ctx.save_for_backward(xs, w)
+            ctx.xshape = x.shape
+        else:
+            y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax)
+            ctx.save_for_backward(x, w)
         ctx.xmax = xmax
         ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
         ctx.gv = (_gv(w), _gv(bias))
@@ -212,10 +244,15 @@ class Conv3x3Fn(torch.autograd.Function):
         gvw, gvb = ctx.gv
         B, N = dy.shape[0], dy.shape[-1]
         dymax = absmax_rows(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
-        dx = conv3x3_dgrad_raw(dy, w, dymax=dymax) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
-            dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None, xmax=ctx.xmax, dymax=dymax)
+        if ctx.planes:                # x is the plane tensor here
+            dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True)
+            dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
+                                          out=_fresh(gvw) if gvw is not None else None)
+        else:
+            dx = conv3x3_dgrad_raw(dy, w, dymax=dymax) if ctx.needs_input_grad[0] else None
+            dw = None
+            if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
+                dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None, xmax=ctx.xmax, dymax=dymax)
         dbias = dcb = None
         per_sample = None
         if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):

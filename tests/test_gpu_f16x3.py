@@ -149,3 +149,38 @@ def test_f16x3_zero_operands(ops):
     assert torch.count_nonzero(z) == 0
     z = ops.conv3x3_wgrad_raw(torch.zeros_like(x), torch.randn(B, 1024, N, device="cuda"))
     assert torch.count_nonzero(z) == 0
+
+
+@pytest.mark.parametrize("B,C,N,ints", [(2, 128, 128, True), (3, 256, 128, True), (1, 128, 256, True),
+                                         (4, 128, 128, False)])
+def test_f16x3_plane_fed_wgrad(ops, B, C, N, ints):
+    """weight gradient from the split planes that the forward / input-gradient convolutions write as a by-product:
+    bit exact on integers; on random data with very different per-image magnitudes (exercises the per-image ->
+    tensor-wide rescale) within the fp32 kernel's error"""
+    rng = np.random.default_rng(B * 7 + C + N)
+    if ints:
+        x = rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64)
+        dy = rng.integers(-2, 3, (B, 32, 32, N)).astype(np.float64)
+        x[0] *= 4.0                      # different power-of-two scales per image
+    else:
+        mags = np.array([1.0, 3e-3, 40.0, 1e-6])[:B, None, None, None]
+        x = rng.standard_normal((B, 32, 32, C)) * mags
+        dy = rng.standard_normal((B, 32, 32, N)) * mags[::-1]
+    w = rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64)
+    xd, dyd, wd = dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N), dev(w)
+    xmax, dymax = ops.absmax_rows(xd), ops.absmax_rows(dyd)
+    y, xs = ops.conv3x3_raw(xd, wd, xmax=xmax, planes=True)
+    dx, dys = ops.conv3x3_dgrad_raw(dyd, wd, dymax=dymax, planes=True)
+    dw = ops.conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, B, C, N).cpu().double().numpy()
+    xt = torch.tensor(x.astype(np.float32).astype(np.float64))
+    wt = torch.tensor(w, requires_grad=True)
+    tr.conv3x3(xt, {"kernel": wt}).backward(torch.tensor(dy.astype(np.float32).astype(np.float64)))
+    ref = wt.grad.numpy()
+    if ints:
+        assert np.array_equal(dw, ref)
+        assert np.array_equal(y.cpu().double().numpy().reshape(B, 32, 32, N), onp.conv3x3(x, w))
+    else:
+        d32 = ops.conv3x3_wgrad_raw(xd, dyd).cpu().double().numpy()      # the fp32-input 9-tap kernel
+        scale = np.abs(ref).max()
+        e_p, e_9 = np.abs(dw - ref).max() / scale, np.abs(d32 - ref).max() / scale
+        assert e_p < 1e-5 and e_p < 2 * e_9 + 1e-6, (e_p, e_9)

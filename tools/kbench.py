@@ -132,8 +132,41 @@ def stamps(batch, C=128, N=128, tune="", mode=None):
           f"(pure MFMA per chunk = 18432 cyc per wave); in-kernel clock {(t[23] - t[0]) / max(1, (t[31] - t[30])) * 0.1:.3f} GHz")
 
 
+def wstamps(batch=128, C=128, N=128):
+    ops.lib.load()
+    ops.CONV_MODE = "f16x3"
+    x, dy = torch.randn(batch, 1024, C, device="cuda"), torch.randn(batch, 1024, N, device="cuda")
+    w = torch.randn(3, 3, C, N, device="cuda") * 0.05
+    xmax, dymax = ops.absmax_rows(x), ops.absmax_rows(dy)
+    _, xs = ops.conv3x3_raw(x, w, xmax=xmax, planes=True)
+    _, dys = ops.conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True)
+    buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+    for _ in range(30):
+        ops.conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, batch, C, N)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        ops.conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, batch, C, N)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / 20
+    call("mulan_set_debug_buffer", ptr(buf))
+    ops.conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, batch, C, N)
+    torch.cuda.synchronize()
+    call("mulan_set_debug_buffer", None)
+    t = buf.cpu().tolist()
+    pairs = [t[3 + i] - t[2 + i] for i in range(19) if t[3 + i] > 0]
+    print(f"wgrad(planes) B={batch} C={C} N={N}: {us:.1f} us incl. slab reduce; prologue {t[1] - t[0]} cyc; pairs {pairs}; "
+          f"loop {t[22] - t[1]}; epilogue {t[23] - t[22]}; total {t[23] - t[0]} (pure MFMA per pair = 144 x 34.6 = 4982 "
+          f"cyc); in-kernel clock {(t[23] - t[0]) / max(1, (t[31] - t[30])) * 0.1:.3f} GHz")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "stamps":
+    if len(sys.argv) > 1 and sys.argv[1] == "wstamps":
+        wstamps()
+        wstamps(C=256)
+    elif len(sys.argv) > 1 and sys.argv[1] == "stamps":
         for md in ("bf16x6", "f16x3"):
             for bsz in (32, 128):
                 stamps(bsz, mode=md)
