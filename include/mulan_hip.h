@@ -66,11 +66,14 @@ int mulan_conv3x3_wgrad_bf16x6(const float* x, const float* dy, float* dw, float
 
 /* fp32-equivalent fast path on the fp16 matrix cores (3-pass split of power-of-two-scaled operands into two fp16
  * pieces each; same contract as above at half the matrix-core cycles).  mulan_absmax_rows gives the per-image
- * maxima (fp32 bit patterns) from which the kernels derive the operand scales: out[r] = bits(max|x[r, 0:row_len]|).
- * wp / wmax[1] come from mulan_conv3x3_pack_f16x3 (flip as above).  Needs C % 16 == 0 and N % 128 == 0. */
+ * maxima from which the kernels derive the operand scales: out[r][0..15] = fp32 bit patterns of 16 partial maxima of
+ * |x[r, 0:row_len]| (consumers take the maximum of a row's 16 entries; no atomics, no zero-fill pass).
+ * wmax[16] = mulan_absmax_rows(w, 1 row); wp from mulan_conv3x3_pack_f16x3 (flip as above).
+ * Needs C % 16 == 0 and N % 128 == 0. */
 int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, mulan_stream_t stream);
 size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N);
-int mulan_conv3x3_pack_f16x3(const float* w, void* wp, unsigned* wmax, int C, int N, int flip, mulan_stream_t stream);
+int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int C, int N, int flip,
+                             mulan_stream_t stream);
 int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
                             const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, void* xs,
                             int B, int H, int W, int C, int N, mulan_stream_t stream);
@@ -109,7 +112,9 @@ size_t mulan_gemm_workspace(int M, int N, int K, int batch);
  * act: 0 none, 1 SiLU.  keep < 1 enables dropout with Philox4x32-10(seed, offset + element/4). */
 int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
                         float* y, float* mean, float* rstd, int B, int hw, int G, float eps, int act, float keep,
-                        unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
+                        unsigned long long seed, unsigned long long offset, unsigned* ymax, mulan_stream_t stream);
+/* ymax (optional, [B][16]): partial maxima of |y| in the format of mulan_absmax_rows, a by-product that saves the
+ * following convolution its own pass over y. */
 /* dgamma_part / dbeta_part are [B, C1+C2] per-sample partials (reduce with mulan_colsum). */
 int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
                         const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,

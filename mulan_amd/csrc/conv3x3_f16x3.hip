@@ -40,6 +40,17 @@ __device__ __forceinline__ void scale_of(unsigned maxbits, float& s, float& inv)
   inv = __uint_as_float((unsigned)(e - 13) << 23);
 }
 
+// Maxima arrays hold kMaxParts partial maxima per row (fp32 bit patterns; producers write their partials without
+// atomics or a zero-fill pass, unused entries are 0); consumers take the maximum of the 16 entries of a row.
+constexpr int kMaxParts = 16;
+__device__ __forceinline__ unsigned row_max16(const unsigned* __restrict__ m, int row) {
+  const unsigned* r = m + (size_t)row * kMaxParts;
+  unsigned v = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxParts; ++i) v = max(v, r[i]);
+  return v;
+}
+
 __device__ __forceinline__ void split2(float vs, _Float16& h, _Float16& l) {
   h = (_Float16)vs;
   l = (_Float16)(vs - (float)h);
@@ -80,8 +91,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_kernel(ConvArgsH p) {
   const int nchunks = C / CK;
   const float* xb = p.x + (size_t)b * p.H * kW * C;
   float sx, inv_x, sw, inv_w;
-  scale_of(p.xmax[b], sx, inv_x);
-  scale_of(p.wmax[0], sw, inv_w);
+  scale_of(row_max16(p.xmax, b), sx, inv_x);
+  scale_of(row_max16(p.wmax, 0), sw, inv_w);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -311,8 +322,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   const int nchunks = C / CK;
   const float* xb = p.x + (size_t)b * p.H * kW * C;
   float sx, inv_x, sw, inv_w;
-  scale_of(p.xmax[b], sx, inv_x);
-  scale_of(p.wmax[0], sw, inv_w);
+  scale_of(row_max16(p.xmax, b), sx, inv_x);
+  scale_of(row_max16(p.wmax, 0), sw, inv_w);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -509,13 +520,14 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-// out[r] = fp32 bits of max |x[r, :]| (out zeroed by the caller; non-negative floats order like their bit patterns)
+// out[r][c] = fp32 bits of the maximum |x| over part c of row r (16 parts per row; non-negative floats order like
+// their bit patterns, so integer max works); no atomics, no zero-fill pass
 __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restrict__ x, unsigned* __restrict__ out,
                                                           size_t row_len4) {
   __shared__ unsigned red[4];
   const f32x4* row = reinterpret_cast<const f32x4*>(x) + (size_t)blockIdx.x * row_len4;
   unsigned m = 0;
-  const size_t stride = (size_t)gridDim.y * 256;
+  const size_t stride = (size_t)kMaxParts * 256;
   size_t i = (size_t)blockIdx.y * 256 + threadIdx.x;
   for (; i + 3 * stride < row_len4; i += 4 * stride) {
     const f32x4 a = row[i], b = row[i + stride], c = row[i + 2 * stride], d = row[i + 3 * stride];
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
   for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) atomicMax(out + blockIdx.x, max(max(red[0], red[1]), max(red[2], red[3])));
+  if (threadIdx.x == 0) out[(size_t)blockIdx.x * kMaxParts + blockIdx.y] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
 // wp[t][cc][o][plane][k] = split2( s_w * Wl[t][cc*16 + k][o] ),  Wl = w (flip = 0) or the tap-flipped,
@@ -546,7 +558,7 @@ __global__ void conv3x3_pack_f16x3_kernel(const float* __restrict__ w, _Float16*
   const int Kin = flip ? N : C, Nout = flip ? C : N;
   const size_t total = (size_t)9 * Kin * Nout;
   float sw, inv_w;
-  scale_of(wmax[0], sw, inv_w);
+  scale_of(row_max16(wmax, 0), sw, inv_w);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % 16);
     size_t r = i / 16;
@@ -610,7 +622,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_kernel(WgradArgsH p) 
   float sx, inv_x, sg, inv_g;
   {
     unsigned mx = 0, mg = 0;
-    for (int i = tid; i < p.B; i += 256) { mx = max(mx, p.xmax[i]); mg = max(mg, p.dymax[i]); }
+    for (int i = tid; i < p.B * kMaxParts; i += 256) { mx = max(mx, p.xmax[i]); mg = max(mg, p.dymax[i]); }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
@@ -891,8 +903,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
     const int pr2 = min(pr + 2, last);                 // past the end: a harmless re-read of the last pair
     const int b_now = pr / pairs_per_img;
     if (b_now != b_acc) {                              // crossed into the next image: move the accumulators to its units
-      const int d = (clamped_exp(p.xmax[b_acc]) - clamped_exp(p.xmax[b_now])) +
-                    (clamped_exp(p.dymax[b_acc]) - clamped_exp(p.dymax[b_now]));
+      const int d = (clamped_exp(row_max16(p.xmax, b_acc)) - clamped_exp(row_max16(p.xmax, b_now))) +
+                    (clamped_exp(row_max16(p.dymax, b_acc)) - clamped_exp(row_max16(p.dymax, b_now)));
       // acc *= 2^d in place on the accumulator registers (kept in the "a" class so that the register allocation of
       // the main loop is not disturbed by this rare path); four registers per block so the moves interleave
 #pragma unroll
@@ -978,8 +990,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 
   if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
   float sdummy, inv_x, inv_g;
-  scale_of(p.xmax[b_acc], sdummy, inv_x);
-  scale_of(p.dymax[b_acc], sdummy, inv_g);
+  scale_of(row_max16(p.xmax, b_acc), sdummy, inv_x);
+  scale_of(row_max16(p.dymax, b_acc), sdummy, inv_g);
   float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
 #pragma unroll
   for (int kw = 0; kw < 3; ++kw)
@@ -1038,30 +1050,22 @@ int wgrad_splits_h(int B, int H, int C, int N) {
 
 }  // namespace
 
-// out[r] = fp32 bit pattern of max |x[r, 0:row_len]| for r < rows  (row_len % 4 == 0, x 16-byte aligned).
-// The per-image maxima feed the power-of-two operand scales of the f16x3 kernels below.
+// out[r][0..15] = fp32 bit patterns of 16 partial maxima of |x[r, 0:row_len]| (row_len % 4 == 0, x 16-byte aligned);
+// the maximum of a row's 16 entries is the per-image maximum that feeds the power-of-two operand scales of the f16x3
+// kernels below.  (The fused GroupNorm kernel writes the same format for its output as a by-product.)
 MULAN_API int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, hipStream_t stream) {
   if (rows <= 0 || row_len == 0 || row_len % 4 != 0) return (int)hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(out, 0, (size_t)rows * sizeof(unsigned), stream);
-  if (e != hipSuccess) return (int)e;
-  const size_t len4 = row_len / 4;
-  int chunks = (int)((len4 + 256 * 8 - 1) / (256 * 8));          // >= 8 float4 per thread
-  const int want = (2048 + rows - 1) / rows;
-  if (chunks > want) chunks = want;
-  if (chunks < 1) chunks = 1;
-  hipLaunchKernelGGL(absmax_rows_kernel, dim3(rows, chunks), dim3(256), 0, stream, x, out, len4);
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3(rows, kMaxParts), dim3(256), 0, stream, x, out, row_len / 4);
   MULAN_CHECK_LAUNCH();
 }
 
 MULAN_API size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N) { return (size_t)9 * C * N * 2 * 2; }
 
-// Packs (and scales, splits) the weights for mulan_conv3x3_fwd_f16x3; wmax[1] receives the fp32 bits of max|w|.
-MULAN_API int mulan_conv3x3_pack_f16x3(const float* w, void* wp, unsigned* wmax, int C, int N, int flip,
+// Packs (and scales, splits) the weights for mulan_conv3x3_fwd_f16x3; wmax[16] = mulan_absmax_rows(w, 1 row).
+MULAN_API int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int C, int N, int flip,
                                        hipStream_t stream) {
   const int Kin = flip ? N : C;
-  if (Kin % 16 != 0 || C <= 0 || N <= 0 || ((size_t)9 * C * N) % 4 != 0) return (int)hipErrorInvalidValue;
-  const int rc = mulan_absmax_rows(w, wmax, 1, (size_t)9 * C * N, stream);
-  if (rc != 0) return rc;
+  if (Kin % 16 != 0 || C <= 0 || N <= 0 || !wmax) return (int)hipErrorInvalidValue;
   const size_t total = (size_t)9 * C * N;
   const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
   hipLaunchKernelGGL(conv3x3_pack_f16x3_kernel, dim3(blocks), dim3(256), 0, stream, w, static_cast<_Float16*>(wp), wmax,

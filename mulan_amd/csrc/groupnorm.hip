@@ -20,6 +20,7 @@ struct GnArgs {
   float* mean; float* rstd;                   // [B,G]
   int B, G; float eps; int act;               // act: 0 none, 1 silu
   float keep; unsigned long long seed, offset;  // dropout: keep == 1 -> off
+  unsigned* ymax;                             // optional [B][16]: partial maxima of |y| (mulan_absmax_rows format)
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
 
   f32x4 v[NP];
   float s1 = 0.f, s2 = 0.f;
-#pragma unroll
+#pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) {
     v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(prow + 32 * i) * ld);
     s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
   const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
   float* dst = p.y + (size_t)b * HW * Ct + c;
-#pragma unroll
+  unsigned amax = 0;
+#pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) {
     const int px = prow + 32 * i;
     f32x4 o;
@@ -98,6 +100,18 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
       drop4(o, p.keep, p.seed, p.offset + idx4);
     }
     *reinterpret_cast<f32x4*>(dst + (size_t)px * Ct) = o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+  }
+  if (p.ymax) {   // this block's slab is partial maximum number blockIdx.y of image b (unused entries zeroed)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+    __syncthreads();
+    unsigned* ured = reinterpret_cast<unsigned*>(red);
+    if ((tid & 63) == 0) ured[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) p.ymax[b * 16 + blockIdx.y] = max(max(ured[0], ured[1]), max(ured[2], ured[3]));
+    if (blockIdx.y == 0 && tid >= (int)gridDim.y && tid < 16) p.ymax[b * 16 + tid] = 0u;
   }
 }
 
@@ -302,12 +316,13 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
 MULAN_API int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma,
                                   const float* beta, float* y, float* mean, float* rstd, int B, int hw, int G,
                                   float eps, int act, float keep, unsigned long long seed,
-                                  unsigned long long offset, hipStream_t stream) {
+                                  unsigned long long offset, unsigned* ymax, hipStream_t stream) {
   const int Ct = C1 + C2;
   if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
-  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset};
+  if (ymax && Ct / 32 > 16) return (int)hipErrorInvalidValue;
+  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax};
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -45,20 +45,33 @@ def _timed(name, flops, launch):
     KERNEL_TIMER.append((name, s, e, flops))
 
 
+MAX_PARTS = 16
+
+
 def absmax_rows(x):
-    """[B] uint32: fp32 bit patterns of max|x[b]| -- the per-image operand scales of the f16x3 kernels"""
+    """[B,16] int32: fp32 bit patterns of 16 partial maxima of |x[b]| (the per-image maximum is the max of a row);
+    they feed the per-image operand scales of the f16x3 kernels"""
     B = x.shape[0]
-    out = torch.empty(B, device=x.device, dtype=torch.int32)
+    out = torch.empty((B, MAX_PARTS), device=x.device, dtype=torch.int32)
     call("mulan_absmax_rows", ptr(x), ptr(out), B, x.numel() // B, stream())
     return out
 
 
-def _pack_weights(w, C, N, flip):
+def cached_absmax(x):
+    """maxima a producer kernel left on its output tensor (GroupNormFn), if still valid; else a pass over x"""
+    c = getattr(x, "_absmax", None)
+    if c is not None and c[1] == x._version and c[0].shape[0] == x.shape[0]:
+        return c[0]
+    return absmax_rows(x)
+
+
+def _pack_weights(w, C, N, flip, wmax=None):
     """weights pre-split into the LDS tile layout of the fast convolution kernels; returns (wp, wmax or None)"""
     L = lib.load()
     if CONV_MODE == "f16x3":
         wp = torch.empty(L.mulan_conv3x3_pack_f16x3_bytes(C, N), device=w.device, dtype=torch.uint8)
-        wmax = torch.empty(1, device=w.device, dtype=torch.int32)
+        if wmax is None:
+            wmax = absmax_rows(w.view(1, -1))
         call("mulan_conv3x3_pack_f16x3", ptr(w), ptr(wp), ptr(wmax), C, N, flip, stream())
         return wp, wmax
     wp = torch.empty(L.mulan_conv3x3_pack_bf16x6_bytes(C, N), device=w.device, dtype=torch.uint8)
@@ -71,7 +84,7 @@ def planes_eligible(C, N):
     return CONV_MODE == "f16x3" and C % 128 == 0 and N % 128 == 0
 
 
-def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False):
+def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False, wmax=None):
     """x [B,1024,C], w [3,3,C,N] -> [B,1024,N]   (xmax: absmax_rows(x) if the caller already has it, f16x3 mode).
     planes=True (f16x3 mode): returns (y, xs) with xs the split fp16 planes of x for conv3x3_wgrad_planes_raw."""
     _chk(x, "conv input")
@@ -90,7 +103,7 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False):
                             C, N, stream()))
         return y
     assert fast or not planes
-    wp, wmax = _pack_weights(w, C, N, 0)
+    wp, wmax = _pack_weights(w, C, N, 0, wmax)
     if CONV_MODE == "f16x3":
         if xmax is None:
             xmax = absmax_rows(x)
@@ -107,13 +120,13 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False):
     return y
 
 
-def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False):
+def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None):
     """dx = conv3x3(dy, flipped w).  planes=True (f16x3 mode): returns (dx, dys), dys = the split planes of dy."""
     C, N = w.shape[2], w.shape[3]
     if CONV_MODE in ("bf16x6", "f16x3") and N % 16 == 0 and C % 128 == 0:
         B = dy.shape[0]
         dx = torch.empty((B, HW, C), device=dy.device, dtype=torch.float32)
-        wp, wmax = _pack_weights(w, C, N, 1)
+        wp, wmax = _pack_weights(w, C, N, 1, wmax)
         flops = 2.0 * B * HW * 9 * C * N
         if CONV_MODE == "f16x3":
             if dymax is None:
@@ -220,15 +233,17 @@ class Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x, w, bias, cbias, res):
         x, w = _c(x), _c(w)
         f16 = CONV_MODE == "f16x3" and x.shape[-1] % 4 == 0        # per-image maxima: shared by fwd and wgrad
-        xmax = absmax_rows(x) if f16 else None
+        xmax = cached_absmax(x) if f16 else None
+        wmax = absmax_rows(w.view(1, -1)) if f16 else None          # shared by the forward and input-gradient packs
+        ctx.wmax = wmax
         # the forward kernel hands its split input planes to the weight-gradient kernel: saved instead of x (same bytes)
         ctx.planes = planes_eligible(x.shape[-1], w.shape[-1]) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         if ctx.planes:
-            y, xs = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax, planes=True)
+            y, xs = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax, planes=True, wmax=wmax)
             ctx.save_for_backward(xs, w)
             ctx.xshape = x.shape
         else:
-            y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax)
+            y = conv3x3_raw(x, w, _c(bias), _c(cbias), _c(res), xmax=xmax, wmax=wmax)
             ctx.save_for_backward(x, w)
         ctx.xmax = xmax
         ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
@@ -245,11 +260,11 @@ class Conv3x3Fn(torch.autograd.Function):
         B, N = dy.shape[0], dy.shape[-1]
         dymax = absmax_rows(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
         if ctx.planes:                # x is the plane tensor here
-            dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True)
+            dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True, wmax=ctx.wmax)
             dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
                                           out=_fresh(gvw) if gvw is not None else None)
         else:
-            dx = conv3x3_dgrad_raw(dy, w, dymax=dymax) if ctx.needs_input_grad[0] else None
+            dx = conv3x3_dgrad_raw(dy, w, dymax=dymax, wmax=ctx.wmax) if ctx.needs_input_grad[0] else None
             dw = None
             if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
                 dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None, xmax=ctx.xmax, dymax=dymax)
@@ -392,8 +407,13 @@ class GroupNormFn(torch.autograd.Function):
         y = torch.empty((B, HW, C1 + C2), device=x1.device, dtype=torch.float32)
         mean = torch.empty((B, groups), device=x1.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        # by-product for a following f16x3 convolution: the per-image maxima of y
+        ymax = (torch.empty((B, MAX_PARTS), device=x1.device, dtype=torch.int32)
+                if CONV_MODE == "f16x3" and (C1 + C2) // 32 <= MAX_PARTS else None)
         call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B,
-             HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), stream())
+             HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), ptr(ymax), stream())
+        if ymax is not None:
+            y._absmax = (ymax, y._version)
         ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
         ctx.meta = (groups, int(act), float(keep), int(seed), int(offset))
         ctx.gv = (_gv(gamma), _gv(beta))

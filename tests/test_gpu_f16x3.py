@@ -114,7 +114,25 @@ def test_absmax_rows(ops):
     x[3, 1023, 47] = -77.0
     x[4, 0, 0] = 1e30
     got = ops.absmax_rows(dev(x)).cpu().numpy().view(np.float32)
-    assert np.array_equal(got, np.abs(x).reshape(5, -1).max(1))
+    assert got.shape == (5, 16) and np.array_equal(got.max(1), np.abs(x).reshape(5, -1).max(1))
+
+
+def test_groupnorm_leaves_output_maxima(ops):
+    """the fused GroupNorm kernel's by-product (per-image maxima of its output) equals a pass over the output, with
+    and without dropout, for 128 and 128+128 channels, and the convolution picks it up"""
+    torch.manual_seed(3)
+    for C1, C2, keep in ((128, 0, 1.0), (128, 128, 0.9)):
+        x1 = torch.randn(3, 1024, C1, device="cuda") * torch.tensor([1.0, 1e-3, 50.0], device="cuda").view(3, 1, 1)
+        x2 = torch.randn(3, 1024, C2, device="cuda") if C2 else None
+        g, b = torch.randn(C1 + C2, device="cuda"), torch.randn(C1 + C2, device="cuda")
+        y = ops.GroupNormFn.apply(x1, x2, g, b, 32, 1e-6, 1, keep, 7, 0)
+        ymax, ver = y._absmax
+        assert ver == y._version
+        got = ymax.cpu().numpy().view(np.float32).max(1)
+        assert np.array_equal(got, y.abs().reshape(3, -1).amax(1).cpu().numpy())
+        assert ops.cached_absmax(y) is ymax
+        y.add_(1.0)                                       # modified in place: the cached maxima are stale
+        assert ops.cached_absmax(y) is not ymax
 
 
 def test_f16x3_per_image_dynamic_range(ops):

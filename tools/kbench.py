@@ -63,7 +63,7 @@ def main():
             y = torch.empty(B, 1024, C1 + C2, device=dev)
             mean, rstd = torch.empty(B, 32, device=dev), torch.empty(B, 32, device=dev)
             f = lambda keep: call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(g), ptr(b_), ptr(y), ptr(mean),
-                                  ptr(rstd), B, 1024, 32, 1e-6, 1, keep, 123, 0, stream())
+                                  ptr(rstd), B, 1024, 32, 1e-6, 1, keep, 123, 0, None, stream())
             for keep in (1.0, 0.9):
                 t = timeit(lambda: f(keep), a.reps)
                 by = 2.0 * B * 1024 * (C1 + C2) * 4
