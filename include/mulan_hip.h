@@ -94,6 +94,21 @@ int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const
                                      float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
                                      mulan_stream_t stream);
 
+/* ---- per-pixel dense layers on the fp16 matrix cores (f16x3 scheme) -------------------------------
+ *   y[M, N1 | N2] = [x1 | x2][M, K1 + K2] @ W + bias + res
+ * with a virtual channel concat on the input side and a split on the output side: nin_shortcut on
+ * concat[h, skip] (model_vdm.py:369,652-653) and its input gradient, q / k / v / proj_out of AttnBlock
+ * (model_vdm.py:676-685).  Rows are pixels (rows_per_img per image); x1max / x2max are per-image maxima in the
+ * mulan_absmax_rows format; wp from mulan_linear_pack_f16x3 (transpose = 1 packs w^T for dx = dy @ w^T);
+ * wmax[16] = mulan_absmax_rows(w, 1 row).  Needs M % 128 == 0, rows_per_img % 128 == 0, K1, K2 % 32 == 0,
+ * N1, N2 % 128 == 0 (K2 = 0 / N2 = 0 without x2 / y2); res only with N2 = 0. */
+size_t mulan_linear_pack_f16x3_bytes(int K, int N);
+int mulan_linear_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int K, int N, int transpose,
+                            mulan_stream_t stream);
+int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1, int K2,
+                       const void* wp, const unsigned* wmax, const float* bias, const float* res, float* y1, float* y2,
+                       int N1, int N2, int M, int rows_per_img, mulan_stream_t stream);
+
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),
  * q,k,v,proj_out and the attention products (model_vdm.py:676-685,775-796), dense0/dense1/cond_proj

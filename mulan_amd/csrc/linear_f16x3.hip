@@ -1,0 +1,257 @@
+// Per-pixel dense layers (1x1 convolutions) with fp32-equivalent products on the fp16 matrix cores ("f16x3", the
+// scheme of conv3x3_f16x3.hip: two power-of-two-scaled fp16 pieces per fp32 operand, three MFMA passes).
+//     y[M, N1 | N2] = [x1 | x2][M, K1 + K2] @ W[K1 + K2, N1 + N2] + bias + res
+// over a virtual channel concat on the input side (nin_shortcut on concat[h, skip], ldm/model_vdm.py:369,652-653)
+// and a split on the output side (its input gradient), so neither concat nor split is ever materialised, and for
+// q / k / v / proj_out of AttnBlock (ldm/model_vdm.py:676-685).  These layers are memory bound (K = 128 .. 256):
+// one pass over the inputs, one over the output.
+//
+// Block = 128 rows x 128 output columns, wave = 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers, two to three
+// blocks per CU so that one block's loads overlap another's MFMAs).  A stage is 32 input channels: the activations
+// are split while they are staged into LDS (double buffered, one barrier per stage), the weight fragments are read
+// straight from the packed global tensor [K/16][N][plane][16] (L2 resident) one stage ahead.
+// Rows are pixels of images of `rows_per_img` rows; the activation scale is per image (maxima in the 16-partials
+// format of mulan_absmax_rows).
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxParts = 16;
+constexpr int TM = 128, TN = 128, SK = 32;
+constexpr int ROWB = 144;                      // LDS bytes per row of a stage: 2 planes x 64 B + 16 pad
+constexpr int STAGE_B = TM * ROWB;             // 18432
+constexpr int LIN_SMEM = 2 * STAGE_B;          // 36864 (the epilogue staging tile, 34816 B, reuses it)
+
+__device__ __forceinline__ unsigned row_max16(const unsigned* __restrict__ m, int row) {
+  const unsigned* r = m + (size_t)row * kMaxParts;
+  unsigned v = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxParts; ++i) v = max(v, r[i]);
+  return v;
+}
+
+__device__ __forceinline__ void scale_of(unsigned maxbits, float& s, float& inv) {   // see conv3x3_f16x3.hip
+  int e = (int)((maxbits >> 23) & 255u);
+  e = e < 14 ? 14 : (e > 254 ? 254 : e);
+  s = __uint_as_float((unsigned)(267 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
+
+__device__ __forceinline__ void split2(float vs, _Float16& h, _Float16& l) {
+  h = (_Float16)vs;
+  l = (_Float16)(vs - (float)h);
+}
+
+struct LinArgs {
+  const float* x1; const float* x2;            // [M, K1], [M, K2] (x2 may be null, K2 = 0)
+  const unsigned* x1max; const unsigned* x2max;
+  const unsigned char* wp; const unsigned* wmax;   // packed weights [K/16][N][2][16] fp16 (scaled), N = N1 + N2
+  const float* bias; const float* res;         // bias [N]; res like y1 (single-output calls only)
+  float* y1; float* y2;                        // [M, N1], [M, N2]
+  int M, K1, K2, N1, N2, rows_per_img;
+};
+
+__global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
+  constexpr int MT = 2, NT = 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LIN_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int K = p.K1 + p.K2, N = p.N1 + p.N2;
+  const int nst = K / SK;
+  const int b = r0 / p.rows_per_img;
+  unsigned mb = row_max16(p.x1max, b);
+  if (p.x2) mb = max(mb, row_max16(p.x2max, b));
+  float sx, inv_x, sw, inv_w;
+  scale_of(mb, sx, inv_x);
+  scale_of(row_max16(p.wmax, 0), sw, inv_w);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // activation staging: 128 rows x 8 float4 per stage, 4 slots per thread (slot = tid + 256 i: quad = slot & 7)
+  const int aq = tid & 7, arow = tid >> 3;                     // + 32 i rows
+  f32x4 areg[4];
+  auto gload_a = [&](int s) {
+    const int c = s * SK;
+    const float* src; int ld, cl;
+    if (c < p.K1) { src = p.x1; ld = p.K1; cl = c; } else { src = p.x2; ld = p.K2; cl = c - p.K1; }
+    const float* base = src + (size_t)(r0 + arow) * ld + cl + aq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(32 * i) * ld);
+  };
+  auto store_a = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split2(areg[i][e] * sx, h, l);
+        hi[e] = h; lo[e] = l;
+      }
+      unsigned char* d = buf + (arow + 32 * i) * ROWB + aq * 8;
+      *reinterpret_cast<f16x4*>(d) = hi;
+      *reinterpret_cast<f16x4*>(d + 64) = lo;
+    }
+  };
+  // weight fragments of a stage: [k step j][n tile][plane]
+  const unsigned char* bbase = p.wp + (size_t)(n0 + wn * 64 + li) * 64 + lh * 16;
+  const size_t chunk_stride = (size_t)N * 64;
+  auto gload_b = [&](f16x8 (&bs)[2][NT][2], int s) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char* t = bbase + (size_t)(2 * s + j) * chunk_stride;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) bs[j][nt][pl] = *reinterpret_cast<const f16x8*>(t + nt * 2048 + pl * 32);
+    }
+  };
+
+  f16x8 bcur[2][NT][2], bnxt[2][NT][2];
+  gload_a(0);
+  gload_b(bcur, 0);
+  for (int s = 0; s < nst; ++s) {
+    unsigned char* buf = smem + (s & 1) * STAGE_B;
+    store_a(buf);
+    __syncthreads();
+    const bool more = s + 1 < nst;
+    if (more) {
+      gload_a(s + 1);
+      gload_b(bnxt, s + 1);
+    }
+    f16x8 af[2][MT][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          af[j][mt][pl] = *reinterpret_cast<const f16x8*>(buf + (wm * 64 + mt * 32 + li) * ROWB + pl * 64 + j * 32 + lh * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][PA[term]], bcur[j][nt][PB[term]], acc[mt][nt], 0,
+                                                                 0, 0);
+      }
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) bcur[j][nt][pl] = bnxt[j][nt][pl];
+    }
+  }
+
+  // epilogue: transposed through LDS so every lane moves float4s; scales divided out here
+  const float* __restrict__ res = p.res;
+  float* out; int ldo, col0;
+  if (n0 < p.N1) { out = p.y1; ldo = p.N1; col0 = n0; } else { out = p.y2; ldo = p.N2; col0 = n0 - p.N1; }
+  float* __restrict__ yout = out;
+  constexpr int TS = 64 + 4;
+  float* stage = reinterpret_cast<float*>(smem) + wave * 32 * TS;
+  const int c4 = lane & 15, prl = lane >> 4;
+  const int nb = wn * 64 + c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + nb);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = (acc[mt][nt][r] * inv_x) * inv_w;
+    const size_t rowbase = (size_t)(r0 + wm * 64 + mt * 32) * ldo + col0 + nb;
+    f32x4 add[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) add[it] = bias4;
+    if (res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(res + rowbase + (size_t)(it * 4 + prl) * ldo);
+        add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's ds_writes have landed (tile is wave private)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(stage + (it * 4 + prl) * TS + c4 * 4);
+      const f32x4 o = {a[0] + add[it][0], a[1] + add[it][1], a[2] + add[it][2], a[3] + add[it][3]};
+      *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * ldo) = o;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// wp[cc][o][plane][k] = split2( s_w * Wl[cc*16 + k][o] ),  Wl[kin][o] = w[kin][o] (w row-major [Kin, Nout]) or, with
+// transpose, w[o][kin] (w row-major [Nout, Kin]: the weight of the input-gradient product dy @ w^T)
+__global__ void linear_pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp,
+                                         const unsigned* __restrict__ wmax, int Kin, int Nout, int transpose) {
+  const size_t total = (size_t)Kin * Nout;
+  float sw, inv_w;
+  scale_of(row_max16(wmax, 0), sw, inv_w);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % 16);
+    const size_t r = i / 16;
+    const int o = (int)(r % Nout);
+    const int cc = (int)(r / Nout);
+    const int kin = cc * 16 + k;
+    const float v = transpose ? w[(size_t)o * Kin + kin] : w[(size_t)kin * Nout + o];
+    _Float16 h, l;
+    split2(v * sw, h, l);
+    _Float16* dst = wp + (((size_t)cc * Nout + o) * 2) * 16 + k;
+    dst[0] = h; dst[16] = l;
+  }
+}
+
+}  // namespace
+
+MULAN_API size_t mulan_linear_pack_f16x3_bytes(int K, int N) { return (size_t)K * N * 4; }
+
+// Packs w for mulan_linear_f16x3.  transpose = 0: w is [K, N] (y = x @ w); transpose = 1: w is [N, K] and the packed
+// operand is its transpose (dx = dy @ w^T with K = w's columns).  wmax[16] = mulan_absmax_rows(w, 1 row).
+MULAN_API int mulan_linear_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int K, int N, int transpose,
+                                      hipStream_t stream) {
+  if (K <= 0 || N <= 0 || K % 16 != 0 || !wmax) return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)K * N;
+  const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  hipLaunchKernelGGL(linear_pack_f16x3_kernel, dim3(blocks), dim3(256), 0, stream, w, static_cast<_Float16*>(wp), wmax, K,
+                     N, transpose);
+  MULAN_CHECK_LAUNCH();
+}
+
+// y[M, N1 | N2] = [x1 | x2][M, K1 + K2] @ W + bias + res.  Rows are pixels, rows_per_img per image; x1max / x2max are
+// the per-image maxima ([M / rows_per_img][16], mulan_absmax_rows format).  Needs M % 128 == 0, rows_per_img % 128 == 0,
+// K1 % 32 == 0, K2 % 32 == 0, N1 % 128 == 0, N2 % 128 == 0 (x2 / y2 optional: K2 = 0 / N2 = 0); res only with N2 = 0.
+MULAN_API int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1,
+                                 int K2, const void* wp, const unsigned* wmax, const float* bias, const float* res,
+                                 float* y1, float* y2, int N1, int N2, int M, int rows_per_img, hipStream_t stream) {
+  if (M <= 0 || M % TM != 0 || rows_per_img <= 0 || rows_per_img % TM != 0 || M % rows_per_img != 0 || K1 <= 0 ||
+      K1 % SK != 0 || K2 < 0 || K2 % SK != 0 || N1 <= 0 || N1 % TN != 0 || N2 < 0 || N2 % TN != 0 || !x1 || !x1max ||
+      !wp || !wmax || !y1 || (K2 > 0 && (!x2 || !x2max)) || (N2 > 0 && (!y2 || res)))
+    return (int)hipErrorInvalidValue;
+  LinArgs a{x1, K2 > 0 ? x2 : nullptr, x1max, x2max, static_cast<const unsigned char*>(wp), wmax, bias, res, y1, y2,
+            M, K1, K2, N1, N2, rows_per_img};
+  hipLaunchKernelGGL(linear_f16x3_kernel, dim3(M / TM, (N1 + N2) / TN), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}

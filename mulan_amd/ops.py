@@ -58,11 +58,17 @@ def absmax_rows(x):
 
 
 def cached_absmax(x):
-    """maxima a producer kernel left on its output tensor (GroupNormFn), if still valid; else a pass over x"""
+    """maxima a producer kernel (GroupNormFn) or an earlier consumer left on the tensor, if still valid; else a pass
+    over x, remembered on the tensor for its other consumers (a gradient that feeds a convolution and a 1x1 layer)"""
     c = getattr(x, "_absmax", None)
     if c is not None and c[1] == x._version and c[0].shape[0] == x.shape[0]:
         return c[0]
-    return absmax_rows(x)
+    m = absmax_rows(x)
+    try:
+        x._absmax = (m, x._version)
+    except (AttributeError, RuntimeError):
+        pass
+    return m
 
 
 def _pack_weights(w, C, N, flip, wmax=None):
@@ -258,7 +264,7 @@ class Conv3x3Fn(torch.autograd.Function):
         has_bias, cb_dim, has_res = ctx.has
         gvw, gvb = ctx.gv
         B, N = dy.shape[0], dy.shape[-1]
-        dymax = absmax_rows(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
+        dymax = cached_absmax(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
         if ctx.planes:                # x is the plane tensor here
             dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True, wmax=ctx.wmax)
             dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
@@ -285,6 +291,37 @@ def conv3x3(x, w, bias=None, cbias=None, res=None):
 
 
 # ----------------------------------------------------------------------------- dense
+def linear_fast_ok(x, K1, K2, N1, N2):
+    """per-pixel dense layers go through the f16x3 kernel (linear_f16x3.hip) when the shapes are image shaped"""
+    return (CONV_MODE == "f16x3" and x.dim() == 3 and x.shape[1] == HW and K1 % 32 == 0 and K2 % 32 == 0 and
+            N1 % 128 == 0 and N2 % 128 == 0)
+
+
+def linear_pack(w, transpose, wmax=None):
+    """w [K,N] -> packed operand of y = x @ w (transpose=False) or of dx = dy @ w^T (transpose=True)"""
+    K, N = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    if wmax is None:
+        wmax = absmax_rows(w.reshape(1, -1))
+    wp = torch.empty(lib.load().mulan_linear_pack_f16x3_bytes(K, N), device=w.device, dtype=torch.uint8)
+    call("mulan_linear_pack_f16x3", ptr(w), ptr(wp), ptr(wmax), K, N, int(transpose), stream())
+    return wp, wmax
+
+
+def linear_f16x3_raw(x1, x2, wp, wmax, N1, N2, bias=None, res=None):
+    """[x1 | x2] @ W + bias + res -> (y1 [B,1024,N1], y2 [B,1024,N2] or None); x* are [B,1024,K*] pixel tensors"""
+    B, K1 = x1.shape[0], x1.shape[-1]
+    K2 = 0 if x2 is None else x2.shape[-1]
+    M = B * HW
+    y1 = torch.empty((B, HW, N1), device=x1.device, dtype=torch.float32)
+    y2 = torch.empty((B, HW, N2), device=x1.device, dtype=torch.float32) if N2 else None
+    m1 = cached_absmax(x1)
+    m2 = cached_absmax(x2) if x2 is not None else None
+    _timed("linear_f16x3_kernel", 2.0 * M * (K1 + K2) * (N1 + N2),
+           lambda: call("mulan_linear_f16x3", ptr(x1), ptr(m1), ptr(x2), ptr(m2), K1, K2, ptr(wp), ptr(wmax), ptr(bias),
+                        ptr(res), ptr(y1), ptr(y2), N1, N2, M, HW, stream()))
+    return y1, y2
+
+
 class LinearFn(torch.autograd.Function):
     """y[M,N] = x[M,K] @ w[K,N] + bias + res   (flax nn.Dense: y = x @ kernel + bias)"""
 
@@ -294,7 +331,13 @@ class LinearFn(torch.autograd.Function):
         K, N = w.shape
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
-        y = gemm_raw(x2, w, M, N, K, bias=_c(bias), R=None if res is None else _c(res).reshape(M, N))
+        ctx.fast = linear_fast_ok(x, K, 0, N, 0) and K % 128 == 0
+        ctx.wmax = None
+        if ctx.fast:
+            wp, ctx.wmax = linear_pack(w, False)
+            y, _ = linear_f16x3_raw(x, None, wp, ctx.wmax, N, 0, bias=_c(bias), res=_c(res))
+        else:
+            y = gemm_raw(x2, w, M, N, K, bias=_c(bias), R=None if res is None else _c(res).reshape(M, N))
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, bias is not None, res is not None)
         ctx.gv = (_gv(w), _gv(bias))
@@ -307,10 +350,15 @@ class LinearFn(torch.autograd.Function):
         xshape, has_bias, has_res = ctx.meta
         K, N = w.shape
         M = x2.shape[0]
-        dy2 = _c(dy).reshape(M, N)
+        dy = _c(dy)
+        dy2 = dy.reshape(M, N)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_raw(dy2, w, M, K, N, transB=True).view(xshape)
+            if ctx.fast:
+                wpt, _ = linear_pack(w, True, ctx.wmax)
+                dx = linear_f16x3_raw(dy.view(-1, HW, N), None, wpt, ctx.wmax, K, 0)[0].view(xshape)
+            else:
+                dx = gemm_raw(dy2, w, M, K, N, transB=True).view(xshape)
         gvw, gvb = ctx.gv
         if ctx.needs_input_grad[1]:
             dw = gemm_raw(x2, dy2, K, N, M, transA=True, out=_fresh(gvw) if gvw is not None else None)
@@ -334,8 +382,14 @@ class Linear2Fn(torch.autograd.Function):
         K1, K2, N = x1.shape[-1], x2.shape[-1], w.shape[1]
         a1, a2 = x1.reshape(-1, K1), x2.reshape(-1, K2)
         M = a1.shape[0]
-        y = gemm_raw(a1, w[:K1], M, N, K1, bias=_c(bias))
-        y = gemm_raw(a2, w[K1:], M, N, K2, R=y, out=torch.empty_like(y))
+        ctx.fast = linear_fast_ok(x1, K1, K2, N, 0) and K1 % 128 == 0 and K2 % 128 == 0
+        ctx.wmax = None
+        if ctx.fast:      # one pass over both inputs, no intermediate
+            wp, ctx.wmax = linear_pack(w, False)
+            y = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias))[0].view(M, N)
+        else:
+            y = gemm_raw(a1, w[:K1], M, N, K1, bias=_c(bias))
+            y = gemm_raw(a2, w[K1:], M, N, K2, R=y, out=torch.empty_like(y))
         ctx.save_for_backward(a1, a2, w)
         ctx.shape = x1.shape[:-1]
         ctx.gv = (_gv(w), _gv(bias))
@@ -347,9 +401,15 @@ class Linear2Fn(torch.autograd.Function):
         a1, a2, w = ctx.saved_tensors
         K1, K2, N = a1.shape[1], a2.shape[1], w.shape[1]
         M = a1.shape[0]
-        dy2 = _c(dy).reshape(M, N)
-        dx1 = gemm_raw(dy2, w[:K1], M, K1, N, transB=True).view(*ctx.shape, K1) if ctx.needs_input_grad[0] else None
-        dx2 = gemm_raw(dy2, w[K1:], M, K2, N, transB=True).view(*ctx.shape, K2) if ctx.needs_input_grad[1] else None
+        dy = _c(dy)
+        dy2 = dy.reshape(M, N)
+        if ctx.fast and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            wpt, _ = linear_pack(w, True, ctx.wmax)          # dy @ w^T, split into the two inputs' gradients on the way out
+            dx1, dx2 = linear_f16x3_raw(dy.view(-1, HW, N), None, wpt, ctx.wmax, K1, K2)
+            dx1, dx2 = dx1.view(*ctx.shape, K1), dx2.view(*ctx.shape, K2)
+        else:
+            dx1 = gemm_raw(dy2, w[:K1], M, K1, N, transB=True).view(*ctx.shape, K1) if ctx.needs_input_grad[0] else None
+            dx2 = gemm_raw(dy2, w[K1:], M, K2, N, transB=True).view(*ctx.shape, K2) if ctx.needs_input_grad[1] else None
         dw = None
         gvw, gvb = ctx.gv
         if ctx.needs_input_grad[2]:

@@ -202,3 +202,64 @@ def test_f16x3_plane_fed_wgrad(ops, B, C, N, ints):
         scale = np.abs(ref).max()
         e_p, e_9 = np.abs(dw - ref).max() / scale, np.abs(d32 - ref).max() / scale
         assert e_p < 1e-5 and e_p < 2 * e_9 + 1e-6, (e_p, e_9)
+
+
+@pytest.mark.parametrize("B,K1,K2,N", [(2, 128, 0, 128), (1, 128, 128, 128), (3, 256, 0, 256), (2, 128, 128, 256)])
+def test_f16x3_linear_exact_on_integers_and_accuracy(ops, B, K1, K2, N):
+    """[x1 | x2] @ w + bias + res through the f16x3 per-pixel dense kernel, and dy @ w^T split into two outputs"""
+    rng = np.random.default_rng(B + K1 + K2 + N)
+    K = K1 + K2
+    for ints in (True, False):
+        if ints:
+            x = rng.integers(-3, 4, (B, 1024, K)).astype(np.float64)
+            w = rng.integers(-2, 3, (K, N)).astype(np.float64)
+            bias = rng.integers(-3, 4, N).astype(np.float64)
+            res = rng.integers(-3, 4, (B, 1024, N)).astype(np.float64)
+            dy = rng.integers(-2, 3, (B, 1024, N)).astype(np.float64)
+        else:
+            x = rng.standard_normal((B, 1024, K)) * np.array([1.0, 1e-4, 300.0])[:B, None, None]
+            w = rng.standard_normal((K, N)) / math.sqrt(K)
+            bias, res = rng.standard_normal(N), rng.standard_normal((B, 1024, N))
+            dy = rng.standard_normal((B, 1024, N)) * np.array([1e-5, 1.0, 7.0])[:B, None, None]
+        f32 = lambda a: a.astype(np.float32).astype(np.float64)
+        x1d = dev(x[..., :K1])
+        x2d = dev(x[..., K1:]) if K2 else None
+        wd = dev(w)
+        wp, wmax = ops.linear_pack(wd, False)
+        y, _ = ops.linear_f16x3_raw(x1d, x2d, wp, wmax, N, 0, bias=dev(bias), res=None if K2 else dev(res))
+        ref = f32(x) @ f32(w) + f32(bias) + (0 if K2 else f32(res))
+        wpt, _ = ops.linear_pack(wd, True, wmax)
+        dx1, dx2 = ops.linear_f16x3_raw(dev(dy), None, wpt, wmax, K1, K2)
+        dxr = f32(dy) @ f32(w).T
+        got_dx = dx1.cpu().double().numpy() if not K2 else np.concatenate([dx1.cpu().double().numpy(),
+                                                                         dx2.cpu().double().numpy()], -1)
+        if ints:
+            assert np.array_equal(y.cpu().double().numpy(), ref)
+            assert np.array_equal(got_dx, dxr)
+        else:
+            for b in range(B):   # per image: the scales are per image
+                mag = np.abs(f32(x[b])) @ np.abs(f32(w)) + np.abs(f32(bias)) + (0 if K2 else np.abs(f32(res[b])))
+                assert float((np.abs(y[b].cpu().double().numpy() - ref[b]) / mag).max()) < 2e-6, b
+                magd = np.abs(f32(dy[b])) @ np.abs(f32(w)).T
+                assert float((np.abs(got_dx[b] - dxr[b]) / magd).max()) < 2e-6, b
+
+
+def test_f16x3_linear_autograd_matches_fp32_gemm(ops, monkeypatch):
+    torch.manual_seed(1)
+    B, K, N = 2, 128, 128
+    x1 = torch.randn(B, 1024, K, device="cuda", requires_grad=True)
+    x2 = torch.randn(B, 1024, K, device="cuda", requires_grad=True)
+    w = (torch.randn(2 * K, N, device="cuda") * 0.05).requires_grad_(True)
+    w1 = (torch.randn(K, N, device="cuda") * 0.05).requires_grad_(True)
+    bias = torch.randn(N, device="cuda", requires_grad=True)
+    g = torch.randn(B, 1024, N, device="cuda")
+    outs = {}
+    for mode in ("f32", "f16x3"):
+        monkeypatch.setattr(ops, "CONV_MODE", mode)
+        for t in (x1, x2, w, w1, bias):
+            t.grad = None
+        y = ops.linear2(x1, x2, w, bias) + ops.linear(x1, w1, bias, x2)
+        y.backward(g)
+        outs[mode] = [y.detach().clone()] + [t.grad.clone() for t in (x1, x2, w, w1, bias)]
+    for a, b in zip(outs["f32"], outs["f16x3"]):
+        assert float((a - b).abs().max() / a.abs().max()) < 1e-5
