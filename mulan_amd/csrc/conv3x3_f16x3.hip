@@ -906,7 +906,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
       const int d = (clamped_exp(row_max16(p.xmax, b_acc)) - clamped_exp(row_max16(p.xmax, b_now))) +
                     (clamped_exp(row_max16(p.dymax, b_acc)) - clamped_exp(row_max16(p.dymax, b_now)));
       // acc *= 2^d in place on the accumulator registers (kept in the "a" class so that the register allocation of
-      // the main loop is not disturbed by this rare path); four registers per block so the moves interleave
+      // the main loop is not disturbed by this rare path); four registers per block so the moves interleave.
+      // Neighbouring images mostly share their exponents: nothing to do then.
+      if (d != 0) {
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -927,6 +929,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
                     "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
                   : "v"(d));
             }
+      }
       b_acc = b_now;
     }
     const unsigned char* xa = bc + xa_off;
@@ -1014,7 +1017,7 @@ int wgrad_splits_p(int B, int H, int C, int N) {   // 3 kh blocks per (tile, pix
   const int pairs = B * (H / WG_ROWS);
   const int target = g_mulan_tune[1] > 0 ? g_mulan_tune[1] : 240;
   int S = target / (3 * tiles);
-  if (S >= 8) S &= ~7;
+  if (S >= 8 && g_mulan_tune[6] != 1) S &= ~7;      // tune[6] = 1: dev switch, no XCD alignment
   if (S < 1) S = 1;
   if (S > pairs) S = pairs;
   return S;
