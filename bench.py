@@ -169,8 +169,20 @@ def main():
             # split modes: `passes` 16-bit MFMA passes per algorithmic product -> the scheme's ceiling in algorithmic
             # FLOP/s is the dense bf16/fp16 MFMA peak / passes; exact-fp32 MFMA mode: the fp32 MFMA peak.
             peak = PEAK_BF16_MFMA_TFLOPS / passes if bf else PEAK_F32_MFMA_TFLOPS
+            # HBM bytes per launch: from the committed rocprofv3 PMC passes of this kernel (separate FETCH_SIZE /
+            # WRITE_SIZE runs, gfx950 corrections applied; tools/pmc_conv.py), not re-measured inside the bench
+            traffic, pmc = a.traffic, None
+            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_conv3x3_f16x3.json")
+            if "f16x3" in name and os.path.exists(pmc_file):
+                with open(pmc_file) as f:
+                    pj = json.load(f)
+                pmc = {"source": "profiles/r01_pmc_conv3x3_f16x3.json (B=128, 128->128 launch)",
+                       "hbm_bytes_per_launch": pj["hbm_bytes_per_launch"], "hbm_GBps": round(pj["hbm_GBps"], 1),
+                       "mfma_util": round(pj["mfma_util"], 4), "clock_GHz": round(pj["clock_GHz_from_GRBM"], 3)}
+                if traffic is None:
+                    traffic = pj["hbm_bytes_per_launch"]
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
-                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": a.traffic,
+                    "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "pmc": pmc,
                     "peak_note": (f"dense 16-bit MFMA 2500 TFLOP/s / {passes} passes (split operands, fp32-equivalent "
                                   "products)" if bf else "dense fp32 MFMA"),
                     "executed_mfma_tflops": round(passes * ach, 1) if bf else None,
