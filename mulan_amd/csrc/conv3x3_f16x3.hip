@@ -360,9 +360,11 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
 #pragma unroll
     for (int s = 0; s < PV; ++s) preg[s] = *reinterpret_cast<const f32x4*>(pptr[s] + (((phalo >> s) & 1u) ? cc * CK : 0));
   };
-  // branch free (the loop body must stay one basic block so that this work can be scheduled between the MFMAs):
-  // slots beyond the patch, and every slot when `live` is false, land in a dummy area behind the two patches
-  auto store_slot = [&](unsigned char* pb, int s, bool live, int cc) {
+  // branch free (the loop body must stay one basic block so that this work can be scheduled between the MFMAs;
+  // even a uniform condition in here makes the compiler branch): slots beyond the patch land in a dummy area behind
+  // the two patches.  (During the last chunk the "next" patch is a harmless re-load of the current one: same data,
+  // stored into the idle buffer and re-emitted to the same place.)
+  auto store_slot = [&](unsigned char* pb, int s, int cc) {
     f32x4 v = preg[s];
     if (!((phalo >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
     f16x4 hi, lo;
@@ -372,17 +374,17 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
       split2(v[e] * sx, h, l);
       hi[e] = h; lo[e] = l;
     }
-    unsigned char* d = (live && pdst[s] >= 0) ? pb + pdst[s] : smem + 2 * PATCH2_B;
+    unsigned char* d = pdst[s] >= 0 ? pb + pdst[s] : smem + 2 * PATCH2_B;
     *reinterpret_cast<f16x4*>(d) = hi;
     *reinterpret_cast<f16x4*>(d + 32) = lo;
     // the same two quads go to the plane tensor (consumed by the weight-gradient kernel)
-    const unsigned eo = (live && pemit[s] != 0xffffffffu) ? pemit[s] + (unsigned)cc * 65536u : 0xffffffffu;
+    const unsigned eo = pemit[s] != 0xffffffffu ? pemit[s] + (unsigned)cc * 65536u : 0xffffffffu;
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), xs_rsrc, eo, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo == 0xffffffffu ? eo : eo + 32, 0, 0);
   };
   auto store_patch = [&](unsigned char* pb, int cc) {
 #pragma unroll
-    for (int s = 0; s < PV; ++s) store_slot(pb, s, true, cc);
+    for (int s = 0; s < PV; ++s) store_slot(pb, s, cc);
   };
   // weight fragments: packed [tap][chunk][cout][plane][16 k] fp16; this lane's 8 k of cout (n0 + wn*64 + nt*32 + li)
   const size_t tile_stride = (size_t)N * 64;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
       }
       if (tap == 0) gload_patch(more ? cc + 1 : cc);
       // the next patch is split and stored one float4 slot per stage (taps 2..7), inside the MFMA shadow
-      if (tap >= 2 && tap < 2 + PV) store_slot(pnxt, tap - 2, more, cc + 1);
+      if (tap >= 2 && tap < 2 + PV) store_slot(pnxt, tap - 2, more ? cc + 1 : cc);
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
         constexpr int PA[3] = {1, 0, 0};
@@ -478,8 +480,9 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
     const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + (size_t)b * N + nb);
     bias4[0] += c[0]; bias4[1] += c[1]; bias4[2] += c[2]; bias4[3] += c[3];
   }
-  // (issuing the residual / per-pixel bias loads of all four rows up front was measured slower: the epilogue is bound
-  // by the memory system's throughput -- every CU is in its epilogue at the same time -- not by load latency)
+  // (issuing the residual / per-pixel bias loads of all four rows up front, or of row mt + 1 before row mt is stored,
+  // were both measured slower: with a residual the launch moves 285 MB and the epilogue is bound by the memory
+  // system's throughput, not by load latency; staggering the blocks' start does not help either)
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
