@@ -76,7 +76,7 @@ int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int
                              mulan_stream_t stream);
 int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
                             const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, void* xs,
-                            int B, int H, int W, int C, int N, mulan_stream_t stream);
+                            unsigned* ymax, int B, int H, int W, int C, int N, mulan_stream_t stream);
 
 size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,
@@ -87,7 +87,8 @@ int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float*
  * scaled fp16 planes of x as [B][C/16][H*W][plane][16].  The weight gradient below consumes the planes of the forward
  * input (xs, from the forward call) and of the output gradient (dys, from the input-gradient call, i.e. the same
  * kernel run on dy with flip = 1 weights), so the fp32 -> 2 x fp16 split is done once per tensor.  xmax / dymax are
- * the per-image maxima the planes were scaled with.  Needs C % 128 == 0 and N % 128 == 0. */
+ * the per-image maxima the planes were scaled with.  Needs C % 128 == 0 and N % 128 == 0.
+ * ymax (optional, [B][16]): the maxima of the convolution's own output, for whichever f16x3 kernel reads it next. */
 size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C);
 size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
@@ -134,7 +135,10 @@ int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const 
 int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
                         const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
                         float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
-                        unsigned long long seed, unsigned long long offset, int accumulate, mulan_stream_t stream);
+                        unsigned long long seed, unsigned long long offset, int accumulate, unsigned* dx1max,
+                        unsigned* dx2max, mulan_stream_t stream);
+/* dx1max / dx2max (optional, [B][16]): maxima of the written input gradients in the mulan_absmax_rows format (the
+ * gradient that reaches the previous convolution as dy). */
 
 /* ---- small fused elementwise / reduction kernels ---------------------------------------------- */
 /* kind 1: SiLU (nn.swish); kind 2: shift + softplus (model_mulan_epsilon.py:537). */

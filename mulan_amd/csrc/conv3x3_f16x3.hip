@@ -66,6 +66,7 @@ struct ConvArgsH {
   int B, H, C, N, cbias_mode;
   unsigned long long* stamps;   // dev-only (mulan_set_debug_buffer)
   unsigned char* xs;            // optional by-product: the split planes of x, [B][C/16][H*W][plane][16] fp16
+  unsigned* ymax;               // optional by-product: [B][16] partial maxima of |y| (mulan_absmax_rows format)
 };
 
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   // (issuing the residual / per-pixel bias loads of all four rows up front, or of row mt + 1 before row mt is stored,
   // were both measured slower: with a residual the launch moves 285 MB and the epilogue is bound by the memory
   // system's throughput, not by load latency; staggering the blocks' start does not help either)
+  unsigned omax = 0;
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -516,9 +518,22 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(stage + (it * 4 + prl) * TS + c4 * 4);
       const f32x4 o = {a[0] + add[it][0], a[1] + add[it][1], a[2] + add[it][2], a[3] + add[it][3]};
       *reinterpret_cast<f32x4*>(yout + rowbase + (size_t)(it * 4 + prl) * N) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) omax = max(omax, __float_as_uint(o[e]) & 0x7fffffffu);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+  }
+  if (p.ymax) {   // this block is partial maximum number (row tile, cout block) of image b; unused entries zeroed
+    const int part = (h0 / TR2) * gridDim.y + blockIdx.y, nparts = tiles_per_img * gridDim.y;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+    __syncthreads();
+    unsigned* ured = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) ured[wave] = omax;
+    __syncthreads();
+    if (tid == 0) p.ymax[b * 16 + part] = max(max(ured[0], ured[1]), max(ured[2], ured[3]));
+    if (part == 0 && tid >= nparts && tid < 16) p.ymax[b * 16 + tid] = 0u;
   }
   if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -1087,7 +1102,8 @@ MULAN_API size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C) { return
 // mulan_conv3x3_wgrad_f16x3_planes.
 MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
                                       const float* bias, const float* cbias, int cbias_mode, const float* res,
-                                      float* y, void* xs, int B, int H, int W, int C, int N, hipStream_t stream) {
+                                      float* y, void* xs, unsigned* ymax, int B, int H, int W, int C, int N,
+                                      hipStream_t stream) {
   if (W != kW || H % TROWS != 0 || B <= 0 || C % CK != 0 || C <= 0 || N % BN != 0 || N <= 0 || !xmax || !wmax)
     return (int)hipErrorInvalidValue;
   static bool configured = false;
@@ -1098,9 +1114,10 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
     configured = true;
   }
   ConvArgsH a{x, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
-              cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(xs)};
+              cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(xs), ymax};
   if (xs && (H % TR2 != 0 || (size_t)B * H * W * C * 4 >= 0x80000000ull)) return (int)hipErrorInvalidValue;
-  if (H % TR2 == 0 && g_mulan_tune[3] != 1) {     // tune[3] = 1: dev A/B switch back to the 2 x 2-tile variant
+  if (ymax && (H % TR2 != 0 || (H / TR2) * (N / BN) > kMaxParts)) return (int)hipErrorInvalidValue;
+  if (H % TR2 == 0 && (g_mulan_tune[3] != 1 || xs || ymax)) {   // tune[3] = 1: dev A/B switch to the 2 x 2-tile variant
     static bool configured2 = false;
     if (!configured2) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v2_kernel),

@@ -123,6 +123,7 @@ struct GnBwdArgs {
   float* dgamma_part; float* dbeta_part;       // [B,C1+C2] per-sample partials
   int B, G; int act; float keep; unsigned long long seed, offset;
   int accumulate;                              // dx += instead of dx =
+  unsigned* dx1max; unsigned* dx2max;          // optional [B][16]: partial maxima of |dx1|, |dx2| (single-pass kernel)
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
   }
   const int g0 = (quad / qpg) * qpg;
   float t1 = 0.f, t2 = 0.f;
+  unsigned amax = 0;
   for (int q = g0; q < g0 + qpg; ++q)
 #pragma unroll
     for (int w = 0; w < 8; ++w) { t1 += red[w * 8 + q]; t2 += red[64 + w * 8 + q]; }
@@ -308,6 +310,25 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
       o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3];
     }
     *reinterpret_cast<f32x4*>(dp) = o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+  }
+  unsigned* mout = c0 < p.C1 ? p.dx1max : p.dx2max;
+  if (mout) {   // this block's slab is one partial maximum of its image in its input tensor (unused entries zeroed)
+    const int slab = (c0 < p.C1 ? c0 : c0 - p.C1) / 32, nslab = (c0 < p.C1 ? p.C1 : p.C2) / 32;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+    __syncthreads();
+    unsigned* ured = reinterpret_cast<unsigned*>(red);
+    if ((tid & 63) == 0) ured[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned m = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) m = max(m, ured[w]);
+      mout[b * 16 + slab] = m;
+    }
+    if (slab == 0 && tid >= nslab && tid < 16) mout[b * 16 + tid] = 0u;
   }
 }
 
@@ -331,14 +352,15 @@ MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float*
                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   float* dx1, float* dx2, float* dgamma_part, float* dbeta_part, int B, int hw,
                                   int G, int act, float keep, unsigned long long seed, unsigned long long offset,
-                                  int accumulate, hipStream_t stream) {
+                                  int accumulate, unsigned* dx1max, unsigned* dx2max, hipStream_t stream) {
   const int Ct = C1 + C2;
   if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
+  if ((dx1max && C1 / 32 > 16) || (dx2max && C2 / 32 > 16)) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
-              B, G, act, keep, seed, offset, accumulate};
-  if (g_mulan_tune[2] == 1)   // dev A/B: the two-pass 256-thread variant
+              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max};
+  if (g_mulan_tune[2] == 1 && !dx1max && !dx2max)   // dev A/B: the two-pass 256-thread variant
     hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);

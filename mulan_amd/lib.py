@@ -27,7 +27,7 @@ SIGNATURES = {
     "mulan_absmax_rows": [P, P, I, Z, P],
     "mulan_conv3x3_pack_f16x3_bytes": [I, I],
     "mulan_conv3x3_pack_f16x3": [P, P, P, I, I, I, P],
-    "mulan_conv3x3_fwd_f16x3": [P, P, P, P, P, P, I, P, P, P, I, I, I, I, I, P],
+    "mulan_conv3x3_fwd_f16x3": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],
     "mulan_conv3x3_planes_bytes": [I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3_planes_workspace": [I, I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, P],
@@ -39,7 +39,7 @@ SIGNATURES = {
     "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P],
     "mulan_gemm_workspace": [I, I, I, I],
     "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P],
-    "mulan_groupnorm_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, I, P],
+    "mulan_groupnorm_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, I, P, P, P],
     "mulan_act_fwd": [P, P, Z, I, F, P],
     "mulan_act_bwd": [P, P, P, Z, I, P],
     "mulan_colsum": [P, P, I, I, I, I, I, P],

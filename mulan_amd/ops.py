@@ -114,9 +114,13 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False, 
         if xmax is None:
             xmax = absmax_rows(x)
         xs = torch.empty(B * HW * C * 4, device=x.device, dtype=torch.uint8) if planes else None
+        # by-product: the maxima of y, left on the tensor for whichever f16x3 kernel reads it next
+        ymax = torch.empty((B, MAX_PARTS), device=x.device, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
         _timed("conv3x3_f16x3_kernel", flops,
                lambda: call("mulan_conv3x3_fwd_f16x3", ptr(x), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cbias), mode,
-                            ptr(res), ptr(y), ptr(xs), B, H, W, C, N, stream()))
+                            ptr(res), ptr(y), ptr(xs), ptr(ymax), B, H, W, C, N, stream()))
+        if ymax is not None:
+            y._absmax = (ymax, y._version)
         if planes:
             return y, xs
     else:
@@ -140,7 +144,7 @@ def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None):
             dys = torch.empty(B * HW * N * 4, device=dy.device, dtype=torch.uint8) if planes else None
             _timed("conv3x3_f16x3_kernel", flops,
                    lambda: call("mulan_conv3x3_fwd_f16x3", ptr(dy), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
-                                ptr(dx), ptr(dys), B, H, W, N, C, stream()))
+                                ptr(dx), ptr(dys), None, B, H, W, N, C, stream()))
             if planes:
                 return dx, dys
         else:
@@ -492,8 +496,17 @@ class GroupNormFn(torch.autograd.Function):
         dx2 = torch.empty_like(x2) if x2 is not None else None
         dgp = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
         dbp = torch.empty_like(dgp)
+        # by-product: maxima of the input gradients (dx1 is the dy of the convolution in front of this GroupNorm)
+        f16 = CONV_MODE == "f16x3"
+        m1 = torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32) if f16 and C1 // 32 <= MAX_PARTS else None
+        m2 = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
+              if f16 and x2 is not None and C2 // 32 <= MAX_PARTS else None)
         call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-             ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, stream())
+             ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, ptr(m1), ptr(m2), stream())
+        if m1 is not None:
+            dx1._absmax = (m1, dx1._version)
+        if m2 is not None:
+            dx2._absmax = (m2, dx2._version)
         gvg, gvb = ctx.gv
         dgamma = colsum_raw(dgp, 1, B, Ct, out=_fresh(gvg).view(1, Ct) if gvg is not None else None).view(Ct)
         dbeta = colsum_raw(dbp, 1, B, Ct, out=_fresh(gvb).view(1, Ct) if gvb is not None else None).view(Ct)

@@ -263,3 +263,28 @@ def test_f16x3_linear_autograd_matches_fp32_gemm(ops, monkeypatch):
         outs[mode] = [y.detach().clone()] + [t.grad.clone() for t in (x1, x2, w, w1, bias)]
     for a, b in zip(outs["f32"], outs["f16x3"]):
         assert float((a - b).abs().max() / a.abs().max()) < 1e-5
+
+
+def test_conv_and_gn_backward_leave_maxima(ops):
+    """by-products: the f16x3 convolution leaves the maxima of its output, GroupNorm backward those of its input
+    gradients; both equal a pass over the tensor"""
+    torch.manual_seed(5)
+    B, C, N = 3, 128, 256
+    x = torch.randn(B, 1024, C, device="cuda") * torch.tensor([1.0, 1e-3, 30.0], device="cuda").view(3, 1, 1)
+    w = torch.randn(3, 3, C, N, device="cuda") * 0.05
+    res = torch.randn(B, 1024, N, device="cuda")
+    y = ops.conv3x3_raw(x, w, torch.randn(N, device="cuda"), None, res)
+    got = y._absmax[0].cpu().numpy().view(np.float32).max(1)
+    assert np.array_equal(got, y.abs().reshape(B, -1).amax(1).cpu().numpy())
+    x1 = torch.randn(B, 1024, 128, device="cuda", requires_grad=True)
+    x2 = torch.randn(B, 1024, 128, device="cuda", requires_grad=True)
+    g, b = torch.randn(256, device="cuda", requires_grad=True), torch.randn(256, device="cuda", requires_grad=True)
+    out = ops.group_norm(x1, x2, g, b, act=True, keep=0.9, seed=3, offset=0)
+    seen = {}
+    x1.register_hook(lambda t: seen.__setitem__("dx1", getattr(t, "_absmax", None)))
+    x2.register_hook(lambda t: seen.__setitem__("dx2", getattr(t, "_absmax", None)))
+    out.backward(torch.randn_like(out) * torch.tensor([1.0, 1e-4, 9.0], device="cuda").view(3, 1, 1))
+    for name, t in (("dx1", x1.grad), ("dx2", x2.grad)):
+        assert seen[name] is not None
+        got = seen[name][0].cpu().numpy().view(np.float32).max(1)
+        assert np.array_equal(got, t.abs().reshape(B, -1).amax(1).cpu().numpy()), name
