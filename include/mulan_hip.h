@@ -95,6 +95,15 @@ int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const
                                      float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
                                      mulan_stream_t stream);
 
+/* Once-per-step weight preparation for all eligible parameter leaves of the flat parameter buffer in two launches
+ * (instead of maxima + pack per layer and direction).  Leaf record = 8 x int64: element offset in `flat`, kind (0: 3x3
+ * conv [3,3,C,N], 1: dense [C,N]), C, N, byte offset of the forward operand in `packed` or -1, byte offset of the
+ * gradient operand (tap-flipped / transposed) or -1, number of elements, 0.  Formats as produced by
+ * mulan_absmax_rows / mulan_conv3x3_pack_f16x3 / mulan_linear_pack_f16x3. */
+int mulan_param_maxima(const float* flat, const long long* leaves, int n, unsigned* out, mulan_stream_t stream);
+int mulan_param_pack_f16x3(const float* flat, const long long* leaves, int n, const unsigned* maxima, void* packed,
+                           mulan_stream_t stream);
+
 /* ---- per-pixel dense layers on the fp16 matrix cores (f16x3 scheme) -------------------------------
  *   y[M, N1 | N2] = [x1 | x2][M, K1 + K2] @ W + bias + res
  * with a virtual channel concat on the input side and a split on the output side: nin_shortcut on

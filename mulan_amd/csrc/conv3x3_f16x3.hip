@@ -1069,6 +1069,60 @@ int wgrad_splits_h(int B, int H, int C, int N) {
   return S;
 }
 
+// ---- once-per-step weight preparation for every eligible parameter leaf at a time (two launches instead of two
+// per layer and direction): maxima of all leaves, then both packed operands (forward and gradient) of all leaves.
+// Leaf record (8 x int64): [0] element offset in the flat parameter buffer, [1] kind (0: 3x3 conv [3,3,C,N],
+// 1: dense [C,N]), [2] C, [3] N, [4] byte offset of the forward operand in the packed buffer or -1, [5] of the
+// gradient operand (tap-flipped / transposed) or -1, [6] number of elements.
+__global__ __launch_bounds__(256) void param_maxima_kernel(const float* __restrict__ flat, const long long* __restrict__ leaves,
+                                                           unsigned* __restrict__ out) {
+  __shared__ unsigned red[4];
+  const long long* L = leaves + (size_t)blockIdx.x * 8;
+  const f32x4* row = reinterpret_cast<const f32x4*>(flat + L[0]);
+  const size_t len4 = (size_t)L[6] / 4;
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < len4; i += (size_t)kMaxParts * 256) {
+    const f32x4 a = row[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(a[e]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(size_t)blockIdx.x * kMaxParts + blockIdx.y] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void param_pack_kernel(const float* __restrict__ flat, const long long* __restrict__ leaves,
+                                                         const unsigned* __restrict__ maxima, unsigned char* __restrict__ packed) {
+  const long long* L = leaves + (size_t)blockIdx.x * 8;
+  const int dir = blockIdx.y;                       // 0: forward operand, 1: gradient operand
+  const long long dst_off = L[4 + dir];
+  if (dst_off < 0) return;
+  const float* w = flat + L[0];
+  const int kind = (int)L[1], C = (int)L[2], N = (int)L[3];
+  _Float16* wp = reinterpret_cast<_Float16*>(packed + dst_off);
+  float sw, inv_w;
+  scale_of(row_max16(maxima, blockIdx.x), sw, inv_w);
+  const int taps = kind == 0 ? 9 : 1;
+  const int Kin = dir ? N : C, Nout = dir ? C : N;
+  const size_t total = (size_t)taps * Kin * Nout;
+  for (size_t i = (size_t)blockIdx.z * 256 + threadIdx.x; i < total; i += (size_t)gridDim.z * 256) {
+    const int k = (int)(i % 16);
+    size_t r = i / 16;
+    const int o = (int)(r % Nout); r /= Nout;
+    const int cc = (int)(r % (Kin / 16));
+    const int t = (int)(r / (Kin / 16));
+    const int kin = cc * 16 + k;
+    // forward: Wl[t][kin][o] = w[t][kin][o]; gradient: Wl[t][kin][o] = w[taps-1-t][o][kin]   (w is [taps][C][N])
+    const float v = dir ? w[((size_t)(taps - 1 - t) * C + o) * N + kin] : w[((size_t)t * C + kin) * N + o];
+    _Float16 h, l;
+    split2(v * sw, h, l);
+    _Float16* dst = wp + (((size_t)(t * (Kin / 16) + cc) * Nout + o) * 2) * 16 + k;
+    dst[0] = h; dst[16] = l;
+  }
+}
+
 }  // namespace
 
 // out[r][0..15] = fp32 bit patterns of 16 partial maxima of |x[r, 0:row_len]| (row_len % 4 == 0, x 16-byte aligned);
@@ -1187,5 +1241,22 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
                      stream, a);
   const int E = 9 * C * N;
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
+  MULAN_CHECK_LAUNCH();
+}
+
+// Maxima of n parameter leaves in one launch (leaf records: see param_maxima_kernel); out is [n][16].
+MULAN_API int mulan_param_maxima(const float* flat, const long long* leaves, int n, unsigned* out, hipStream_t stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(param_maxima_kernel, dim3(n, kMaxParts), dim3(256), 0, stream, flat, leaves, out);
+  MULAN_CHECK_LAUNCH();
+}
+
+// Both packed f16x3 operands (forward: mulan_conv3x3_pack_f16x3 flip = 0 / mulan_linear_pack_f16x3 transpose = 0;
+// gradient: flip = 1 / transpose = 1) of n parameter leaves in one launch, into `packed` at the records' offsets.
+MULAN_API int mulan_param_pack_f16x3(const float* flat, const long long* leaves, int n, const unsigned* maxima,
+                                     void* packed, hipStream_t stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(param_pack_kernel, dim3(n, 2, 16), dim3(256), 0, stream, flat, leaves, maxima,
+                     static_cast<unsigned char*>(packed));
   MULAN_CHECK_LAUNCH();
 }

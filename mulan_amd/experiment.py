@@ -106,11 +106,16 @@ class Experiment(abc.ABC):
         rng = base_rng.fold_in(self.rank).fold_in(state.step)
         state.zero_grad()
         self.reducer.prepare()
+        packer = state.param_packer()        # f16x3 mode: weight maxima + packed operands of all layers, two launches
+        if packer is not None:
+            packer.refresh()
         bpd, metrics = self.loss_fn(state.params, batch, step=state.step, rng=rng, is_train=True)
         bpd.backward()
         state.collect_grads()
         self.reducer.finish()
         learning_rate = self.lr_schedule(state.step)
+        if packer is not None:
+            packer.invalidate()              # the optimizer rewrites the parameters
         state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate, grad_scale=1.0 / self.world)
         scalars = parallel.allreduce_mean_scalars(metrics['scalars'], self.device)
         metrics['scalars'] = {'train_' + k: v for k, v in scalars.items()}

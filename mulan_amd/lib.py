@@ -33,6 +33,8 @@ SIGNATURES = {
     "mulan_conv3x3_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_conv3x3_wgrad_f16x3_workspace": [I, I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "mulan_param_maxima": [P, P, I, P, P],
+    "mulan_param_pack_f16x3": [P, P, I, P, P, P],
     "mulan_linear_pack_f16x3_bytes": [I, I],
     "mulan_linear_pack_f16x3": [P, P, P, I, I, I, P],
     "mulan_linear_f16x3": [P, P, P, P, I, I, P, P, P, P, P, P, I, I, I, I, P],

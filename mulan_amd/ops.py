@@ -71,9 +71,68 @@ def cached_absmax(x):
     return m
 
 
+class ParamPacker:
+    """Once-per-step weight preparation (f16x3 mode): maxima and both packed operands of every eligible parameter
+    leaf of a TrainState in two launches; the leaves carry views of the result (`_prepacked`), valid until the
+    optimizer touches the parameters again (`invalidate`)."""
+
+    def __init__(self, flat, leaves_with_offsets):
+        """leaves_with_offsets: [(leaf tensor (view of flat), element offset)]"""
+        recs, self.items, off = [], [], 0
+        for leaf, eoff in leaves_with_offsets:
+            if leaf.dim() == 4 and tuple(leaf.shape[:2]) == (3, 3):
+                kind, C, N = 0, leaf.shape[2], leaf.shape[3]
+                fwd_ok, bwd_ok = C % 16 == 0 and N % 128 == 0, N % 16 == 0 and C % 128 == 0
+            elif leaf.dim() == 2 and leaf.shape[0] % 128 == 0 and leaf.shape[1] % 128 == 0 and leaf.numel() <= 512 * 512:
+                kind, C, N = 1, leaf.shape[0], leaf.shape[1]
+                fwd_ok = bwd_ok = True
+            else:
+                continue
+            if not (fwd_ok or bwd_ok):
+                continue
+            nb = leaf.numel() * 4
+            d0 = off if fwd_ok else -1
+            off += nb if fwd_ok else 0
+            d1 = off if bwd_ok else -1
+            off += nb if bwd_ok else 0
+            recs.append([eoff, kind, C, N, d0, d1, leaf.numel(), 0])
+            self.items.append((leaf, d0, d1, nb))
+        self.n = len(recs)
+        self.flat = flat
+        self.valid = False
+        if self.n:
+            self.table = torch.tensor(recs, dtype=torch.int64, device=flat.device)
+            self.maxima = torch.empty((self.n, MAX_PARTS), dtype=torch.int32, device=flat.device)
+            self.packed = torch.empty(off, dtype=torch.uint8, device=flat.device)
+            for i, (leaf, d0, d1, nb) in enumerate(self.items):
+                leaf._prepacked = (self, self.packed[d0:d0 + nb] if d0 >= 0 else None,
+                                   self.packed[d1:d1 + nb] if d1 >= 0 else None, self.maxima[i:i + 1])
+
+    def refresh(self):
+        if self.n:
+            call("mulan_param_maxima", ptr(self.flat), ptr(self.table), self.n, ptr(self.maxima), stream())
+            call("mulan_param_pack_f16x3", ptr(self.flat), ptr(self.table), self.n, ptr(self.maxima), ptr(self.packed),
+                 stream())
+            self.valid = True
+
+    def invalidate(self):
+        self.valid = False
+
+
+def _prepacked(w, direction):
+    """(wp, wmax) prepared by a ParamPacker for this leaf, if still valid"""
+    pre = getattr(w, "_prepacked", None)
+    if pre is not None and pre[0].valid and CONV_MODE == "f16x3" and pre[1 + direction] is not None:
+        return pre[1 + direction], pre[3]
+    return None
+
+
 def _pack_weights(w, C, N, flip, wmax=None):
     """weights pre-split into the LDS tile layout of the fast convolution kernels; returns (wp, wmax or None)"""
     L = lib.load()
+    pre = _prepacked(w, int(flip))
+    if pre is not None:
+        return pre
     if CONV_MODE == "f16x3":
         wp = torch.empty(L.mulan_conv3x3_pack_f16x3_bytes(C, N), device=w.device, dtype=torch.uint8)
         if wmax is None:
@@ -244,7 +303,8 @@ class Conv3x3Fn(torch.autograd.Function):
         x, w = _c(x), _c(w)
         f16 = CONV_MODE == "f16x3" and x.shape[-1] % 4 == 0        # per-image maxima: shared by fwd and wgrad
         xmax = cached_absmax(x) if f16 else None
-        wmax = absmax_rows(w.view(1, -1)) if f16 else None          # shared by the forward and input-gradient packs
+        pre = _prepacked(w, 0)
+        wmax = (pre[1] if pre is not None else absmax_rows(w.view(1, -1))) if f16 else None   # shared by both packs
         ctx.wmax = wmax
         # the forward kernel hands its split input planes to the weight-gradient kernel: saved instead of x (same bytes)
         ctx.planes = planes_eligible(x.shape[-1], w.shape[-1]) and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
@@ -304,6 +364,9 @@ def linear_fast_ok(x, K1, K2, N1, N2):
 def linear_pack(w, transpose, wmax=None):
     """w [K,N] -> packed operand of y = x @ w (transpose=False) or of dx = dy @ w^T (transpose=True)"""
     K, N = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    pre = _prepacked(w, int(transpose))
+    if pre is not None:
+        return pre
     if wmax is None:
         wmax = absmax_rows(w.reshape(1, -1))
     wp = torch.empty(lib.load().mulan_linear_pack_f16x3_bytes(K, N), device=w.device, dtype=torch.uint8)

@@ -81,6 +81,17 @@ class TrainState:
             d[path[-1]] = v
         return tree
 
+    def param_packer(self):
+        """f16x3 mode: the once-per-step weight preparation of all eligible leaves (ops.ParamPacker), else None"""
+        from . import ops
+        if ops.CONV_MODE != "f16x3" or not self.flat.is_cuda:
+            return None
+        if getattr(self, "_packer", None) is None:
+            leaves = [(leaf, off) for (path, off, shape), (_, leaf) in
+                      zip(self.layout, tree_leaves_in_layout(self.params, self.layout))]
+            self._packer = ops.ParamPacker(self.flat, leaves)
+        return self._packer
+
     def zero_grad(self):
         """Call before each backward: clears the flat buffer and detaches stale .grad handles."""
         self.grad.zero_()

@@ -288,3 +288,36 @@ def test_conv_and_gn_backward_leave_maxima(ops):
         assert seen[name] is not None
         got = seen[name][0].cpu().numpy().view(np.float32).max(1)
         assert np.array_equal(got, t.abs().reshape(B, -1).amax(1).cpu().numpy()), name
+
+
+def test_param_packer_matches_per_layer_packs(ops):
+    """the once-per-step weight preparation (all leaves, two launches) is bit-identical to the per-layer maxima +
+    pack calls, for both operands of a 3x3 kernel and a dense kernel, and is ignored once invalidated"""
+    from mulan_amd.train_state import TrainState
+    g = torch.Generator().manual_seed(0)
+    tree = {"score_model": {"conv1": {"kernel": torch.randn(3, 3, 128, 128, generator=g) * 0.05,
+                                      "bias": torch.randn(128, generator=g)},
+                            "conv_in": {"kernel": torch.randn(3, 3, 16, 128, generator=g)},
+                            "nin_shortcut": {"kernel": torch.randn(256, 128, generator=g) * 0.1},
+                            "dense_big": {"kernel": torch.randn(1024, 1024, generator=g)}}}
+    st = TrainState.create(apply_fn=None, variables={"params": tree}, device="cuda")
+    packer = st.param_packer()
+    assert packer is not None and packer.n == 3          # conv1, conv_in (forward operand only), nin_shortcut
+    p = st.params["score_model"]
+    wc, wi, wn = p["conv1"]["kernel"], p["conv_in"]["kernel"], p["nin_shortcut"]["kernel"]
+    ref = {}
+    for name, w, fn, args in (("c0", wc, ops._pack_weights, (128, 128, 0)), ("c1", wc, ops._pack_weights, (128, 128, 1)),
+                              ("i0", wi, ops._pack_weights, (16, 128, 0)), ("n0", wn, ops.linear_pack, (False,)),
+                              ("n1", wn, ops.linear_pack, (True,))):
+        ref[name] = fn(w, *args)
+    packer.refresh()
+    for name, w, fn, args in (("c0", wc, ops._pack_weights, (128, 128, 0)), ("c1", wc, ops._pack_weights, (128, 128, 1)),
+                              ("i0", wi, ops._pack_weights, (16, 128, 0)), ("n0", wn, ops.linear_pack, (False,)),
+                              ("n1", wn, ops.linear_pack, (True,))):
+        wp, wmax = fn(w, *args)
+        assert wp.data_ptr() >= packer.packed.data_ptr() and wp.data_ptr() < packer.packed.data_ptr() + packer.packed.numel()
+        assert torch.equal(wp, ref[name][0]), name
+        assert int(wmax.max()) == int(ref[name][1].max()), name
+    packer.invalidate()
+    wp, _ = ops._pack_weights(wc, 128, 128, 0)
+    assert not (packer.packed.data_ptr() <= wp.data_ptr() < packer.packed.data_ptr() + packer.packed.numel())
