@@ -145,9 +145,12 @@ int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C
                         const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
                         float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
                         unsigned long long seed, unsigned long long offset, int accumulate, unsigned* dx1max,
-                        unsigned* dx2max, mulan_stream_t stream);
-/* dx1max / dx2max (optional, [B][16]): maxima of the written input gradients in the mulan_absmax_rows format (the
- * gradient that reaches the previous convolution as dy). */
+                        unsigned* dx2max, const float* add1, const float* add2, float* dxsum_part,
+                        mulan_stream_t stream);
+/* add1 / add2 (optional): gradients arriving through a skip path of x1 / x2 (the ResnetBlock residual, nin_shortcut),
+ * added while dx is written, so that no separate accumulation pass exists.  By-products of the written gradients (the
+ * dy of the convolution in front): dx1max / dx2max (optional, [B][16], mulan_absmax_rows format) and dxsum_part
+ * (optional, [B, C1+C2]: per-sample channel sums = that convolution's per-sample bias gradient). */
 
 /* ---- small fused elementwise / reduction kernels ---------------------------------------------- */
 /* kind 1: SiLU (nn.swish); kind 2: shift + softplus (model_mulan_epsilon.py:537). */

@@ -124,6 +124,8 @@ struct GnBwdArgs {
   int B, G; int act; float keep; unsigned long long seed, offset;
   int accumulate;                              // dx += instead of dx =
   unsigned* dx1max; unsigned* dx2max;          // optional [B][16]: partial maxima of |dx1|, |dx2| (single-pass kernel)
+  const float* add1; const float* add2;        // optional: dx1 += add1, dx2 += add2 (gradient of a skip path of x)
+  float* dxsum_part;                           // optional [B, C1+C2]: per-sample channel sums of the written dx
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -231,6 +233,8 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
   else { src = p.x2; dxp = p.dx2; ld = p.C2; cs = c0 - p.C1; }
   src += (size_t)b * HW * ld + cs + quad * 4;
   dxp += (size_t)b * HW * ld + cs + quad * 4;
+  const float* addp = c0 < p.C1 ? p.add1 : p.add2;
+  if (addp) addp += (size_t)b * HW * ld + cs + quad * 4;
   const int c = c0 + quad * 4, g = c / cpg;
   const float mean = p.mean[b * p.G + g], rstd = p.rstd[b * p.G + g];
   const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
   const int g0 = (quad / qpg) * qpg;
   float t1 = 0.f, t2 = 0.f;
   unsigned amax = 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
   for (int q = g0; q < g0 + qpg; ++q)
 #pragma unroll
     for (int w = 0; w < 8; ++w) { t1 += red[w * 8 + q]; t2 += red[64 + w * 8 + q]; }
@@ -309,9 +314,34 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
       const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
       o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3];
     }
+    if (addp) {
+      const f32x4 ad = *reinterpret_cast<const f32x4*>(addp + (size_t)px * ld);
+      o[0] += ad[0]; o[1] += ad[1]; o[2] += ad[2]; o[3] += ad[3];
+    }
     *reinterpret_cast<f32x4*>(dp) = o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+    for (int e = 0; e < 4; ++e) {
+      amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+      csum[e] += o[e];
+    }
+  }
+  if (p.dxsum_part) {   // per-sample channel sums of what was written (the bias gradient of the convolution in front)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) csum[e] += __shfl_xor(csum[e], o, 64);
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cred[wave * 32 + lane * 4 + e] = csum[e];
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += cred[w * 32 + tid];
+      p.dxsum_part[(size_t)b * Ct + c0 + tid] = a;
+    }
   }
   unsigned* mout = c0 < p.C1 ? p.dx1max : p.dx2max;
   if (mout) {   // this block's slab is one partial maximum of its image in its input tensor (unused entries zeroed)
@@ -352,15 +382,16 @@ MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float*
                                   const float* gamma, const float* beta, const float* mean, const float* rstd,
                                   float* dx1, float* dx2, float* dgamma_part, float* dbeta_part, int B, int hw,
                                   int G, int act, float keep, unsigned long long seed, unsigned long long offset,
-                                  int accumulate, unsigned* dx1max, unsigned* dx2max, hipStream_t stream) {
+                                  int accumulate, unsigned* dx1max, unsigned* dx2max, const float* add1,
+                                  const float* add2, float* dxsum_part, hipStream_t stream) {
   const int Ct = C1 + C2;
   if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   if ((dx1max && C1 / 32 > 16) || (dx2max && C2 / 32 > 16)) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
-              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max};
-  if (g_mulan_tune[2] == 1 && !dx1max && !dx2max)   // dev A/B: the two-pass 256-thread variant
+              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max, add1, add2, dxsum_part};
+  if (g_mulan_tune[2] == 1 && !dx1max && !dx2max && !add1 && !add2 && !dxsum_part)   // dev A/B: two-pass 256-thread variant
     hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);

@@ -41,7 +41,7 @@ SIGNATURES = {
     "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P],
     "mulan_gemm_workspace": [I, I, I, I],
     "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P],
-    "mulan_groupnorm_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, I, P, P, P],
+    "mulan_groupnorm_bwd": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, I, P, P, P, P, P, P],
     "mulan_act_fwd": [P, P, Z, I, F, P],
     "mulan_act_bwd": [P, P, P, Z, I, P],
     "mulan_colsum": [P, P, I, I, I, I, I, P],

@@ -154,7 +154,8 @@ class _Drop:
 
 def resnet_block(p, x1, x2, cond, drop):
     """ResnetBlock.__call__ (ldm/model_vdm.py:618-657 / ldm/ldm_unet.py:18-61) on [x1|x2]."""
-    h = ops.group_norm(x1, x2, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
+    # s1 / s2 alias x1 / x2 for the skip path: their gradients are added inside the GroupNorm backward kernel
+    h, s1, s2 = ops.group_norm_skip(x1, x2, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
     cb = ops.linear(cond, p["cond_proj"]["kernel"])          # [B,E] or [B,1024,E]
     h = ops.conv3x3(h, p["conv1"]["kernel"], p["conv1"]["bias"], cbias=cb)
     keep, seed, off = drop.next()
@@ -162,11 +163,11 @@ def resnet_block(p, x1, x2, cond, drop):
                        offset=off)
     if "nin_shortcut" in p:
         if x2 is None:
-            res = ops.linear(x1, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
+            res = ops.linear(s1, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
         else:
-            res = ops.linear2(x1, x2, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
+            res = ops.linear2(s1, s2, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
     else:
-        res = x1
+        res = s1
     return ops.conv3x3(h, p["conv2"]["kernel"], p["conv2"]["bias"], res=res)
 
 

@@ -341,7 +341,9 @@ class Conv3x3Fn(torch.autograd.Function):
         dbias = dcb = None
         per_sample = None
         if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):
-            per_sample = colsum_raw(dy, B, HW, N)          # [B,N]
+            cs = getattr(dy, "_colsum", None)              # left by the GroupNorm backward that produced dy
+            per_sample = cs[0] if (cs is not None and cs[1] == dy._version and cs[0].shape == (B, N)) \
+                else colsum_raw(dy, B, HW, N)              # [B,N]
         if has_bias and ctx.needs_input_grad[2]:
             dbias = colsum_raw(per_sample, 1, B, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
         if cb_dim is not None and ctx.needs_input_grad[3]:
@@ -523,61 +525,105 @@ def softplus_shift(x, shift):
 
 
 # ----------------------------------------------------------------------------- group norm
+def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
+    x1, x2 = _c(x1), _c(x2)
+    B, C1 = x1.shape[0], x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    y = torch.empty((B, HW, C1 + C2), device=x1.device, dtype=torch.float32)
+    mean = torch.empty((B, groups), device=x1.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    # by-product for a following f16x3 convolution: the per-image maxima of y
+    ymax = (torch.empty((B, MAX_PARTS), device=x1.device, dtype=torch.int32)
+            if CONV_MODE == "f16x3" and (C1 + C2) // 32 <= MAX_PARTS else None)
+    call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B,
+         HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), ptr(ymax), stream())
+    if ymax is not None:
+        y._absmax = (ymax, y._version)
+    ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
+    ctx.meta = (groups, int(act), float(keep), int(seed), int(offset))
+    ctx.gv = (_gv(gamma), _gv(beta))
+    return y, x1, x2
+
+
+def _gn_backward(ctx, dy, add1=None, add2=None):
+    """dx1, dx2 (+ the gradients add1 / add2 that reach x1 / x2 through a skip path), dgamma, dbeta.  The written dx1
+    carries its maxima and per-sample channel sums for the convolution in front (whose dy it is)."""
+    x1, x2, gamma, beta, mean, rstd = ctx.saved_tensors
+    groups, act, keep, seed, offset = ctx.meta
+    dy = _c(dy)
+    B, C1 = x1.shape[0], x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Ct = C1 + C2
+    dx1 = torch.empty_like(x1)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    dgp = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
+    dbp = torch.empty_like(dgp)
+    f16 = CONV_MODE == "f16x3"
+    m1 = torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32) if f16 and C1 // 32 <= MAX_PARTS else None
+    m2 = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
+          if f16 and x2 is not None and C2 // 32 <= MAX_PARTS else None)
+    csum = torch.empty((B, Ct), device=dy.device, dtype=torch.float32) if x2 is None else None
+    call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+         ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, ptr(m1), ptr(m2),
+         ptr(_c(add1)), ptr(_c(add2)), ptr(csum), stream())
+    if m1 is not None:
+        dx1._absmax = (m1, dx1._version)
+    if m2 is not None:
+        dx2._absmax = (m2, dx2._version)
+    if csum is not None:
+        dx1._colsum = (csum, dx1._version)
+    gvg, gvb = ctx.gv
+    dgamma = colsum_raw(dgp, 1, B, Ct, out=_fresh(gvg).view(1, Ct) if gvg is not None else None).view(Ct)
+    dbeta = colsum_raw(dbp, 1, B, Ct, out=_fresh(gvb).view(1, Ct) if gvb is not None else None).view(Ct)
+    return dx1, dx2, dgamma, dbeta
+
+
 class GroupNormFn(torch.autograd.Function):
     """y = dropout(act(GroupNorm([x1|x2])))  -> [B,1024,C1+C2]"""
 
     @staticmethod
     def forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
-        x1, x2 = _c(x1), _c(x2)
-        B, C1 = x1.shape[0], x1.shape[-1]
-        C2 = 0 if x2 is None else x2.shape[-1]
-        y = torch.empty((B, HW, C1 + C2), device=x1.device, dtype=torch.float32)
-        mean = torch.empty((B, groups), device=x1.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        # by-product for a following f16x3 convolution: the per-image maxima of y
-        ymax = (torch.empty((B, MAX_PARTS), device=x1.device, dtype=torch.int32)
-                if CONV_MODE == "f16x3" and (C1 + C2) // 32 <= MAX_PARTS else None)
-        call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B,
-             HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), ptr(ymax), stream())
-        if ymax is not None:
-            y._absmax = (ymax, y._version)
-        ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
-        ctx.meta = (groups, int(act), float(keep), int(seed), int(offset))
-        ctx.gv = (_gv(gamma), _gv(beta))
-        return y
+        return _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset)[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        x1, x2, gamma, beta, mean, rstd = ctx.saved_tensors
-        groups, act, keep, seed, offset = ctx.meta
-        dy = _c(dy)
-        B, C1 = x1.shape[0], x1.shape[-1]
-        C2 = 0 if x2 is None else x2.shape[-1]
-        Ct = C1 + C2
-        dx1 = torch.empty_like(x1)
-        dx2 = torch.empty_like(x2) if x2 is not None else None
-        dgp = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
-        dbp = torch.empty_like(dgp)
-        # by-product: maxima of the input gradients (dx1 is the dy of the convolution in front of this GroupNorm)
-        f16 = CONV_MODE == "f16x3"
-        m1 = torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32) if f16 and C1 // 32 <= MAX_PARTS else None
-        m2 = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
-              if f16 and x2 is not None and C2 // 32 <= MAX_PARTS else None)
-        call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-             ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, ptr(m1), ptr(m2), stream())
-        if m1 is not None:
-            dx1._absmax = (m1, dx1._version)
-        if m2 is not None:
-            dx2._absmax = (m2, dx2._version)
-        gvg, gvb = ctx.gv
-        dgamma = colsum_raw(dgp, 1, B, Ct, out=_fresh(gvg).view(1, Ct) if gvg is not None else None).view(Ct)
-        dbeta = colsum_raw(dbp, 1, B, Ct, out=_fresh(gvb).view(1, Ct) if gvb is not None else None).view(Ct)
-        return dx1, dx2, dgamma, dbeta, None, None, None, None, None, None
+        return _gn_backward(ctx, dy) + (None,) * 6
+
+
+class GroupNormSkipFn(torch.autograd.Function):
+    """(y, s1, s2) with y as GroupNormFn and s1 / s2 aliases of x1 / x2 for the block's skip path (the ResnetBlock
+    residual or nin_shortcut, ldm/model_vdm.py:652-656): the gradients that come back through s1 / s2 are added
+    inside the GroupNorm backward kernel instead of by a separate accumulation pass."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
+        y, x1c, x2c = _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset)
+        s1 = x1c.view_as(x1c)
+        s2 = x2c.view_as(x2c) if x2c is not None else None
+        for src, dst in ((x1, s1), (x2, s2)):                 # the maxima a producer left on x stay valid for the alias
+            c = getattr(src, "_absmax", None) if src is not None else None
+            if c is not None and c[1] == src._version:
+                dst._absmax = (c[0], dst._version)
+        ctx.has2 = x2c is not None
+        return (y, s1, s2) if ctx.has2 else (y, s1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, ds1, ds2=None):
+        if dy is None:     # only the skip path was used downstream
+            return (ds1, ds2) + (None,) * 8
+        return _gn_backward(ctx, dy, ds1, ds2) + (None,) * 6
 
 
 def group_norm(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=1.0, seed=0, offset=0):
     return GroupNormFn.apply(x1, x2, gamma, beta, groups, eps, int(act), keep, seed, offset)
+
+
+def group_norm_skip(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=1.0, seed=0, offset=0):
+    """-> (y, s1, s2): use s1 / s2 instead of x1 / x2 on the skip path of the block (see GroupNormSkipFn)"""
+    out = GroupNormSkipFn.apply(x1, x2, gamma, beta, groups, eps, int(act), keep, seed, offset)
+    return out if len(out) == 3 else (out[0], out[1], None)
 
 
 # ----------------------------------------------------------------------------- attention core

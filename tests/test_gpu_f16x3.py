@@ -321,3 +321,40 @@ def test_param_packer_matches_per_layer_packs(ops):
     packer.invalidate()
     wp, _ = ops._pack_weights(wc, 128, 128, 0)
     assert not (packer.packed.data_ptr() <= wp.data_ptr() < packer.packed.data_ptr() + packer.packed.numel())
+
+
+def test_group_norm_skip_adds_the_skip_gradient_in_kernel(ops):
+    """GroupNormSkipFn: gradients through the aliases s1 / s2 are added inside the backward kernel; the result, its
+    maxima and its per-sample channel sums equal the two-step computation"""
+    torch.manual_seed(9)
+    B = 2
+    for C2 in (0, 128):
+        x1 = torch.randn(B, 1024, 128, device="cuda", requires_grad=True)
+        x2 = torch.randn(B, 1024, C2, device="cuda", requires_grad=True) if C2 else None
+        g = torch.randn(128 + C2, device="cuda", requires_grad=True)
+        b = torch.randn(128 + C2, device="cuda", requires_grad=True)
+        gy = torch.randn(B, 1024, 128 + C2, device="cuda")
+        g1 = torch.randn(B, 1024, 128, device="cuda")
+        g2 = torch.randn(B, 1024, 128, device="cuda") if C2 else None
+        y = ops.group_norm(x1, x2, g, b, act=True, keep=0.9, seed=5, offset=64)
+        loss = (y * gy).sum() + (x1 * g1).sum() + ((x2 * g2).sum() if C2 else 0)
+        loss.backward()
+        ref = [t.grad.clone() for t in (x1, x2, g, b) if t is not None]
+        for t in (x1, x2, g, b):
+            if t is not None:
+                t.grad = None
+        seen = {}
+        x1.register_hook(lambda t: seen.__setitem__("dx1", t))
+        y, s1, s2 = ops.group_norm_skip(x1, x2, g, b, act=True, keep=0.9, seed=5, offset=64)
+        loss = (y * gy).sum() + (s1 * g1).sum() + ((s2 * g2).sum() if C2 else 0)
+        loss.backward()
+        got = [t.grad for t in (x1, x2, g, b) if t is not None]
+        for a, r in zip(got, ref):
+            assert float((a - r).abs().max()) <= 1e-5 * float(r.abs().max())
+        dx1 = seen["dx1"]
+        m = dx1._absmax[0].cpu().numpy().view(np.float32).max(1)
+        assert np.array_equal(m, dx1.abs().reshape(B, -1).amax(1).cpu().numpy())
+        if not C2:
+            cs = dx1._colsum[0]
+            refcs = dx1.double().sum(1)
+            assert float((cs.double() - refcs).abs().max()) <= 2e-5 * float(dx1.abs().double().sum(1).max())

@@ -73,7 +73,7 @@ def main():
             dx2 = torch.empty_like(x2) if C2 else None
             dgp, dbp = torch.empty(B, C1 + C2, device=dev), torch.empty(B, C1 + C2, device=dev)
             fb = lambda: call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(g), ptr(b_), ptr(mean),
-                              ptr(rstd), ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, 1024, 32, 1, 0.9, 123, 0, 0, None, None, stream())
+                              ptr(rstd), ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, 1024, 32, 1, 0.9, 123, 0, 0, None, None, None, None, None, stream())
             t = timeit(fb, a.reps)
             by = 3.0 * B * 1024 * (C1 + C2) * 4
             print(f"groupnorm_bwd C={C1}+{C2} keep=0.9: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s algorithmic (x, dy -> dx)")
