@@ -98,6 +98,9 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
     _lib = lib
+    for kv in filter(None, os.environ.get("MULAN_TUNE", "").split(",")):   # developer knobs, e.g. MULAN_TUNE=8=1
+        k, v = kv.split("=")
+        lib.mulan_set_tuning(int(k), int(v))
     return lib
 
 
