@@ -295,11 +295,19 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
 // split-K plan: only when the output has too few tiles to fill the chip and K is long
 int plan_ksplit(int M, int N, int K, int batch, int* kchunk) {
   *kchunk = K;
-  if (batch != 1 || K < 4096) return 1;
+  if (batch != 1) return 1;
   const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
-  if (tiles >= 256) return 1;
-  int s = (int)(512 / tiles);
-  if (s > K / 512) s = K / 512;
+  int s;
+  if (K >= 4096) {
+    if (tiles >= 256) return 1;
+    s = (int)(512 / tiles);
+    if (s > K / 512) s = K / 512;
+  } else {
+    // a handful of tiles with a few hundred k steps each (the [B,512] x [512,128] FiLM projections of every
+    // ResnetBlock) would run as one latency-bound wavefront per tile: cut K into 64-deep pieces
+    if (tiles > 8 || K < 256) return 1;
+    s = K / 64;
+  }
   if (s < 2) return 1;
   int kc = ((K + s - 1) / s + 15) / 16 * 16;
   *kchunk = kc;

@@ -265,7 +265,7 @@ def gemm_raw(A, Bm, M, N, K, *, bias=None, R=None, transA=False, transB=False, a
     if out is None:
         out = torch.empty((batch, M, N) if batch > 1 else (M, N), device=A.device, dtype=torch.float32)
     ws = None
-    if batch == 1 and K >= 4096:
+    if batch == 1 and K >= 256:
         nbytes = lib.load().mulan_gemm_workspace(M, N, K, batch)
         if nbytes:
             ws = torch.empty(nbytes // 4, device=A.device, dtype=torch.float32)
