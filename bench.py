@@ -246,8 +246,9 @@ def main():
                      "accumulate (error vs fp64 equal to the fp32 MFMA kernel's; the float32 matmul precision the "
                      "reference requests, ldm/main.py:39)",
             "f32": ": exact fp32 MFMA"}.get(ops.CONV_MODE, ""),
-        "config": {"workload": f"MuLAN ({a.vdm_type}) CIFAR-10 config ldm/configs/cifar10-conditioned.py, full train "
-                               f"step (fwd+bwd+all-reduce+AdamW/EMA), batch {B}/GPU",
+        "config": {"workload": f"MuLAN ({a.vdm_type}) config ldm/configs/{os.path.basename(a.config)} "
+                               f"(E={config.model.sm_n_embd}, {config.model.sm_n_layer}+2+{config.model.sm_n_layer + 1} "
+                               f"ResnetBlocks), full train step (fwd+bwd+all-reduce+AdamW/EMA), batch {B}/GPU",
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
         "model_tflops_per_gpu": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3, 2),
         "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 /
