@@ -23,6 +23,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (~2.5 PF)
 FWD_GFLOP_PER_IMAGE = 57.78           # score 53.37 + encoder 4.33 + gamma 0.076 (CIFAR config)
+FWD_GFLOP_BY_WIDTH = {128: 57.78, 256: 228.58}   # CIFAR config / ImageNet-32 config
 
 
 def parse():
@@ -236,6 +237,7 @@ def main():
             cpu = {"value": None, "error": f"cpu baseline exceeded {a.cpu_timeout}s"}
     ms = elapsed / a.steps * 1e3
     value = B * world * a.steps / elapsed
+    FWD_GFLOP_PER_IMAGE = FWD_GFLOP_BY_WIDTH.get(int(config.model.sm_n_embd), 57.78)
     out = {
         "metric": "train images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
