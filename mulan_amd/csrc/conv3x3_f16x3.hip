@@ -321,7 +321,6 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   const int n0 = blockIdx.y * BN;
   const int C = p.C, N = p.N;
   const int nchunks = C / CK;
-  const float* xb = p.x + (size_t)b * p.H * kW * C;
   float sx, inv_x, sw, inv_w;
   scale_of(row_max16(p.xmax, b), sx, inv_x);
   scale_of(row_max16(p.wmax, 0), sw, inv_w);
@@ -334,10 +333,15 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const float* pptr[PV];
+  // Global operands go through buffer descriptors: per-stage offsets are formed on the scalar unit (soffset) instead
+  // of 64-bit vector address arithmetic, and halo / out-of-image slots simply read zeros (offset 2^31 is out of range).
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)((size_t)p.B * p.H * kW * C * 4), kBufWord3);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(p.wp), 0, 9 * C * N * 4, kBufWord3);
+  unsigned poff[PV];
   int pdst[PV];
   unsigned pemit[PV];
-  unsigned phalo = 0;
 #pragma unroll
   for (int s = 0; s < PV; ++s) {
     const int slot = tid + s * 256;
@@ -346,9 +350,8 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
     const int hh = h0 + prow - 1, ww = pcol - 1;
     const bool inb = slot < (TR2 + 2) * kPW * 4;
     const bool ok = inb && hh >= 0 && hh < p.H && ww >= 0 && ww < kW;
-    pptr[s] = ok ? xb + ((size_t)hh * kW + ww) * C + q * 4 : p.x;
+    poff[s] = ok ? (unsigned)((((b * p.H + hh) * kW + ww) * C + q * 4) * 4) : 0x80000000u;
     pdst[s] = inb ? pix * PIXB + q * 8 : -1;
-    phalo |= (ok ? 1u : 0u) << s;
     // byte offset of this slot's hi quad inside (image b, chunk 0) of the plane tensor; interior pixels only
     const bool interior = inb && prow >= 1 && prow <= TR2 && ww >= 0 && ww < kW;
     pemit[s] = interior ? (unsigned)(((hh * kW + ww) * 2) * 32 + q * 8) : 0xffffffffu;
@@ -356,18 +359,17 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
   // plane output window of this block: image b (nothing for the other cout blocks, or when not requested)
   const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       p.xs + (size_t)b * nchunks * 65536, 0, (p.xs && blockIdx.y == 0) ? nchunks * 65536 : 0, kBufWord3);
-  f32x4 preg[PV];
+  i32x4 preg[PV];
   auto gload_patch = [&](int cc) {
 #pragma unroll
-    for (int s = 0; s < PV; ++s) preg[s] = *reinterpret_cast<const f32x4*>(pptr[s] + (((phalo >> s) & 1u) ? cc * CK : 0));
+    for (int s = 0; s < PV; ++s) preg[s] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, poff[s], cc * CK * 4, 0);
   };
   // branch free (the loop body must stay one basic block so that this work can be scheduled between the MFMAs;
   // even a uniform condition in here makes the compiler branch): slots beyond the patch land in a dummy area behind
   // the two patches.  (During the last chunk the "next" patch is a harmless re-load of the current one: same data,
   // stored into the idle buffer and re-emitted to the same place.)
   auto store_slot = [&](unsigned char* pb, int s, int cc) {
-    f32x4 v = preg[s];
-    if (!((phalo >> s) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 v = __builtin_bit_cast(f32x4, preg[s]);
     f16x4 hi, lo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -388,14 +390,14 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
     for (int s = 0; s < PV; ++s) store_slot(pb, s, cc);
   };
   // weight fragments: packed [tap][chunk][cout][plane][16 k] fp16; this lane's 8 k of cout (n0 + wn*64 + nt*32 + li)
-  const size_t tile_stride = (size_t)N * 64;
-  const unsigned char* bbase = p.wp + (size_t)(n0 + wn * 64 + li) * 64 + lh * 16;
+  const unsigned bvoff = (unsigned)((n0 + wn * 64 + li) * 64 + lh * 16);
   auto gload_b = [&](f16x8 (&bs)[NT][2], int cc, int tap) {
-    const unsigned char* t = bbase + ((size_t)tap * nchunks + cc) * tile_stride;
+    const int so = (tap * nchunks + cc) * N * 64;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) bs[nt][pl] = *reinterpret_cast<const f16x8*>(t + nt * 2048 + pl * 32);
+      for (int pl = 0; pl < 2; ++pl)
+        bs[nt][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wp_rsrc, bvoff + nt * 2048 + pl * 32, so, 0));
   };
   auto read_a = [&](f16x8 (&af)[MT][2], const unsigned char* pb, int tap) {
     const int kh = tap / 3, kw = tap - kh * 3;
