@@ -238,8 +238,8 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
     out = vdm.apply(params, torch.tensor(x).cuda(), None, torch.zeros(B, dtype=torch.uint8).cuda(), step=0, rngs=None,
                     deterministic=True, noise=noise)
     rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
-    assert rel(out.loss_recon.detach().cpu().numpy(), ref["loss_recon"].detach().numpy()) < 1e-4 * tol
-    assert rel(out.loss_klz.detach().cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-4 * tol
+    assert rel(out.loss_recon.detach().cpu().numpy(), ref["loss_recon"].detach().numpy()) < 1e-4
+    assert rel(out.loss_klz.detach().cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-4
     assert rel(out.loss_diff.detach().cpu().numpy(), ref["loss_diff"].detach().numpy()) < (2e-3 if T else 5e-4)
     r = 1.0 / (3072 * np.log(2.0))
     ((out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) * r).backward()
