@@ -63,9 +63,7 @@ class Experiment(abc.ABC):
         if ckpt_restore_dir != 'None':
             self.state = restore_partial(self.state, ckpt_lib.restore_dict(ckpt_restore_dir))
 
-        leaves = [(leaf, off, leaf.numel()) for (path, off, shape), (_, leaf) in
-                  zip(self.state.layout, tree_leaves_in_layout(self.state.params, self.state.layout))]
-        self.reducer = parallel.GradReducer(self.state.grad, leaves)
+        self.reducer = parallel.GradReducer(self.state.grad, self.state.reducer_leaves())
 
         self.rng, train_rng = self.rng.split()
         self._train_rng = train_rng

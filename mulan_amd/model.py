@@ -156,7 +156,7 @@ def resnet_block(p, x1, x2, cond, drop):
     """ResnetBlock.__call__ (ldm/model_vdm.py:618-657 / ldm/ldm_unet.py:18-61) on [x1|x2]."""
     # s1 / s2 alias x1 / x2 for the skip path: their gradients are added inside the GroupNorm backward kernel
     h, s1, s2 = ops.group_norm_skip(x1, x2, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
-    cb = ops.linear(cond, p["cond_proj"]["kernel"])          # [B,E] or [B,1024,E]
+    cb = ops.cond_proj(cond, p["cond_proj"]["kernel"])       # [B,E] or [B,1024,E]
     h = ops.conv3x3(h, p["conv1"]["kernel"], p["conv1"]["bias"], cbias=cb)
     keep, seed, off = drop.next()
     h = ops.group_norm(h, None, p["GroupNorm_1"]["scale"], p["GroupNorm_1"]["bias"], act=True, keep=keep, seed=seed,

@@ -441,6 +441,77 @@ def linear(x, w, bias=None, res=None):
     return LinearFn.apply(x, w, bias, res)
 
 
+class CondProjAllFn(torch.autograd.Function):
+    """outs[g] = cond @ W[g] for all G FiLM projections of a U-Net at once (cond_proj of every ResnetBlock,
+    ldm/model_vdm.py:639-641: they share their input): one batched GEMM forward, two backward, instead of three small
+    latency-bound GEMMs per block."""
+
+    @staticmethod
+    def forward(ctx, cond, W):
+        cond, W = _c(cond), _c(W)
+        G, K, N = W.shape
+        B = cond.shape[0]
+        out = gemm_raw(cond, W, B, N, K, batch=G, sA=0, sB=K * N)            # [G,B,N]
+        ctx.save_for_backward(cond, W)
+        ctx.gv = _gv(W)
+        return tuple(out[g] for g in range(G))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *douts):
+        cond, W = ctx.saved_tensors
+        G, K, N = W.shape
+        B = cond.shape[0]
+        zero = None
+        parts = []
+        for d in douts:
+            if d is None:
+                if zero is None:
+                    zero = torch.zeros((B, N), device=cond.device, dtype=torch.float32)
+                d = zero
+            parts.append(d)
+        dO = torch.stack(parts)                                              # [G,B,N]
+        dcond = dW = None
+        if ctx.needs_input_grad[0]:
+            dcond = gemm_raw(dO, W, B, K, N, transB=True, batch=G, sA=B * N, sB=K * N).sum(0)
+        if ctx.needs_input_grad[1]:
+            gvw = ctx.gv
+            dW = gemm_raw(cond, dO, K, N, B, transA=True, batch=G, sA=0, sB=B * N,
+                          out=_fresh(gvw) if gvw is not None else None)
+        return dcond, dW
+
+
+class CondProjGroup:
+    """The strided super-parameter [G,K,N] over G back-to-back cond_proj kernels (TrainState lays them out that way)
+    and the per-forward cache of their outputs."""
+
+    def __init__(self, weight):
+        self.weight = weight
+        self._cond = None
+        self._key = None
+        self._outs = None
+
+    def outputs(self, cond):
+        import weakref
+        key = (cond._version, torch.is_grad_enabled())
+        if self._cond is None or self._cond() is not cond or self._key != key:
+            self._outs = CondProjAllFn.apply(cond, self.weight)
+            self._cond, self._key = weakref.ref(cond), key
+        return self._outs
+
+
+GROUP_COND_PROJ = _os.environ.get("MULAN_GROUP_COND_PROJ", "1") == "1"
+
+
+def cond_proj(cond, w):
+    """cond @ w for a ResnetBlock's FiLM projection; grouped over all blocks of the U-Net when the parameters come
+    from a TrainState (per-sample conditioning only; the per-pixel ldm variant is an ordinary per-pixel dense layer)"""
+    grp = getattr(w, "_group", None)
+    if grp is None or cond.dim() != 2 or not GROUP_COND_PROJ:
+        return linear(cond, w)
+    return grp[0].outputs(cond)[grp[1]]
+
+
 class Linear2Fn(torch.autograd.Function):
     """y = [x1 | x2] @ w + bias over a virtual channel concat (nin_shortcut on concat[h, skip],
     ldm/model_vdm.py:369,652-653) without materialising the concat."""

@@ -25,6 +25,9 @@ class TrainState:
             assert path[0] in {'encoder_model', 'score_model', 'gamma'}, path
         decayed = [(p, v) for p, v in leaves if _is_decayed(p)]
         plain = [(p, v) for p, v in leaves if not _is_decayed(p)]
+        # the FiLM projection kernels (cond_proj) of one U-Net share their input: they are laid out back to back so
+        # that one strided view [G, K, N] over the flat buffers serves a single batched GEMM (ops.cond_proj)
+        decayed.sort(key=lambda pv: (0, pv[0][0]) if pv[0][-2:] == ('cond_proj', 'kernel') else (1, ''))
         self.layout = []   # (path, offset, shape)
         off = 0
         self.n_decay = 0
@@ -61,6 +64,45 @@ class TrainState:
             # (mulan_amd.ops reads `_gview`), autograd then adopts the view as .grad without an extra add
             leaf._gview = self.grad[off_:off_ + n].view(shape)
             self._leaves.append(leaf)
+        self._build_groups()
+
+    def _build_groups(self):
+        """one strided super-parameter per run of equally shaped, contiguous cond_proj kernels (see __init__)"""
+        self._supers = []
+        run = []
+
+        def flush():
+            if len(run) >= 2:
+                (path0, off0, shape), _ = run[0]
+                G, n = len(run), run[0][1].numel()
+                w = self.flat[off0:off0 + G * n].view(G, *shape).detach().requires_grad_(True)
+                w._gview = self.grad[off0:off0 + G * n].view(G, *shape)
+                grp = ops.CondProjGroup(w)
+                for i, (_, leaf) in enumerate(run):
+                    leaf._group = (grp, i)
+                self._supers.append((w, off0, G * n, [leaf for _, leaf in run]))
+            run.clear()
+
+        for entry, leaf in zip(self.layout, self._leaves):
+            path, off_, shape = entry
+            ok = path[-2:] == ('cond_proj', 'kernel') and leaf.numel() % 4 == 0
+            if ok and run and (run[-1][0][0][0] != path[0] or run[-1][0][2] != shape or
+                               run[-1][0][1] + run[-1][1].numel() != off_):
+                flush()
+            if ok:
+                run.append((entry, leaf))
+            else:
+                flush()
+        flush()
+
+    def reducer_leaves(self):
+        """(tensor, offset, numel) per gradient-carrying tensor for parallel.GradReducer: grouped leaves are
+        represented by their super-parameter (that is where autograd delivers their gradient)"""
+        grouped = {id(l): None for _, _, _, ls in self._supers for l in ls}
+        out = [(leaf, off, leaf.numel()) for (path, off, shape), leaf in zip(self.layout, self._leaves)
+               if id(leaf) not in grouped]
+        out += [(w, off0, n) for w, off0, n, _ in self._supers]
+        return out
 
     @classmethod
     def create(cls, *, apply_fn, variables, device, optimizer_args=None):
@@ -97,14 +139,19 @@ class TrainState:
         self.grad.zero_()
         for leaf in self._leaves:
             leaf.grad = None
+        for w, _, _, _ in self._supers:
+            w.grad = None
 
     def collect_grads(self):
         """Call after backward: any gradient that did not land in the flat buffer (ops without a sink, or a
         copy made by autograd) is copied in, so `self.grad` is complete for the all-reduce / optimizer."""
-        for leaf in self._leaves:
+        for leaf in self._leaves + [w for w, _, _, _ in self._supers]:
             g = leaf.grad
             if g is not None and g.data_ptr() != leaf._gview.data_ptr():
-                leaf._gview.copy_(g)
+                if getattr(leaf, "_group", None) is not None:      # a grouped leaf used on its own as well
+                    leaf._gview.add_(g)
+                else:
+                    leaf._gview.copy_(g)
                 leaf.grad = leaf._gview
 
     def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0):

@@ -287,11 +287,16 @@ def test_gradient_sink_equals_autograd_accumulation():
     """The backward kernels write parameter gradients straight into TrainState's flat buffer (`_gview` sink);
     the result must equal ordinary autograd accumulation bit for bit, and .grad must alias the flat buffer."""
     from mulan_amd import model as M
+    from mulan_amd import ops as _ops
     from mulan_amd.rng import PRNGKey
     from mulan_amd.train_state import TrainState
     cfg, _ = make_cfg()
     vdm = M.make_vdm("mulan_velocity", cfg)
     st = TrainState.create(apply_fn=vdm.apply, variables={"params": vdm.init(PRNGKey(3))}, device=torch.device("cuda"))
+    # this test is about the per-leaf sink; the grouped FiLM projections (one super-parameter per U-Net, different
+    # summation order for d cond) have their own test below
+    saved_group = _ops.GROUP_COND_PROJ
+    _ops.GROUP_COND_PROJ = False
     with torch.no_grad():   # un-zero the zero-initialised tensors so every gradient is non-trivial
         st.flat.add_(0.01 * torch.randn(st.flat.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(0)))
         st.params["score_model"]["conv_in"]["kernel"][:, :, 15, :] = 0
@@ -317,8 +322,11 @@ def test_gradient_sink_equals_autograd_accumulation():
             leaf._gview = leaf._saved_gview
         return flat, 0
 
-    g_sink, aliased = grads(True)
-    g_ref, _ = grads(False)
+    try:
+        g_sink, aliased = grads(True)
+        g_ref, _ = grads(False)
+    finally:
+        _ops.GROUP_COND_PROJ = saved_group
     assert torch.equal(g_sink, g_ref)
     assert aliased >= 0.9 * len(st._leaves), (aliased, len(st._leaves))   # autograd adopted the flat views
 
@@ -355,3 +363,43 @@ def test_imagenet32_width_train_parity():
     """E = 256 (ldm/configs/imagenet32.py): 256 / 512-channel convolutions, GroupNorm over 512 concatenated channels,
     two cout blocks per convolution tile, four weight-gradient tiles -- same parity bars as the CIFAR width"""
     run_case("mulan_velocity", "vdm", True, train=True, E=256, tol=3.0)
+
+
+def test_grouped_film_projections_match_per_block_gemms():
+    """TrainState lays the cond_proj kernels of a U-Net back to back; ops.cond_proj then serves all blocks from one
+    batched GEMM (forward and both gradients).  Values and every gradient in the flat buffer equal the per-block path."""
+    from mulan_amd import ops
+    from mulan_amd.train_state import TrainState
+    ops.lib.load()
+    g = torch.Generator().manual_seed(2)
+    blk = lambda: {"cond_proj": {"kernel": torch.randn(512, 128, generator=g) * 0.05},
+                   "conv1": {"kernel": torch.randn(3, 3, 16, 16, generator=g), "bias": torch.randn(16, generator=g)}}
+    tree = {"score_model": {f"down.block_{i}": blk() for i in range(3)},
+            "encoder_model": {f"down.block_{i}": blk() for i in range(2)},
+            "gamma": {"dense": {"kernel": torch.randn(8, 8, generator=g)}}}
+    cond = torch.randn(4, 512, generator=g).cuda()
+    gout = [torch.randn(4, 128, generator=g).cuda() for _ in range(5)]
+    results = {}
+    for grouped in (True, False):
+        ops.GROUP_COND_PROJ = grouped
+        st = TrainState.create(apply_fn=None, variables={"params": tree}, device="cuda")
+        assert len(st._supers) == 2 and sorted(w.shape[0] for w, _, _, _ in st._supers) == [2, 3]
+        c = cond.clone().requires_grad_(True)
+        st.zero_grad()
+        outs, k = [], 0
+        for mod, n in (("score_model", 3), ("encoder_model", 2)):
+            for i in range(n):
+                if (mod, i) == ("score_model", 1):
+                    continue                              # an unused block: its gradient must come out as zero
+                outs.append((ops.cond_proj(c, st.params[mod][f"down.block_{i}"]["cond_proj"]["kernel"]), gout[k]))
+                k += 1
+        loss = sum((o * go).sum() for o, go in outs)
+        loss.backward()
+        st.collect_grads()
+        results[grouped] = ([o.detach().clone() for o, _ in outs], c.grad.clone(), st.grad.clone())
+    ops.GROUP_COND_PROJ = True
+    for a, b in zip(results[True][0], results[False][0]):        # (the per-block path sums K = 512 in 8 split-K pieces)
+        assert float((a - b).abs().max()) < 1e-5 * float(b.abs().max())
+    assert float((results[True][1] - results[False][1]).abs().max()) < 1e-5 * float(results[False][1].abs().max())
+    assert float((results[True][2] - results[False][2]).abs().max()) < 1e-5 * float(results[False][2].abs().max())
+    assert float(results[True][2].abs().max()) > 0
