@@ -293,14 +293,19 @@ __global__ void splitk_reduce_kernel(GemmArgs p) {
 }
 
 // split-K plan: only when the output has too few tiles to fill the chip and K is long
+// long-K products whose output is a whole number of 128 x 128 tiles use those (each operand element is fetched once
+// per tile row / column instead of twice with 64 x 64 tiles): the dense weight gradients [128 x 131072] x [131072 x 128]
+bool ksplit_big_tile(int M, int N, int K) { return K >= 4096 && M % 128 == 0 && N % 128 == 0; }
+
 int plan_ksplit(int M, int N, int K, int batch, int* kchunk) {
   *kchunk = K;
   if (batch != 1) return 1;
-  const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+  const bool big = ksplit_big_tile(M, N, K);
+  const long long tiles = big ? (long long)(M / 128) * (N / 128) : (long long)((M + 63) / 64) * ((N + 63) / 64);
   int s;
   if (K >= 4096) {
     if (tiles >= 256) return 1;
-    s = (int)(512 / tiles);
+    s = (int)((big ? 256 : 512) / tiles);
     if (s > K / 512) s = K / 512;
   } else {
     // a handful of tiles with a few hundred k steps each (the [B,512] x [512,128] FiLM projections of every
@@ -351,7 +356,8 @@ MULAN_API int mulan_gemm(const float* A, const float* B, float* C, const float* 
     const int s = plan_ksplit(M, N, K, batch, &kc);
     if (s > 1) {
       a.ksplit = s; a.kchunk = kc; a.ws = workspace;
-      launch<64, 64, 2, 2>(a, transA, transB, vec, s, stream);
+      if (ksplit_big_tile(M, N, K)) launch<128, 128, 2, 2>(a, transA, transB, vec, s, stream);
+      else launch<64, 64, 2, 2>(a, transA, transB, vec, s, stream);
       const size_t E = (size_t)M * N;
       const int blocks = (int)((E + 255) / 256 > 2048 ? 2048 : (E + 255) / 256);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
