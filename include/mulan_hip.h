@@ -159,6 +159,8 @@ int mulan_act_bwd(const float* x, const float* dy, float* dx, size_t n, int kind
 /* out[s][c] (+)= sum_{r<seg} x[s*seg + r][c]  (bias and per-sample cond-bias gradients) */
 int mulan_colsum(const float* x, float* out, int nseg, int seg, int C, int ld, int accumulate,
                  mulan_stream_t stream);
+/* the two column sums of x [2, seg, C] in one launch, each to its own destination (GroupNorm dgamma / dbeta) */
+int mulan_colsum_pair(const float* x, float* out0, float* out1, int seg, int C, mulan_stream_t stream);
 /* row softmax of the attention weights (model_vdm.py:786) and its backward */
 int mulan_softmax_fwd(const float* x, float* y, size_t rows, int cols, mulan_stream_t stream);
 int mulan_softmax_bwd(const float* p, const float* dp, float* ds, size_t rows, int cols, mulan_stream_t stream);

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 // Same reduction for C % 4 == 0 and 16-byte aligned rows: block = 16 row-lanes x 16 float4 columns,
 // 8 independent 16-byte loads in flight per thread.
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int seg,
-                                                         int C, int ld, int accumulate) {
+                                                         int C, int ld, int accumulate, float* __restrict__ out1) {
   __shared__ f32x4 red[256];
   const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int col = blockIdx.y * 64 + cq * 4;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
   }
   if (rl == 0 && col < C) {
     f32x4 v = red[threadIdx.x];
-    float* o = out + (size_t)s * C + col;
+    float* o = (out1 && s == 1 ? out1 : out + (size_t)s * C) + col;   // out1: segment 1 has its own destination
     if (accumulate) { v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
     *reinterpret_cast<f32x4*>(o) = v;
   }
@@ -270,9 +270,18 @@ MULAN_API int mulan_colsum(const float* x, float* out, int nseg, int seg, int C,
                    ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
   if (vec)
     hipLaunchKernelGGL(colsum_vec_kernel, dim3(nseg, (C + 63) / 64), dim3(256), 0, stream, x, out, seg, C, ld,
-                       accumulate);
+                       accumulate, static_cast<float*>(nullptr));
   else
     hipLaunchKernelGGL(colsum_kernel, dim3(nseg, (C + 63) / 64), dim3(256), 0, stream, x, out, seg, C, ld, accumulate);
+  MULAN_CHECK_LAUNCH();
+}
+// Two column sums in one launch: out0[c] = sum_r x[0][r][c], out1[c] = sum_r x[1][r][c] for x [2, seg, C]
+// (the dgamma / dbeta partials of a GroupNorm backward, whose destinations are far apart in the flat gradient buffer).
+MULAN_API int mulan_colsum_pair(const float* x, float* out0, float* out1, int seg, int C, hipStream_t stream) {
+  if (seg <= 0 || C <= 0 || C % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out0) & 15) ||
+      (reinterpret_cast<uintptr_t>(out1) & 15))
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(colsum_vec_kernel, dim3(2, (C + 63) / 64), dim3(256), 0, stream, x, out0, seg, C, C, 0, out1);
   MULAN_CHECK_LAUNCH();
 }
 MULAN_API int mulan_softmax_fwd(const float* x, float* y, size_t rows, int cols, hipStream_t stream) {

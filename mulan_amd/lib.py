@@ -45,6 +45,7 @@ SIGNATURES = {
     "mulan_act_fwd": [P, P, Z, I, F, P],
     "mulan_act_bwd": [P, P, P, Z, I, P],
     "mulan_colsum": [P, P, I, I, I, I, I, P],
+    "mulan_colsum_pair": [P, P, P, I, I, P],
     "mulan_softmax_fwd": [P, P, Z, I, P],
     "mulan_softmax_bwd": [P, P, P, Z, I, P],
     "mulan_fourier_fwd": [P, P, Z, P],

@@ -346,6 +346,10 @@ class Conv3x3Fn(torch.autograd.Function):
                 else colsum_raw(dy, B, HW, N)              # [B,N]
         if has_bias and ctx.needs_input_grad[2]:
             dbias = colsum_raw(per_sample, 1, B, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
+            try:       # the shortcut layer that shares this dy (nin_shortcut + bias) needs the very same column sum
+                dy._biasgrad = (dbias, dy._version)
+            except (AttributeError, RuntimeError):
+                pass
         if cb_dim is not None and ctx.needs_input_grad[3]:
             dcb = per_sample if cb_dim == 2 else dy
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
@@ -357,6 +361,18 @@ def conv3x3(x, w, bias=None, cbias=None, res=None):
 
 
 # ----------------------------------------------------------------------------- dense
+def _dense_bias_grad(dy, M, N, gvb):
+    """sum of dy over all rows; re-used from the convolution that consumed the same dy when there is one"""
+    out = _fresh(gvb) if gvb is not None else None
+    c = getattr(dy, "_biasgrad", None)
+    if c is not None and c[1] == dy._version and c[0].numel() == N:
+        if out is None:
+            return c[0].view(N)
+        out.view(N).copy_(c[0].view(N))
+        return out.view(N)
+    return colsum_raw(dy.reshape(M, N), 1, M, N, out=out.view(1, N) if out is not None else None).view(N)
+
+
 def linear_fast_ok(x, K1, K2, N1, N2):
     """per-pixel dense layers go through the f16x3 kernel (linear_f16x3.hip) when the shapes are image shaped"""
     return (CONV_MODE == "f16x3" and x.dim() == 3 and x.shape[1] == HW and K1 % 32 == 0 and K2 % 32 == 0 and
@@ -432,7 +448,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = gemm_raw(x2, dy2, K, N, M, transA=True, out=_fresh(gvw) if gvw is not None else None)
         if has_bias and ctx.needs_input_grad[2]:
-            db = colsum_raw(dy2, 1, M, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
+            db = _dense_bias_grad(dy, M, N, gvb)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres
 
@@ -558,7 +574,7 @@ class Linear2Fn(torch.autograd.Function):
             gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])
         db = None
         if ctx.needs_input_grad[3]:
-            db = colsum_raw(dy2, 1, M, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
+            db = _dense_bias_grad(dy, M, N, gvb)
         return dx1, dx2, dw, db
 
 
@@ -627,13 +643,13 @@ def _gn_backward(ctx, dy, add1=None, add2=None):
     Ct = C1 + C2
     dx1 = torch.empty_like(x1)
     dx2 = torch.empty_like(x2) if x2 is not None else None
-    dgp = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
-    dbp = torch.empty_like(dgp)
+    parts = torch.empty((2, B, Ct), device=dy.device, dtype=torch.float32)     # dgamma / dbeta per-sample partials
+    dgp, dbp = parts[0], parts[1]
     f16 = CONV_MODE == "f16x3"
     m1 = torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32) if f16 and C1 // 32 <= MAX_PARTS else None
     m2 = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
           if f16 and x2 is not None and C2 // 32 <= MAX_PARTS else None)
-    csum = torch.empty((B, Ct), device=dy.device, dtype=torch.float32) if x2 is None else None
+    csum = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
     call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
          ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, ptr(m1), ptr(m2),
          ptr(_c(add1)), ptr(_c(add2)), ptr(csum), stream())
@@ -641,11 +657,15 @@ def _gn_backward(ctx, dy, add1=None, add2=None):
         dx1._absmax = (m1, dx1._version)
     if m2 is not None:
         dx2._absmax = (m2, dx2._version)
-    if csum is not None:
-        dx1._colsum = (csum, dx1._version)
+    dx1._colsum = (csum if x2 is None else csum[:, :C1].contiguous(), dx1._version)
     gvg, gvb = ctx.gv
-    dgamma = colsum_raw(dgp, 1, B, Ct, out=_fresh(gvg).view(1, Ct) if gvg is not None else None).view(Ct)
-    dbeta = colsum_raw(dbp, 1, B, Ct, out=_fresh(gvb).view(1, Ct) if gvb is not None else None).view(Ct)
+    dgamma = _fresh(gvg) if gvg is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
+    dbeta = _fresh(gvb) if gvb is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
+    if Ct % 4 == 0 and dgamma.data_ptr() % 16 == 0 and dbeta.data_ptr() % 16 == 0:
+        call("mulan_colsum_pair", ptr(parts), ptr(dgamma), ptr(dbeta), B, Ct, stream())     # both sums, one launch
+    else:
+        colsum_raw(dgp, 1, B, Ct, out=dgamma.view(1, Ct))
+        colsum_raw(dbp, 1, B, Ct, out=dbeta.view(1, Ct))
     return dx1, dx2, dgamma, dbeta
 
 
