@@ -16,6 +16,7 @@ All tensor math runs in libmulan_hip.so (mulan_amd.ops); there is no CPU path.
 """
 import dataclasses
 import math
+import numpy as np
 from typing import Any, Optional
 
 import torch
@@ -281,12 +282,14 @@ class _VDMBase:
         if not cfg.antithetic_time_sampling:
             raise NotImplementedError("antithetic_time_sampling=False")
         # t = mod(t0 + arange(0, 1, 1/B), 1)  (ldm/model_mulan_velocity.py:196-198), built in fp32 like jnp
-        t = torch.remainder(torch.tensor(float(t0), dtype=torch.float32) + torch.arange(B, dtype=torch.float32)
-                            * torch.tensor(1.0 / B, dtype=torch.float32), 1.0)
+        # (evaluated on the device: the same IEEE fp32 multiply / add / floor as on the host, and no blocking
+        # host-to-device copy, which would make the host wait for the whole previous step)
+        t = torch.remainder(torch.arange(B, dtype=torch.float32, device=device) * float(np.float32(1.0 / B))
+                            + float(np.float32(t0)), 1.0)
         T = cfg.sm_n_timesteps
         if T > 0:
             t = torch.ceil(t * T) / T
-        return t.to(device)
+        return t
 
     def __call__(self, params, *a, **kw):
         return self.apply(params, *a, **kw)
