@@ -245,8 +245,8 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     const int px = prow + 64 * i;
-    xh[i] = *reinterpret_cast<const f32x4*>(src + (size_t)px * ld);
-    gq[i] = *reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct);
+    xh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)px * ld));
+    gq[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct));
   }
   float s1 = 0.f, s2 = 0.f;
   f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
       o[0] += old[0]; o[1] += old[1]; o[2] += old[2]; o[3] += old[3];
     }
     if (addp) {
-      const f32x4 ad = *reinterpret_cast<const f32x4*>(addp + (size_t)px * ld);
+      const f32x4 ad = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(addp + (size_t)px * ld));
       o[0] += ad[0]; o[1] += ad[1]; o[2] += ad[2]; o[3] += ad[3];
     }
     *reinterpret_cast<f32x4*>(dp) = o;
