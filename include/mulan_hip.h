@@ -117,7 +117,15 @@ int mulan_linear_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int 
                             mulan_stream_t stream);
 int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1, int K2,
                        const void* wp, const unsigned* wmax, const float* bias, const float* res, float* y1, float* y2,
-                       int N1, int N2, int M, int rows_per_img, mulan_stream_t stream);
+                       void* xs, int N1, int N2, int M, int rows_per_img, mulan_stream_t stream);
+/* xs (optional, M (K1+K2) 4 bytes): the layer hands the split planes of [x1 | x2] on (scaled per image with the larger
+ * of the two maxima).  Its weight gradient dw[K1+K2, N] (+)= [x1|x2]^T dy then comes from those planes and the planes of
+ * dy handed on by the convolution that consumed the same dy (nin_shortcut and conv2 of a ResnetBlock share dy):
+ * H x W = 32 x 32 pixels per image; C = K1 + K2 and N multiples of 128; xmax = elementwise max of x1max, x2max. */
+size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N);
+int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
+                                    float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
+                                    mulan_stream_t stream);
 
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),

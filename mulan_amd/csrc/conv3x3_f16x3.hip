@@ -822,13 +822,18 @@ __device__ __forceinline__ int clamped_exp(unsigned maxbits) {
 }
 
 
+// TAPS = 3: one kernel row of a 3x3 convolution per block (blockIdx.y = kh).  TAPS = 1: a 1x1 "convolution", i.e. the
+// weight gradient x^T dy of a per-pixel dense layer (nin_shortcut) from the planes its forward kernel handed on: the
+// same block with only the centre tap.
+template <int TAPS>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradArgsP p) {
+  constexpr int NQ = 4 * TAPS;                   // stages per row pair: 4 k steps x TAPS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wci = wave >> 1, wco = wave & 1;
   const int C = p.C, N = p.N;
-  const int kh = blockIdx.y;
+  const int kh = TAPS == 3 ? blockIdx.y : 1;
   const int ntn = N / WG3_T;
   const int c0 = (blockIdx.z / ntn) * WG3_T, n0 = (blockIdx.z % ntn) * WG3_T;
   const int nchc = C / 16, nchn = N / 16;
@@ -837,9 +842,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
   const int pair_begin = (int)((long long)blockIdx.x * total_pairs / p.S);
   const int pair_end = (int)((long long)(blockIdx.x + 1) * total_pairs / p.S);
 
-  f32x16 acc[3][2][2];      // [kw][ci tile][co tile]
+  f32x16 acc[TAPS][2][2];   // [kw][ci tile][co tile]
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
       // Neighbouring images mostly share their exponents: nothing to do then.
       if (d != 0) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -962,12 +967,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) af[0][i][pl] = tr_read8h(xa + pl * X3_PLANE + i * X3_HALF);
+      for (int pl = 0; pl < 2; ++pl) af[0][i][pl] = tr_read8h(xa + pl * X3_PLANE + i * X3_HALF + (TAPS == 1 ? 64 : 0));
 #pragma unroll
-    for (int q = 0; q < 12; ++q) {                     // q = ks * 3 + kw; k step ks = 16 pixels of row rr = ks >> 1
-      const int ks = q / 3, kw = q - ks * 3;
-      if (q + 1 < 12) {                                // next stage's x fragments
-        const int ks1 = (q + 1) / 3, kw1 = (q + 1) - ks1 * 3;
+    for (int q = 0; q < NQ; ++q) {                     // q = ks * TAPS + tap; k step ks = 16 pixels of row rr = ks >> 1
+      const int ks = q / TAPS, kw = TAPS == 3 ? q - ks * 3 : 1, ti = TAPS == 3 ? kw : 0;
+      if (q + 1 < NQ) {                                // next stage's x fragments
+        const int ks1 = (q + 1) / TAPS, kw1 = TAPS == 3 ? (q + 1) - ks1 * 3 : 1;
         const int rr = ks1 >> 1, w0 = (ks1 & 1) * 16;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -975,7 +980,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
           for (int pl = 0; pl < 2; ++pl)
             af[(q + 1) & 1][i][pl] = tr_read8h(xa + pl * X3_PLANE + i * X3_HALF + (rr * kPW + w0 + kw1) * 64);
       }
-      if (kw == 1 && ks + 1 < 4) {                     // next k step's dy fragments
+      if ((TAPS == 1 || kw == 1) && ks + 1 < 4) {      // next k step's dy fragments
         const int rr = (ks + 1) >> 1, w0 = ((ks + 1) & 1) * 16;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -983,10 +988,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
           for (int pl = 0; pl < 2; ++pl)
             bfr[(ks + 1) & 1][j][pl] = tr_read8h(db + pl * D3_PLANE + j * D3_HALF + (rr * kW + w0) * 64);
       }
-      // staging: x unit q in stages 0..8, dy unit q - 4 in stages 4..11; each register is refilled at once with the
-      // same unit of pair p + 2
-      if (q < XV) { store_x(bn, q); gload_x1(pr2, q); }
-      if (q >= 4) { store_d(bn, q - 4); gload_d1(pr2, q - 4); }
+      // staging, each register refilled at once with the same unit of pair p + 2.  TAPS = 3: x unit q in stages
+      // 0..8, dy unit q - 4 in stages 4..11.  TAPS = 1 (4 stages): units q, q + 4, (q + 8).
+      if (TAPS == 3) {
+        if (q < XV) { store_x(bn, q); gload_x1(pr2, q); }
+        if (q >= 4) { store_d(bn, q - 4); gload_d1(pr2, q - 4); }
+      } else {
+#pragma unroll
+        for (int uu = q; uu < XV; uu += 4) { store_x(bn, uu); gload_x1(pr2, uu); }
+#pragma unroll
+        for (int uu = q; uu < DV; uu += 4) { store_d(bn, uu); gload_d1(pr2, uu); }
+      }
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
         constexpr int PA[3] = {1, 0, 0};
@@ -995,16 +1007,16 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[kw][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]],
-                                                                   acc[kw][i][j], 0, 0, 0);
+            acc[ti][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]],
+                                                                   acc[ti][i][j], 0, 0, 0);
       }
 #pragma unroll
       for (int g = 0; g < 12; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        if ((g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        if ((g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (TAPS == 1 || (g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (TAPS == 1 || (g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1016,8 +1028,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
   scale_of(row_max16(p.xmax, b_acc), sdummy, inv_x);
   scale_of(row_max16(p.dymax, b_acc), sdummy, inv_g);
   float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
+  const int ntaps = TAPS == 3 ? 9 : 1;
+  slab = p.slab + (size_t)blockIdx.x * ntaps * C * N;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
+  for (int kw = 0; kw < TAPS; ++kw)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1026,7 +1040,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = c0 + wci * 64 + i * 32 + mfma32_row(r, lane);
-          slab[((size_t)(kh * 3 + kw) * C + c) * N + n] = (acc[kw][i][j][r] * inv_x) * inv_g;
+          slab[((size_t)(TAPS == 3 ? kh * 3 + kw : 0) * C + c) * N + n] = (acc[kw][i][j][r] * inv_x) * inv_g;
         }
       }
   if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
@@ -1231,7 +1245,7 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
     return (int)hipErrorInvalidValue;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
     if (e != hipSuccess) return (int)e;
     configured = true;
@@ -1239,7 +1253,7 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
   const int S = wgrad_splits_p(B, H, C, N);
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
                B, H, C, N, S, g_mulan_debug_buffer};
-  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel, dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256), WG3_SMEM + 64,
+  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<3>, dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256), WG3_SMEM + 64,
                      stream, a);
   const int E = 9 * C * N;
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
@@ -1260,5 +1274,45 @@ MULAN_API int mulan_param_pack_f16x3(const float* flat, const long long* leaves,
   if (n <= 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(param_pack_kernel, dim3(n, 2, 16), dim3(256), 0, stream, flat, leaves, maxima,
                      static_cast<unsigned char*>(packed));
+  MULAN_CHECK_LAUNCH();
+}
+
+// ---- weight gradient of a per-pixel dense layer from split planes: dw[C, N] (+)= x^T dy, x planes [B][C/16][HW][2][16]
+// (handed on by mulan_linear_f16x3), dy planes [B][N/16][HW][2][16] (handed on by the convolution that consumed the same
+// dy); xmax / dymax are the per-image maxima the planes were scaled with.  Needs C % 128 == 0, N % 128 == 0.
+static int linear_wgrad_splits(int B, int H, int C, int N) {
+  const int tiles = (C / WG3_T) * (N / WG3_T);
+  const int pairs = B * (H / WG_ROWS);
+  int S = 240 / tiles;
+  if (S < 1) S = 1;
+  if (S > pairs) S = pairs;
+  return S;
+}
+
+MULAN_API size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N) {
+  if (W != kW || H % WG_ROWS != 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
+  return (size_t)linear_wgrad_splits(B, H, C, N) * C * N * sizeof(float);
+}
+
+MULAN_API int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys,
+                                              const unsigned* dymax, float* dw, float* workspace, int B, int H, int W,
+                                              int C, int N, int accumulate, hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0 || !xs || !dys || !xmax || !dymax ||
+      (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
+    return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int S = linear_wgrad_splits(B, H, C, N);
+  WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
+               B, H, C, N, S, g_mulan_debug_buffer};
+  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<1>, dim3(S, 1, (C / WG3_T) * (N / WG3_T)), dim3(256),
+                     WG3_SMEM + 64, stream, a);
+  const int E = C * N;
+  hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
   MULAN_CHECK_LAUNCH();
 }

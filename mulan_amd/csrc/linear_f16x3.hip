@@ -52,7 +52,11 @@ struct LinArgs {
   const float* bias; const float* res;         // bias [N]; res like y1 (single-output calls only)
   float* y1; float* y2;                        // [M, N1], [M, N2]
   int M, K1, K2, N1, N2, rows_per_img;
+  unsigned char* xs;                           // optional by-product: split planes of [x1 | x2], [B][K/16][rows][2][16] fp16
 };
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+constexpr int kBufWord3 = 0x00020000;          // raw buffer resource; out-of-range lanes are dropped
 
 __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
   constexpr int MT = 2, NT = 2;
@@ -89,7 +93,12 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) areg[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(32 * i) * ld);
   };
-  auto store_a = [&](unsigned char* buf) {
+  // plane output window: this block's image (only the first column block writes; nothing when not requested)
+  const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.xs + (size_t)b * (K / 16) * p.rows_per_img * 64, 0, (p.xs && blockIdx.y == 0) ? (K / 16) * p.rows_per_img * 64 : 0,
+      kBufWord3);
+  const int pix0 = r0 - b * p.rows_per_img + arow;
+  auto store_a = [&](unsigned char* buf, int s) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f16x4 hi, lo;
@@ -102,6 +111,10 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
       unsigned char* d = buf + (arow + 32 * i) * ROWB + aq * 8;
       *reinterpret_cast<f16x4*>(d) = hi;
       *reinterpret_cast<f16x4*>(d + 64) = lo;
+      // the same quads go to the plane tensor (consumed by the weight gradient of this layer)
+      const unsigned eo = (unsigned)((((2 * s + (aq >> 2)) * p.rows_per_img + pix0 + 32 * i) * 2) * 32 + (aq & 3) * 8);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), xs_rsrc, eo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo + 32, 0, 0);
     }
   };
   // weight fragments of a stage: [k step j][n tile][plane]
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
   gload_b(bcur, 0);
   for (int s = 0; s < nst; ++s) {
     unsigned char* buf = smem + (s & 1) * STAGE_B;
-    store_a(buf);
+    store_a(buf, s);
     __syncthreads();
     const bool more = s + 1 < nst;
     if (more) {
@@ -243,15 +256,19 @@ MULAN_API int mulan_linear_pack_f16x3(const float* w, void* wp, const unsigned* 
 // y[M, N1 | N2] = [x1 | x2][M, K1 + K2] @ W + bias + res.  Rows are pixels, rows_per_img per image; x1max / x2max are
 // the per-image maxima ([M / rows_per_img][16], mulan_absmax_rows format).  Needs M % 128 == 0, rows_per_img % 128 == 0,
 // K1 % 32 == 0, K2 % 32 == 0, N1 % 128 == 0, N2 % 128 == 0 (x2 / y2 optional: K2 = 0 / N2 = 0); res only with N2 = 0.
+// xs (optional, M * (K1 + K2) * 4 bytes): receives the split planes of [x1 | x2] (scaled with max(x1max, x2max) per
+// image), the input format of mulan_linear_wgrad_f16x3_planes.
 MULAN_API int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1,
                                  int K2, const void* wp, const unsigned* wmax, const float* bias, const float* res,
-                                 float* y1, float* y2, int N1, int N2, int M, int rows_per_img, hipStream_t stream) {
+                                 float* y1, float* y2, void* xs, int N1, int N2, int M, int rows_per_img,
+                                 hipStream_t stream) {
   if (M <= 0 || M % TM != 0 || rows_per_img <= 0 || rows_per_img % TM != 0 || M % rows_per_img != 0 || K1 <= 0 ||
       K1 % SK != 0 || K2 < 0 || K2 % SK != 0 || N1 <= 0 || N1 % TN != 0 || N2 < 0 || N2 % TN != 0 || !x1 || !x1max ||
       !wp || !wmax || !y1 || (K2 > 0 && (!x2 || !x2max)) || (N2 > 0 && (!y2 || res)))
     return (int)hipErrorInvalidValue;
+  if (xs && (size_t)M * (K1 + K2) * 4 >= 0x80000000ull) return (int)hipErrorInvalidValue;
   LinArgs a{x1, K2 > 0 ? x2 : nullptr, x1max, x2max, static_cast<const unsigned char*>(wp), wmax, bias, res, y1, y2,
-            M, K1, K2, N1, N2, rows_per_img};
+            M, K1, K2, N1, N2, rows_per_img, static_cast<unsigned char*>(xs)};
   hipLaunchKernelGGL(linear_f16x3_kernel, dim3(M / TM, (N1 + N2) / TN), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

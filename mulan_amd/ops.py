@@ -331,6 +331,10 @@ class Conv3x3Fn(torch.autograd.Function):
         dymax = cached_absmax(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
         if ctx.planes:                # x is the plane tensor here
             dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True, wmax=ctx.wmax)
+            try:       # the shortcut layer that shares this dy takes its weight gradient from the same planes
+                dy._planes = (dys, dymax, dy._version)
+            except (AttributeError, RuntimeError):
+                pass
             dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
                                           out=_fresh(gvw) if gvw is not None else None)
         else:
@@ -392,8 +396,10 @@ def linear_pack(w, transpose, wmax=None):
     return wp, wmax
 
 
-def linear_f16x3_raw(x1, x2, wp, wmax, N1, N2, bias=None, res=None):
-    """[x1 | x2] @ W + bias + res -> (y1 [B,1024,N1], y2 [B,1024,N2] or None); x* are [B,1024,K*] pixel tensors"""
+def linear_f16x3_raw(x1, x2, wp, wmax, N1, N2, bias=None, res=None, planes=False):
+    """[x1 | x2] @ W + bias + res -> (y1 [B,1024,N1], y2 [B,1024,N2] or None); x* are [B,1024,K*] pixel tensors.
+    planes=True: also returns (xs, xmax): the split planes of [x1 | x2] and the per-image maxima they were scaled with
+    (the input of linear_wgrad_planes_raw)."""
     B, K1 = x1.shape[0], x1.shape[-1]
     K2 = 0 if x2 is None else x2.shape[-1]
     M = B * HW
@@ -401,10 +407,25 @@ def linear_f16x3_raw(x1, x2, wp, wmax, N1, N2, bias=None, res=None):
     y2 = torch.empty((B, HW, N2), device=x1.device, dtype=torch.float32) if N2 else None
     m1 = cached_absmax(x1)
     m2 = cached_absmax(x2) if x2 is not None else None
+    xs = torch.empty(M * (K1 + K2) * 4, device=x1.device, dtype=torch.uint8) if planes else None
     _timed("linear_f16x3_kernel", 2.0 * M * (K1 + K2) * (N1 + N2),
            lambda: call("mulan_linear_f16x3", ptr(x1), ptr(m1), ptr(x2), ptr(m2), K1, K2, ptr(wp), ptr(wmax), ptr(bias),
-                        ptr(res), ptr(y1), ptr(y2), N1, N2, M, HW, stream()))
+                        ptr(res), ptr(y1), ptr(y2), ptr(xs), N1, N2, M, HW, stream()))
+    if planes:
+        return y1, y2, xs, (m1 if m2 is None else torch.maximum(m1, m2))
     return y1, y2
+
+
+def linear_wgrad_planes_raw(xs, xmax, dys, dymax, B, K, N, out=None):
+    """dw[K,N] = [x1|x2]^T dy from the planes handed on by linear_f16x3_raw (xs) and by the convolution that consumed
+    the same dy (dys)"""
+    nbytes = lib.load().mulan_linear_wgrad_f16x3_planes_workspace(B, H, W, K, N)
+    ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((K, N), device=xs.device, dtype=torch.float32)
+    _timed("linear_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * K * N,
+           lambda: call("mulan_linear_wgrad_f16x3_planes", ptr(xs), ptr(xmax), ptr(dys), ptr(dymax), ptr(dw), ptr(ws), B, H,
+                        W, K, N, 0, stream()))
+    return dw
 
 
 class LinearFn(torch.autograd.Function):
@@ -540,9 +561,14 @@ class Linear2Fn(torch.autograd.Function):
         M = a1.shape[0]
         ctx.fast = linear_fast_ok(x1, K1, K2, N, 0) and K1 % 128 == 0 and K2 % 128 == 0
         ctx.wmax = None
+        ctx.xs = None
         if ctx.fast:      # one pass over both inputs, no intermediate
             wp, ctx.wmax = linear_pack(w, False)
-            y = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias))[0].view(M, N)
+            if ctx.needs_input_grad[2] and (K1 + K2) % 128 == 0 and N % 128 == 0:
+                y, _, ctx.xs, ctx.xsmax = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias), planes=True)
+                y = y.view(M, N)
+            else:
+                y = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias))[0].view(M, N)
         else:
             y = gemm_raw(a1, w[:K1], M, N, K1, bias=_c(bias))
             y = gemm_raw(a2, w[K1:], M, N, K2, R=y, out=torch.empty_like(y))
@@ -570,8 +596,12 @@ class Linear2Fn(torch.autograd.Function):
         gvw, gvb = ctx.gv
         if ctx.needs_input_grad[2]:
             dw = _fresh(gvw) if gvw is not None else torch.empty_like(w)
-            gemm_raw(a1, dy2, K1, N, M, transA=True, out=dw[:K1])
-            gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])
+            pl = getattr(dy, "_planes", None)
+            if ctx.xs is not None and pl is not None and pl[2] == dy._version and pl[0].numel() == M * N * 4:
+                linear_wgrad_planes_raw(ctx.xs, ctx.xsmax, pl[0], pl[1], M // HW, K1 + K2, N, out=dw)
+            else:
+                gemm_raw(a1, dy2, K1, N, M, transA=True, out=dw[:K1])
+                gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])
         db = None
         if ctx.needs_input_grad[3]:
             db = _dense_bias_grad(dy, M, N, gvb)

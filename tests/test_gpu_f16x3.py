@@ -358,3 +358,36 @@ def test_group_norm_skip_adds_the_skip_gradient_in_kernel(ops):
             cs = dx1._colsum[0]
             refcs = dx1.double().sum(1)
             assert float((cs.double() - refcs).abs().max()) <= 2e-5 * float(dx1.abs().double().sum(1).max())
+
+
+@pytest.mark.parametrize("B,K1,K2,N", [(2, 128, 128, 128), (3, 128, 0, 128), (1, 256, 256, 256)])
+def test_f16x3_dense_weight_gradient_from_planes(ops, B, K1, K2, N):
+    """dw = [x1|x2]^T dy of a per-pixel dense layer from the planes handed on by its forward kernel and by the
+    convolution that consumed the same dy: bit exact on integers, fp32-level error on random data"""
+    rng = np.random.default_rng(B + K1 + K2 + N)
+    K = K1 + K2
+    for ints in (True, False):
+        if ints:
+            x = rng.integers(-3, 4, (B, 1024, K)).astype(np.float64)
+            x[0] *= 8.0
+            dy = rng.integers(-2, 3, (B, 1024, N)).astype(np.float64)
+        else:
+            x = rng.standard_normal((B, 1024, K)) * np.array([1.0, 1e-3, 50.0])[:B, None, None]
+            dy = rng.standard_normal((B, 1024, N)) * np.array([2.0, 30.0, 1e-2])[:B, None, None]
+        w = rng.integers(-2, 3, (K, N)).astype(np.float64)
+        x1d = dev(x[..., :K1])
+        x2d = dev(x[..., K1:]) if K2 else None
+        wp, wmax = ops.linear_pack(dev(w), False)
+        y, _, xs, xsmax = ops.linear_f16x3_raw(x1d, x2d, wp, wmax, N, 0, planes=True)
+        dyd = dev(dy)
+        dymax = ops.absmax_rows(dyd)
+        wc = dev(rng.integers(-1, 2, (3, 3, N, N)).astype(np.float64))           # any 3x3 conv whose dgrad hands dy's planes on
+        _, dys = ops.conv3x3_dgrad_raw(dyd, wc, dymax=dymax, planes=True)
+        dw = ops.linear_wgrad_planes_raw(xs, xsmax, dys, dymax, B, K, N).cpu().double().numpy()
+        f32 = lambda a: a.astype(np.float32).astype(np.float64)
+        ref = np.einsum("bpk,bpn->kn", f32(x), f32(dy))
+        if ints:
+            assert np.array_equal(dw, ref)
+        else:
+            mag = np.einsum("bpk,bpn->kn", np.abs(f32(x)), np.abs(f32(dy)))
+            assert float((np.abs(dw - ref) / mag).max()) < 3e-6
