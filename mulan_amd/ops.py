@@ -351,7 +351,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             dbias = colsum_raw(per_sample, 1, B, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
             try:       # the shortcut layer that shares this dy (nin_shortcut + bias) needs the very same column sum
-                dy._biasgrad = (dbias, dy._version)
+                dy._biasgrad = (dbias.view(N), dy._version)    # (a separate view object: autograd adopts `dbias` itself)
             except (AttributeError, RuntimeError):
                 pass
         if cb_dim is not None and ctx.needs_input_grad[3]:
