@@ -187,6 +187,21 @@ int mulan_rowbcast(const float* x, float* y, size_t rows, int cols, int rep, int
 int mulan_encode_u8(const unsigned char* x, float* f, size_t n, mulan_stream_t stream);
 int mulan_axpby(const float* x, float* y, size_t n, float a, float b, mulan_stream_t stream);
 
+/* ---- ancestral sampler ---------------------------------------------------------
+ * One reverse step of VDM.sample / conditional_sample (model_mulan_velocity.py:281-350, model_mulan_epsilon.py:377-437,
+ * model_vdm.py:182-210):  z_s = sqrt(a/b) (z_t - sigma_t c eps_hat) + sqrt((1-a) c) eps  with a = sigmoid(-g_s),
+ * b = sigmoid(-g_t), c = -expm1(g_s - g_t); mode 0: net is the velocity (eps_hat = net alpha_t + sigma_t z_t), mode 1:
+ * net is eps_hat, mode 2: net is x_hat (plain VDM reparam_type 'input': eps_hat = (z_t - alpha_t net) / sigma_t).
+ * gamma per element (g_per_sample = 0) or one value per g_per_sample consecutive elements. */
+int mulan_ancestral_step(const float* zt, const float* net, const float* gt, const float* gs, const float* eps,
+                         float* zs, size_t n, int mode, int g_per_sample, mulan_stream_t stream);
+/* VDM.generate_x with sample_softmax = False (model_mulan_velocity.py:352-368, model_vdm.py:212-227): argmax over the
+ * 256 decoder bins of EncDec.decode (model_vdm.py:282-296) at z_0 / sqrt(1 - sigmoid(g_0)). */
+int mulan_decode_argmax(const float* z0, const float* g0, unsigned char* out, size_t n, int g_per_sample,
+                        mulan_stream_t stream);
+/* out[r] = mean(x[r, :])  (VDM._get_score_model_gt, model_mulan_velocity.py:141-146) */
+int mulan_rowmean(const float* x, float* out, int rows, int cols, mulan_stream_t stream);
+
 /* ---- MuLAN closed-form terms; d must be 3072 ------------------------------------------------- */
 /* NoiseSchedule_polynomial_fixedend._eval_polynomial / _grad_t (model_mulan_epsilon.py:514-555).
  * g0, g1, gprime may be NULL. */

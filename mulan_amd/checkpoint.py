@@ -158,6 +158,16 @@ def save_flax(path, state_dict):
         f.write(msgpack.packb(state_dict, default=enc, use_bin_type=True, strict_types=True))
 
 
+# ------------------------------------------------------------------ image grids
+def generate_image_grids(images):
+    """utils.generate_image_grids (ldm/utils.py:101-122): floor(sqrt(B))^2 images tiled into one picture, each row
+    laid out right to left like the reference's hstack(...[::-1]); images uint8 [B, H, W, C] (tensor or array)"""
+    a = images.detach().cpu().numpy() if torch.is_tensor(images) else np.asarray(images)
+    n = int(np.floor(np.sqrt(a.shape[0])))
+    rows = [np.hstack([a[r * n + c] for c in range(n)][::-1]) for r in range(n)]
+    return np.vstack(rows)
+
+
 # ------------------------------------------------------------------ scalar logging
 class ScalarWriter:
     """CustomLoggingWriter look-alike (ldm/utils.py:168-202): one 'step,key=value,...' line per write."""
@@ -179,6 +189,17 @@ class ScalarWriter:
         if self.f:
             self.f.write(line + "\n")
             self.f.flush()
+
+    def write_images(self, step, images):
+        """one binary PPM per entry (the reference hands [1, H, W, 3] uint8 grids to the clu writers)"""
+        if not self.f:
+            return
+        for name, img in images.items():
+            a = np.asarray(img, dtype=np.uint8)
+            a = a.reshape(a.shape[-3:])                                   # [H, W, 3]
+            with open(os.path.join(os.path.dirname(self.f.name), f"{name}_{int(step):08d}.ppm"), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % (a.shape[1], a.shape[0]))
+                g.write(np.ascontiguousarray(a).tobytes())
 
     def close(self):
         if self.f:

@@ -69,6 +69,7 @@ class Experiment(abc.ABC):
         self._train_rng = train_rng
         self.rng, eval_rng, sample_rng = self.rng.split(3)
         self._eval_rng, self._sample_rng = eval_rng, sample_rng
+        self._sample_dummy = None
 
     # ---- schedules / optimiser ------------------------------------------------------------------
     def get_lr_schedule(self):
@@ -178,11 +179,29 @@ class Experiment(abc.ABC):
                     metrics = self.p_eval_step(state.ema_params, batch, eval_step)
                     eval_metrics.append({k: float(v) for k, v in metrics['scalars'].items()})
                 writer.write_scalars(step, {k: float(np.mean([m[k] for m in eval_metrics])) for k in eval_metrics[0]})
+                self._write_samples(writer, step, state.ema_params)          # ldm/experiment.py:287-289
             if step % config.steps_per_save == 0 or is_last_step:
                 if self.rank == 0:
                     ckpt_lib.save(checkpoint_dir, state.state_dict(), max_to_keep=100)
         writer.close()
         return state
+
+    def p_sample(self, params, T=None):
+        """self.p_sample of the reference (ldm/experiment.py:96-102): sample_fn on a batch shaped like one eval
+        micro-batch, samples of all ranks concatenated.  T: config.training.sample_timesteps, default 1000 like the
+        reference's hard-coded value; 0 disables sampling at evaluation points."""
+        if T is None:
+            T = int(self.config.training.get('sample_timesteps', 1000))
+        if T <= 0:
+            return None
+        if self._sample_dummy is None:
+            self._sample_dummy = torch.empty((self.eval_iter.local, 32, 32, 3), dtype=torch.uint8, device=self.device)
+        return self.sample_fn(dummy_inputs=self._sample_dummy, rng=self._sample_rng, params=params, T=T)
+
+    def _write_samples(self, writer, step, params):
+        samples = self.p_sample(params)
+        if samples is not None:
+            writer.write_images(step, {'samples': ckpt_lib.generate_image_grids(samples)[None]})
 
     def evaluate(self, logdir, checkpoint_dir):
         """Experiment.evaluate (ldm/experiment.py:296-332): num_steps_eval batches on the EMA parameters."""
@@ -197,6 +216,7 @@ class Experiment(abc.ABC):
         out = {k: float(np.mean([m[k] for m in eval_metrics])) for k in eval_metrics[0]}
         writer = ckpt_lib.ScalarWriter(os.path.join(logdir, 'eval') if self.rank == 0 else None)
         writer.write_scalars(step, out)
+        self._write_samples(writer, step, self.state.ema_params)             # ldm/experiment.py:328-332
         writer.close()
         return out
 
@@ -229,6 +249,31 @@ class Experiment_VDM(Experiment):
         metrics = {'scalars': scalar_dict, 'images': {'inputs': inputs['images']}}
         return bpd, metrics
 
-    def sample_fn(self, *, dummy_inputs, rng, params):
-        raise NotImplementedError("ancestral sampler (ldm/experiment_vdm.py:80-110) is outside the round-1 hot path "
-                                  "(SURVEY 8f rank 3)")
+    def sample_fn(self, *, dummy_inputs, rng, params, T=1000, gather=True):
+        """Experiment_VDM.sample_fn (ldm/experiment_vdm.py:80-110): z_T ~ sigma_prior N(0, I), T ancestral steps
+        (`model.sample`), `model.generate_x`; returns uint8 samples [B (* world), 32, 32, 3].  The noise stream is this
+        build's Philox, folded with the rank like the reference folds axis_index."""
+        rng = rng.fold_in(self.rank)
+        B = dummy_inputs.shape[0]
+        conditioning = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        rng, sample_rng = rng.split()
+        packer = None
+        if params is self.state.ema_params:
+            packer = self.state.param_packer("ema")
+        elif params is self.state.params:
+            packer = self.state.param_packer("params")
+        with torch.no_grad():
+            if packer is not None:
+                packer.refresh()                     # weights are constant over the T steps: prepare them once
+            try:
+                z = float(self.config.model.sigma_prior) * sample_rng.normal((B, 3072), self.device)
+                coeffs = None
+                if hasattr(self.model, "deterministic_embedding"):
+                    coeffs = self.model.sample_coefficients(params, self.model.deterministic_embedding(B, self.device))
+                for i in range(T):
+                    z = self.model.sample(params, i, T, z, conditioning, rng, coeffs)
+                samples = self.model.generate_x(params, z, coeffs)
+            finally:
+                if packer is not None:
+                    packer.invalidate()
+        return parallel.all_gather_tensor(samples) if gather else samples

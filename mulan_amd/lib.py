@@ -67,6 +67,9 @@ SIGNATURES = {
     "mulan_diffloss_bwd": [I, P, P, P, I, P, P, P, P, P, P, P, P, I, I, P],
     "mulan_topk_fwd": [P, P, P, P, P, P, I, I, I, F, P],
     "mulan_topk_bwd": [P, P, P, P, P, P, I, I, P],
+    "mulan_ancestral_step": [P, P, P, P, P, P, Z, I, I, P],
+    "mulan_decode_argmax": [P, P, P, Z, I, P],
+    "mulan_rowmean": [P, P, I, I, P],
     "mulan_adamw_ema_step": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P],
     "mulan_randn": [P, Z, U, U, P],
     "mulan_version": [],

@@ -375,9 +375,62 @@ class MulanVDM(_VDMBase):
         return out
 
 
+    # ---- ancestral sampler (ldm/model_mulan_velocity.py:270-368, ldm/model_mulan_epsilon.py:365-460) ----------
+    def deterministic_embedding(self, B, device):
+        """_get_deterministic_embedding for latent_type = topk: the first latent_k entries set"""
+        c = self.config
+        emb = torch.zeros((B, c.latent_size), device=device, dtype=torch.float32)
+        emb[:, :c.latent_k] = 1.0
+        return emb
+
+    def sample_coefficients(self, params, embedding):
+        """(a, b, c) of the per-pixel schedule for an embedding: constant over the T steps of a sampling run"""
+        with torch.no_grad():
+            return poly_coefficients(params["gamma"], embedding)
+
+    def _gamma_at(self, coeffs, t_value, B, device):
+        cfg = self.config
+        t = torch.full((B,), float(np.float32(t_value)), device=device, dtype=torch.float32)
+        _, _, gt, _ = ops.poly_gamma(coeffs[0], coeffs[1], coeffs[2], t, cfg.gamma_min, cfg.gamma_max)
+        return gt                                                          # [B, 3072]
+
+    def conditional_sample(self, params, i, T, z_t, embedding, conditioning, rng, coeffs=None):
+        """one reverse step t = (T-i)/T -> s = (T-i-1)/T given the latent embedding; z_t [B,32,32,3] (any layout with
+        B x 3072 elements); rng: Key, folded with i like the reference"""
+        cfg = self.config
+        with torch.no_grad():
+            B = z_t.shape[0]
+            z = z_t.reshape(B, D).contiguous()
+            eps = rng.fold_in(i).normal((B, D), z.device)
+            if coeffs is None:
+                coeffs = self.sample_coefficients(params, embedding)
+            g_t = self._gamma_at(coeffs, (T - i) / T, B, z.device)
+            g_s = self._gamma_at(coeffs, (T - i - 1) / T, B, z.device)
+            cond = embedding if cfg.z_conditioning else conditioning.reshape(B, 1).to(torch.float32)
+            g_in = g_t.view(B, HW, 3) if cfg.unet_type == 'ldm' else ops.rowmean(g_t)
+            net = score_unet(params["score_model"], cfg, z.view(B, HW, 3), g_in, cond, _Drop(None, 0.0)).reshape(B, D)
+            z_s = ops.ancestral_step(z, net, g_t, g_s, eps, 0 if self.parameterization == "velocity" else 1)
+        return z_s.view(z_t.shape)
+
+    def sample(self, params, i, T, z_t, conditioning, rng, coeffs=None):
+        emb = self.deterministic_embedding(z_t.shape[0], z_t.device)
+        return self.conditional_sample(params, i, T, z_t, emb, conditioning, rng, coeffs)
+
+    def generate_x(self, params, z_0, coeffs=None):
+        cfg = self.config
+        if cfg.sample_softmax:
+            raise NotImplementedError("sample_softmax=True (categorical sampling of the output bins)")
+        with torch.no_grad():
+            B = z_0.shape[0]
+            if coeffs is None:
+                coeffs = self.sample_coefficients(params, self.deterministic_embedding(B, z_0.device))
+            g_0 = self._gamma_at(coeffs, 0.0, B, z_0.device)
+            return ops.decode_argmax(z_0.reshape(B, D), g_0).view(B, 32, 32, 3)
+
+
 class PlainVDM(_VDMBase):
     """model_vdm.VDM (ldm/model_vdm.py:95-180): scalar noise schedule, epsilon prediction, T = 0 or T > 0
-    with reparam_type 'noise'.  gamma_type in {'fixed', 'learnable_scalar'}."""
+    with reparam_type 'noise' | 'input'.  gamma_type in {'fixed', 'learnable_scalar'}."""
 
     def __init__(self, config: VDMConfig):
         super().__init__(config)
@@ -387,6 +440,9 @@ class PlainVDM(_VDMBase):
                                       "ldm/model_vdm.py:101-108)")
         if config.unet_type != 'vdm':
             raise NotImplementedError("model_vdm.VDM always uses ScoreUNet")
+        if config.sm_n_timesteps > 0 and config.reparam_type not in ('noise', 'input'):
+            raise ValueError(f"model_vdm.VDM with T > 0 needs reparam_type noise | input, got {config.reparam_type} "
+                             "(the reference leaves loss_diff undefined there, ldm/model_vdm.py:166-169)")
 
     def init(self, rng: Key):
         c = self.config
@@ -421,9 +477,11 @@ class PlainVDM(_VDMBase):
         g1, _ = self._gamma(params, ones)
         gt, gp = self._gamma(params, t)
         T = cfg.sm_n_timesteps
-        if T > 0:   # ldm/model_vdm.py:162-170 ('noise' reparameterisation)
+        if T > 0:   # ldm/model_vdm.py:162-170
             gs, _ = self._gamma(params, t - 1.0 / T)
             gp = T * torch.expm1(gt - gs)
+            if cfg.reparam_type == 'input':
+                gp = gp * torch.exp(-gt)
         zt, gbar, loss_recon, loss_klz, v0, v1 = ops.qsample(x, g0.contiguous(), g1.contiguous(), gt.contiguous(),
                                                              noise["eps_0"], noise["eps"])
         drop_key = None if deterministic else (rngs or {}).get("dropout")
@@ -436,6 +494,37 @@ class PlainVDM(_VDMBase):
         if return_aux:
             return out, dict(zt=zt, net=net, gt=gt, gp=gp, t=t)
         return out
+
+
+def _plain_sample(self, params, i, T, z_t, conditioning, rng, coeffs=None):
+    """model_vdm.VDM.sample (ldm/model_vdm.py:182-210)"""
+    cfg = self.config
+    with torch.no_grad():
+        B = z_t.shape[0]
+        z = z_t.reshape(B, D).contiguous()
+        eps = rng.fold_in(i).normal((B, D), z.device)
+        ones = torch.ones(B, device=z.device)
+        g_t, _ = self._gamma(params, float(np.float32((T - i) / T)) * ones)
+        g_s, _ = self._gamma(params, float(np.float32((T - i - 1) / T)) * ones)
+        cond = conditioning.reshape(B, 1).to(torch.float32)
+        net = score_unet(params["score_model"], cfg, z.view(B, HW, 3), g_t.contiguous(), cond, _Drop(None, 0.0))
+        z_s = ops.ancestral_step(z, net.reshape(B, D), g_t.contiguous(), g_s.contiguous(), eps,
+                                 2 if cfg.reparam_type == 'input' else 1)
+    return z_s.view(z_t.shape)
+
+
+def _plain_generate_x(self, params, z_0, coeffs=None):
+    if self.config.sample_softmax:
+        raise NotImplementedError("sample_softmax=True (categorical sampling of the output bins)")
+    with torch.no_grad():
+        B = z_0.shape[0]
+        g_0, _ = self._gamma(params, torch.zeros(B, device=z_0.device))
+        return ops.decode_argmax(z_0.reshape(B, D), g_0.contiguous()).view(B, 32, 32, 3)
+
+
+PlainVDM.sample = _plain_sample
+PlainVDM.generate_x = _plain_generate_x
+PlainVDM.sample_coefficients = lambda self, params, embedding: None
 
 
 def make_vdm(vdm_type: str, config: VDMConfig):

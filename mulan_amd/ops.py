@@ -1063,3 +1063,32 @@ def topk_embedding(logits, gnoise, k, tau=10.0):
 def adamw_ema_step(p, g, m, v, ema, n_decay, lr, b1, b2, eps, wd, step, ema_rate, grad_scale=1.0):
     call("mulan_adamw_ema_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(lr),
          float(b1), float(b2), float(eps), float(wd), int(step), float(ema_rate), float(grad_scale), stream())
+
+
+# ----------------------------------------------------------------------------- ancestral sampler (eval only)
+def ancestral_step(zt, net, gt, gs, eps, mode):
+    """one reverse step z_t -> z_s (mulan_ancestral_step); mode 0: net is the velocity, 1: net is eps_hat; gt / gs per
+    element ([B,3072]) or per sample ([B])"""
+    zt, net, gt, gs, eps = _c(zt), _c(net), _c(gt), _c(gs), _c(eps)
+    zs = torch.empty_like(zt)
+    per = zt.numel() // gt.numel()
+    call("mulan_ancestral_step", ptr(zt), ptr(net), ptr(gt), ptr(gs), ptr(eps), ptr(zs), zt.numel(), int(mode),
+         0 if per == 1 else per, stream())
+    return zs
+
+
+def decode_argmax(z0, g0):
+    """uint8 argmax over the 256 decoder bins at z_0 / sqrt(1 - sigmoid(g_0)) (VDM.generate_x, sample_softmax=False)"""
+    z0, g0 = _c(z0), _c(g0)
+    out = torch.empty(z0.shape, device=z0.device, dtype=torch.uint8)
+    per = z0.numel() // g0.numel()
+    call("mulan_decode_argmax", ptr(z0), ptr(g0), ptr(out), z0.numel(), 0 if per == 1 else per, stream())
+    return out
+
+
+def rowmean(x):
+    x = _c(x)
+    rows = x.shape[0]
+    out = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("mulan_rowmean", ptr(x), ptr(out), rows, x.numel() // rows, stream())
+    return out

@@ -135,3 +135,13 @@ def allreduce_mean_scalars(values, device):
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     t = t / world_size()
     return {k: t[i] for i, k in enumerate(keys)}
+
+
+def all_gather_tensor(t):
+    """jax.lax.all_gather over the data-parallel axis (the sample grid at eval checkpoints, ldm/experiment.py:287):
+    [world * B, ...] on every rank"""
+    if world_size() == 1:
+        return t
+    out = [torch.empty_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t.contiguous())
+    return torch.cat(out, dim=0)

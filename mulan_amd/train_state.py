@@ -123,16 +123,19 @@ class TrainState:
             d[path[-1]] = v
         return tree
 
-    def param_packer(self):
-        """f16x3 mode: the once-per-step weight preparation of all eligible leaves (ops.ParamPacker), else None"""
+    def param_packer(self, which="params"):
+        """f16x3 mode: the once-per-step weight preparation of all eligible leaves (ops.ParamPacker), else None.
+        which = "params" (training) or "ema" (the tree evaluators / the sampler run on)"""
         from . import ops
         if ops.CONV_MODE != "f16x3" or not self.flat.is_cuda:
             return None
-        if getattr(self, "_packer", None) is None:
+        attr = "_packer" if which == "params" else "_packer_ema"
+        if getattr(self, attr, None) is None:
+            tree, flat = (self.params, self.flat) if which == "params" else (self.ema_params, self.ema)
             leaves = [(leaf, off) for (path, off, shape), (_, leaf) in
-                      zip(self.layout, tree_leaves_in_layout(self.params, self.layout))]
-            self._packer = ops.ParamPacker(self.flat, leaves)
-        return self._packer
+                      zip(self.layout, tree_leaves_in_layout(tree, self.layout))]
+            setattr(self, attr, ops.ParamPacker(flat, leaves))
+        return getattr(self, attr)
 
     def zero_grad(self):
         """Call before each backward: clears the flat buffer and detaches stale .grad handles."""

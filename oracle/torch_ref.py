@@ -225,6 +225,98 @@ def mulan_forward(params, cfg, x_u8, t0, raw_gamma, eps_0, eps, enc_masks=None, 
                 aux=dict(logits=logits, emb=emb, z_t=z_t, net=net, g_t=g_t, g_p=g_p))
 
 
+# ------------------------------------------------------------------------------ ancestral sampler
+def deterministic_embedding(B, latent_size, latent_k, dtype=torch.float64):
+    """VDM._get_deterministic_embedding, latent_type 'topk' (ldm/model_mulan_velocity.py:270-279)"""
+    return torch.cat([torch.ones(B, latent_k, dtype=dtype), torch.zeros(B, latent_size - latent_k, dtype=dtype)], dim=1)
+
+
+def ancestral_step(z_t, net, g_t, g_s, eps, kind):
+    """the closed-form part of VDM.sample (ldm/model_mulan_velocity.py:335-350 `velocity`, ldm/model_mulan_epsilon.py:
+    400-406 `epsilon`, ldm/model_vdm.py:197-210 `epsilon` / `input`); g broadcastable against z_t"""
+    a, b, c = torch.sigmoid(-g_s), torch.sigmoid(-g_t), -torch.expm1(g_s - g_t)
+    sigma_t, alpha_t = torch.sqrt(torch.sigmoid(g_t)), torch.sqrt(torch.sigmoid(-g_t))
+    if kind == "velocity":
+        eps_hat = net * alpha_t + sigma_t * z_t
+    elif kind == "input":
+        eps_hat = (z_t - alpha_t * net) / sigma_t
+    else:
+        eps_hat = net
+    return torch.sqrt(a / b) * (z_t - sigma_t * c * eps_hat) + torch.sqrt((1. - a) * c) * eps
+
+
+def decode_argmax(z_0, g_0):
+    """VDM.generate_x with sample_softmax False (ldm/model_mulan_velocity.py:352-368, ldm/model_vdm.py:212-227):
+    argmax of EncDec.decode (ldm/model_vdm.py:282-296) at z_0 / sqrt(1 - sigmoid(g_0))"""
+    z = z_0 / torch.sqrt(1. - torch.sigmoid(g_0))
+    vals = encode(torch.arange(256, dtype=z.dtype))
+    logits = -0.5 * torch.square((z[..., None] - vals) * torch.exp(-0.5 * g_0)[..., None])
+    return torch.argmax(torch.log_softmax(logits, dim=-1), dim=-1)
+
+
+def step_gain(g_t, g_s, kind):
+    """|d z_s / d net| of ancestral_step: how far an error of the network output is carried into z_s (test budgets)"""
+    a, b, c = torch.sigmoid(-g_s), torch.sigmoid(-g_t), -torch.expm1(g_s - g_t)
+    k = torch.sqrt(a / b) * torch.sqrt(torch.sigmoid(g_t)) * c
+    if kind == "velocity":
+        k = k * torch.sqrt(b)
+    elif kind == "input":
+        k = k * torch.sqrt(b) / torch.sqrt(torch.sigmoid(g_t))
+    return float(k.max())
+
+
+def mulan_sample_loop(params, cfg, z_init, eps_list, dtype=torch.float64, trajectory=False):
+    """Experiment_VDM.sample_fn (ldm/experiment_vdm.py:80-110) with T = len(eps_list) and the per-step noise given
+    (the reference draws it from fold_in(rng, i)): returns (z_0, uint8 samples) [+ per-step z_t, network output
+    scale x step_gain when trajectory=True]"""
+    B, T = z_init.shape[0], len(eps_list)
+    shp = (B, 32, 32, 3)
+    emb = deterministic_embedding(B, cfg.get("latent_size", 50), cfg["latent_k"], dtype)
+    a, b, c = poly_coefficients(emb, params["gamma"])
+    per_pixel = cfg.get("unet_type", "vdm") == "ldm"
+    kind = "velocity" if cfg["vdm_type"] == "mulan_velocity" else "epsilon"
+    z = z_init.reshape(shp).to(dtype)
+    traj, budget = [z], []
+    for i in range(T):
+        g_t = poly_gamma(a, b, c, torch.full((B,), (T - i) / T, dtype=dtype)).reshape(shp)
+        g_s = poly_gamma(a, b, c, torch.full((B,), (T - i - 1) / T, dtype=dtype)).reshape(shp)
+        g_in = g_t if per_pixel else g_t.reshape(B, -1).mean(dim=1)
+        net = score_unet(z, g_in, emb, params["score_model"], cfg["n_embd"], cfg["n_layer"], per_pixel)
+        z = ancestral_step(z, net, g_t, g_s, eps_list[i].reshape(shp).to(dtype), kind)
+        traj.append(z)
+        budget.append(step_gain(g_t, g_s, kind) * float(net.abs().max()))
+    g_0 = poly_gamma(a, b, c, torch.zeros(B, dtype=dtype)).reshape(shp)
+    if trajectory:
+        return z, decode_argmax(z, g_0), traj, budget
+    return z, decode_argmax(z, g_0)
+
+
+def plain_sample_loop(params, cfg, z_init, eps_list, gmin=GAMMA_MIN, gmax=GAMMA_MAX, dtype=torch.float64,
+                      trajectory=False):
+    """the same loop for model_vdm.VDM (ldm/model_vdm.py:182-227)"""
+    B, T = z_init.shape[0], len(eps_list)
+    shp = (B, 32, 32, 3)
+    if "gamma" in params:
+        w, b0 = torch.abs(params["gamma"]["w"]), params["gamma"]["b"]
+        gamma = lambda tt: (b0 + w * tt).reshape(())
+    else:
+        gamma = lambda tt: torch.tensor(gmin + (gmax - gmin) * tt, dtype=dtype)
+    z = z_init.reshape(shp).to(dtype)
+    kind = "input" if cfg.get("reparam_type") == "input" else "epsilon"
+    traj, budget = [z], []
+    for i in range(T):
+        g_t, g_s = gamma((T - i) / T), gamma((T - i - 1) / T)
+        net = score_unet(z, g_t * torch.ones(B, dtype=dtype), torch.zeros(B, 1, dtype=dtype), params["score_model"],
+                         cfg["n_embd"], cfg["n_layer"], gmin=gmin, gmax=gmax)
+        z = ancestral_step(z, net, g_t, g_s, eps_list[i].reshape(shp).to(dtype), kind)
+        traj.append(z)
+        budget.append(step_gain(g_t, g_s, kind) * float(net.abs().max()))
+    g_0 = gamma(0.) * torch.ones(shp, dtype=dtype)
+    if trajectory:
+        return z, decode_argmax(z, g_0), traj, budget
+    return z, decode_argmax(z, g_0)
+
+
 # ------------------------------------------------------------------------------ parameter trees
 def tree_map(fn, tree):
     return {k: tree_map(fn, v) if isinstance(v, dict) else fn(v) for k, v in tree.items()}

@@ -266,7 +266,7 @@ def test_cli_train_checkpoint_and_dense_eval(tmp_path):
               "--config.training.batch_size_train=4", "--config.training.batch_size_eval=2",
               "--config.training.substeps=1", "--config.training.num_steps_train=2", "--config.training.num_steps_eval=1",
               "--config.training.steps_per_logging=1", "--config.training.steps_per_eval=2",
-              "--config.training.steps_per_save=2"]
+              "--config.training.steps_per_save=2", "--config.training.sample_timesteps=3"]
     ldm.main.main(common + ["--config.data.dataset=synthetic", "--workdir=" + str(tmp_path / "run")])
     ckdirs = [os.path.join(dp, d) for dp, dn, _ in os.walk(tmp_path / "run") for d in dn if d == "checkpoints"]
     assert len(ckdirs) == 1 and ck.checkpoint_numbers(ckdirs[0]) == [1]

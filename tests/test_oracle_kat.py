@@ -179,3 +179,49 @@ def test_golden_tiny_model_fixture():
                          torch.tensor(z["eps_0"]), torch.tensor(z["eps"]))
     assert abs(float(r["bpd"]) - float(z["epsilon_bpd"])) < 1e-9 * abs(float(z["epsilon_bpd"]))
     assert np.allclose(r["loss_diff"].detach().numpy(), z["epsilon_diff"], rtol=1e-9)
+
+
+def test_ancestral_step_marginals_are_consistent():
+    """KAT for the sampler restatement: with the exact eps of z_t = alpha_t x + sigma_t eps the reverse step is
+    q(z_s | z_t, x): mean alpha_s x + (sigma_s^2 alpha_t / (alpha_s sigma_t)) eps, variance sigma_s^2 - that^2, so the
+    total noise variance of z_s is sigma_s^2 (variance-preserving marginals, VDM eq. 32-34); all three
+    parameterisations agree when each is handed its own exact target"""
+    rng = np.random.default_rng(0)
+    n = 4096
+    x, eps = torch.tensor(rng.uniform(-1, 1, n)), torch.tensor(rng.standard_normal(n))
+    g_t = torch.tensor(rng.uniform(-13.3, 5.0, n))
+    g_s = g_t - torch.tensor(rng.uniform(0.01, 2.0, n))
+    a_t, s_t = torch.sqrt(torch.sigmoid(-g_t)), torch.sqrt(torch.sigmoid(g_t))
+    a_s, s_s = torch.sqrt(torch.sigmoid(-g_s)), torch.sqrt(torch.sigmoid(g_s))
+    z_t = a_t * x + s_t * eps
+    zero, one = torch.zeros(n, dtype=torch.float64), torch.ones(n, dtype=torch.float64)
+    mean = tr.ancestral_step(z_t, eps, g_t, g_s, zero, "epsilon")
+    k = s_s ** 2 * a_t / (a_s * s_t)
+    assert torch.allclose(mean, a_s * x + k * eps, rtol=1e-9, atol=1e-12)
+    std = tr.ancestral_step(z_t, eps, g_t, g_s, one, "epsilon") - mean
+    assert torch.allclose(k ** 2 + std ** 2, s_s ** 2, rtol=1e-9, atol=1e-12)
+    v = a_t * eps - s_t * x                                           # velocity target (model_mulan_velocity.py:247)
+    assert torch.allclose(tr.ancestral_step(z_t, v, g_t, g_s, zero, "velocity"), mean, rtol=1e-8, atol=1e-10)
+    assert torch.allclose(tr.ancestral_step(z_t, x, g_t, g_s, zero, "input"), mean, rtol=1e-6, atol=1e-8)
+
+
+def test_decode_argmax_inverts_encode():
+    x = torch.arange(256).repeat(3, 1)
+    for g in (-13.3, -9.0, -5.0):
+        g0 = torch.full(x.shape, g, dtype=torch.float64)
+        z0 = tr.encode(x.double()) * torch.sqrt(torch.sigmoid(-g0))   # noise-free z_0 = alpha_0 f(x)
+        assert torch.equal(tr.decode_argmax(z0, g0), x)
+    assert torch.equal(tr.deterministic_embedding(2, 50, 15).sum(dim=1), torch.full((2,), 15.0, dtype=torch.float64))
+    assert torch.equal(tr.deterministic_embedding(2, 50, 15)[:, :15], torch.ones(2, 15, dtype=torch.float64))
+
+
+def test_sample_loop_runs_and_is_deterministic_given_noise():
+    cfg = dict(vdm_type='mulan_velocity', n_embd=32, n_layer=1, forward_n_layer=1, latent_k=15, unet_type='vdm')
+    P = tr.init_params(cfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 3072, generator=g, dtype=torch.float64)
+    eps = [torch.randn(1, 3072, generator=g, dtype=torch.float64) for _ in range(2)]
+    z0, x0 = tr.mulan_sample_loop(P, cfg, z, eps)
+    z1, x1 = tr.mulan_sample_loop(P, cfg, z, eps)
+    assert torch.equal(z0, z1) and torch.equal(x0, x1) and x0.shape == (1, 32, 32, 3)
+    assert int(x0.min()) >= 0 and int(x0.max()) <= 255 and torch.isfinite(z0).all()
