@@ -202,6 +202,42 @@ int mulan_decode_argmax(const float* z0, const float* g0, unsigned char* out, si
 /* out[r] = mean(x[r, :])  (VDM._get_score_model_gt, model_mulan_velocity.py:141-146) */
 int mulan_rowmean(const float* x, float* out, int rows, int cols, mulan_stream_t stream);
 
+/* ---- exact-likelihood ODE evaluator ------------------------------------------------
+ * Probability-flow drift of VDM.reverse_ode (model_mulan_velocity.py:393-421 modes 0 / 1 = velocity /
+ * velocity_from_epsilon, model_mulan_epsilon.py:459-478 and model_vdm.py:243-260 mode 2) from the network output, and
+ * the cotangent d(sum drift * hutch)/d net that the U-Net's input-gradient pass is fed for the Hutchinson estimator
+ * (notebook_utils._get_value_div_fn, :203-215).  cot / hutch may be NULL (drift only). */
+int mulan_ode_drift(const float* net, const float* x, const float* gt, const float* gp, const float* hutch, float* drift,
+                    float* cot, size_t n, int mode, int g_per_sample, mulan_stream_t stream);
+/* div[b] = sum_i (gx_i + diag_i hutch_i) hutch_i: gx = U-Net input gradient for `cot`, diag = the closed-form
+ * d drift_i / d x_i around the network. */
+int mulan_ode_div(const float* gx, const float* gt, const float* gp, const float* hutch, float* div, int B, int d,
+                  int mode, int g_per_sample, mulan_stream_t stream);
+/* Dormand-Prince RK45 pieces on a device-resident float64 state (replaces the host round trip per function
+ * evaluation of scipy.integrate.solve_ivp, notebook_utils.py:345-358).  K: up to 7 fp32 stage vectors, kstride
+ * elements apart; coef / e: host arrays.  out = y + h sum_j coef_j K_j (float64 and / or fp32). */
+int mulan_rk_combine(const double* y, const float* K, size_t kstride, const double* coef, int ncoef, double h,
+                     double* out, float* out32, size_t n, mulan_stream_t stream);
+size_t mulan_rk_workspace_bytes(void);
+/* out[0] = sum_i (h sum_j e_j K_j[i] / (atol + rtol max(|y_i|, |ynew_i|)))^2   (scipy's RK45 error norm, squared,
+ * not yet divided by n) */
+int mulan_rk_error_norm(const double* y, const double* ynew, const float* K, size_t kstride, const double* e, double h,
+                        double rtol, double atol, double* workspace, double* out, size_t n, mulan_stream_t stream);
+/* out3 = sums of (y0/scale)^2, (f0/scale)^2, ((f1-f0)/scale)^2 with scale = atol + rtol |y0| (scipy's
+ * select_initial_step); f1 may be NULL */
+int mulan_rk_init_norms(const double* y0, const float* f0, const float* f1, double rtol, double atol, double* workspace,
+                        double* out3, size_t n, mulan_stream_t stream);
+/* out[r] = log N(x[r, :]; 0, I)   (notebook_utils._prior_logp, :218-221) */
+int mulan_normal_logp(const float* x, float* out, int rows, int cols, mulan_stream_t stream);
+/* Philox4x32-10 draws: kind 0 U[0,1), 1 Rademacher +-1, 2 standard normal truncated to [lo, hi] (stand in for
+ * jax.random.uniform / randint / truncated_normal, notebook_utils.py:243-260, 318-330) */
+int mulan_noise(float* out, size_t n, unsigned long long seed, unsigned long long offset, int kind, float lo, float hi,
+                mulan_stream_t stream);
+/* data = encode(x) + noise (uniform: 2 (u - .5) / 256; else u * scale); requant = round(clip(128 (data + 1) - .5, 0,
+ * 255)) as the encoder's integer input (notebook_utils.py:316-337) */
+int mulan_dequantize(const unsigned char* x, const float* u, float* data, unsigned char* requant, size_t n, int uniform,
+                     float scale, mulan_stream_t stream);
+
 /* ---- MuLAN closed-form terms; d must be 3072 ------------------------------------------------- */
 /* NoiseSchedule_polynomial_fixedend._eval_polynomial / _grad_t (model_mulan_epsilon.py:514-555).
  * g0, g1, gprime may be NULL. */

@@ -1,8 +1,8 @@
-"""python -m ldm.eval_bpd --config=... --checkpoint_directory=... [--checkpoint N] --bpd_eval_method=dense|sparse
+"""python -m ldm.eval_bpd --config=... --checkpoint_directory=... [--checkpoint N] --bpd_eval_method=ode|dense|sparse
 
-Flag surface of the reference (ldm/eval_bpd.py:17-31).  `dense` and `sparse` (variational bound) run on the
-HIP path, sharded over ranks by test-image index under torchrun; `ode` (exact likelihood) is the next
-tier and raises NotImplementedError."""
+Flag surface of the reference (ldm/eval_bpd.py:17-31).  `dense` and `sparse` (variational bound) and `ode` (exact
+likelihood: probability-flow ODE, Hutchinson divergence, device-resident RK45) run on the HIP path, sharded over
+ranks by test-image index under torchrun."""
 import logging
 import os
 import sys
@@ -48,7 +48,7 @@ def main(argv):
     elif FLAGS.bpd_eval_method == 'ode':
         bpd = eval_bpd_ode(experiment, FLAGS.config, hutchinson_type=FLAGS.hutchinson_type,
                            deterministic_noise=FLAGS.deterministic_noise, num_iters=FLAGS.num_iters,
-                           num_is=FLAGS.n_is, rtol=FLAGS.rtol, atol=FLAGS.atol)
+                           num_is=FLAGS.n_is, rtol=FLAGS.rtol, atol=FLAGS.atol, max_images=FLAGS.max_images)
     else:
         raise SystemExit(f'unknown --bpd_eval_method {FLAGS.bpd_eval_method}')
     if rank == 0:

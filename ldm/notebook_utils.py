@@ -1,3 +1,4 @@
-"""Evaluators of the reference's ldm/notebook_utils.py that sit on the hot path: Experiment_Colab
-(:28-39, EMA parameters of a checkpoint) and the variational-bound BPD evaluators (:157-191)."""
-from mulan_amd.evaluators import Experiment_Colab, eval_bpd_dense_sampling, eval_bpd_sparse_sampling, eval_bpd_ode  # noqa: F401
+"""Evaluators of the reference's ldm/notebook_utils.py: Experiment_Colab (:28-39, EMA parameters of a checkpoint),
+the variational-bound BPD evaluators (:157-191) and the exact-likelihood ODE evaluator (:232-373, 446-531)."""
+from mulan_amd.evaluators import (Experiment_Colab, Hutchinson, eval_bpd_dense_sampling,  # noqa: F401
+                                  eval_bpd_ode, eval_bpd_sparse_sampling, get_ode_likelihood_fn, _get_bpd_offset)

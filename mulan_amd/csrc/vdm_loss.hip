@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void topk_fwd_kernel(TkArgs p) {
   const float klv = wave_sum(on ? q * (logq - logf(1.0f / (float)L)) : 0.f);
   // sum-of-gammas noise (model_mulan_velocity.py:94-104)
   float s = 0.f;
-  if (on) {
+  if (on && p.gnoise) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const float beta = (float)p.k / (float)(i + 1);
@@ -300,10 +300,14 @@ __global__ __launch_bounds__(64) void topk_fwd_kernel(TkArgs p) {
   const float thr = wave_max(is_kth ? l : -INFINITY);
   if (on) {
     const float hard = (l >= thr) ? 1.f : 0.f;
-    p.emb[(size_t)b * L + j] = (hard - soft) + soft;
-    p.soft[(size_t)b * L + j] = soft;
+    // gnoise == nullptr: the hard k-hot of the plain logits (notebook_utils.logits_to_embeddings, :548-551)
+    p.emb[(size_t)b * L + j] = p.gnoise ? (hard - soft) + soft : hard;
+    if (p.soft) p.soft[(size_t)b * L + j] = soft;
   }
-  if (j == 0) { p.kl[b] = klv; p.nrm[b] = nrm; }
+  if (j == 0) {
+    p.kl[b] = klv;
+    if (p.nrm) p.nrm[b] = nrm;
+  }
 }
 
 __global__ __launch_bounds__(64) void topk_bwd_kernel(TkArgs p) {

@@ -84,6 +84,159 @@ def eval_bpd_sparse_sampling(experiment, config, max_images=0):
     return mean
 
 
-def eval_bpd_ode(*args, **kwargs):
-    raise NotImplementedError("exact-likelihood ODE evaluator (ldm/notebook_utils.py:264-373,446-531) is the next tier "
-                              "(SURVEY 8f rank 2); use --bpd_eval_method=dense or sparse")
+# ------------------------------------------------------------------ exact likelihood (probability-flow ODE)
+GAMMA_TN = -13.3                  # `gt` hard-coded in get_ode_likelihood_fn / _get_bpd_offset (notebook_utils.py:321,452)
+TN_LOG_Z = float(np.log(0.9974613))          # mass of N(0,1) on [-3, 3] as the reference rounds it (:331)
+
+
+class Hutchinson:
+    """notebook_utils.Hutchinson (:232-260): one probe per function evaluation, or one fixed probe"""
+
+    def __init__(self, hutchinson_type, shape, rng, device, deterministic=False):
+        if hutchinson_type not in ('Rademacher', 'Gaussian'):
+            raise ValueError(f'hutchinson_type {hutchinson_type}')
+        self.kind, self.shape, self.rng, self.device = hutchinson_type, shape, rng, device
+        self.deterministic = deterministic
+        if deterministic:
+            self.det_noise = self._draw(rng)
+
+    def _draw(self, key):
+        from . import ops
+        if self.kind == 'Gaussian':
+            return key.normal(self.shape, self.device)
+        return ops.noise(self.shape, key.v, 0, self.device, 'rademacher')
+
+    def noise(self):
+        if self.deterministic:
+            return self.det_noise
+        self.rng, key = self.rng.split()
+        return self._draw(key)
+
+
+def get_ode_likelihood_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5, method='RK45',
+                          dequantization='uniform', high_precision=False):
+    """get_ode_likelihood_fn (ldm/notebook_utils.py:263-373).  Returns likelihood_fn(rng, data_u8 [B,32,32,3],
+    deterministic_noise=False, u=None, probes=None) -> (log_p [B] float64, log_q_eps [B] | None, aux_loss [B], info).
+    `u` (dequantisation noise: U[0,1) for 'uniform', standard normal on [-3, 3] for 'tn') and `probes` (a callable
+    returning the Hutchinson probe of each function evaluation) override the Philox draws and `t_grid` replaces the
+    adaptive controller by fixed Dormand-Prince steps: parity tests pass them."""
+    from . import ops
+    from .ode import solve_fixed, solve_rk45
+    if method != 'RK45':
+        raise NotImplementedError("the reference only ever passes method='RK45' (ldm/notebook_utils.py:264)")
+    if dequantization not in ('uniform', 'tn'):
+        raise AssertionError(dequantization)
+    model, params, dev = experiment.model, experiment.orig_params, experiment.device
+    packer = experiment.state.param_packer("ema") if params is experiment.state.ema_params else None
+
+    def likelihood_fn(rng, data, deterministic_noise=False, u=None, probes=None, t_grid=None):
+        rng, init_noise_rng = rng.split()
+        x = data.reshape(-1, 3072).contiguous()
+        B = x.shape[0]
+        if dequantization == 'uniform':
+            if u is None:
+                u = ops.noise((B, 3072), init_noise_rng.v, 0, dev, 'uniform')
+            y, requant = ops.dequantize(x, u, True)
+            log_q_eps = None
+        else:
+            if u is None:
+                u = ops.noise((B, 3072), init_noise_rng.v, 0, dev, 'truncated_normal', -3.0, 3.0)
+            log_q_eps = ops.normal_logp(u).double() - 3072 * TN_LOG_Z
+            y, requant = ops.dequantize(x, u, False, float(np.exp(np.float32(0.5 * GAMMA_TN))))
+        if packer is not None:
+            packer.refresh()
+        try:
+            ctx = model.ode_context(params, requant)
+            rng, hutchinson_rng = rng.split()
+            hutch = Hutchinson(hutchinson_type, (B, 3072), hutchinson_rng, dev, deterministic=deterministic_noise)
+            draw = probes if probes is not None else hutch.noise
+            n_x = B * 3072
+
+            def ode_func(t, y32, out):
+                model.reverse_ode(params, y32[:n_x].view(B, 3072), ctx, t, draw(), drift_out=out[:n_x].view(B, 3072),
+                                  div_out=out[n_x:])
+
+            y0 = torch.cat([y.reshape(-1).double(), torch.zeros(B, device=dev, dtype=torch.float64)])
+            sol = (solve_rk45(ode_func, y0, (0.0, 1.0), rtol=rtol, atol=atol) if t_grid is None
+                   else solve_fixed(ode_func, y0, t_grid))
+        finally:
+            if packer is not None:
+                packer.invalidate()
+        z = sol.y[:n_x].float().view(B, 3072)
+        log_p = ops.normal_logp(z).double() + sol.y[n_x:].float().double()
+        return log_p, log_q_eps, ctx["kl"], dict(nfev=sol.nfev, steps=sol.steps, rejected=sol.rejected, z=z)
+
+    return likelihood_fn
+
+
+def _get_bpd_offset(dequantization, num_is):
+    """notebook_utils._get_bpd_offset (:446-458)"""
+    if dequantization == 'uniform':
+        return float(np.log2(128))
+    if dequantization == 'tn':
+        log_sigma = 0.5 * (GAMMA_TN - float(np.logaddexp(GAMMA_TN, 0.0)))
+        extra = 0.5 * (1 + float(np.log(2 * np.pi))) - 0.01522 if num_is == 1 else 0.0
+        return -(extra + log_sigma) / float(np.log(2))
+    raise AssertionError(dequantization)
+
+
+def _logsumexp0(a):
+    m = a.max(axis=0)
+    return m + np.log(np.exp(a - m).sum(axis=0))
+
+
+def _eval_bpd_ode(experiment, config, rng, deterministic_noise, hutchinson_type, dequantization='tn', num_is=1,
+                  rtol=1e-5, atol=1e-5, max_images=0):
+    """notebook_utils._eval_bpd_ode (:480-531): per batch, num_is likelihood draws, importance-weighted bound,
+    running mean over batches.  Under torchrun the test set is sharded over ranks by index and every rank integrates
+    its own batch (the step-size controller sees the rank's batch, not the global one)."""
+    batch_size = config.training.batch_size_eval
+    loader = dataset.create_one_time_eval_dataset(config, batch_size, experiment.device, experiment.rank,
+                                                  experiment.world)
+    likelihood_function = get_ode_likelihood_fn(experiment, rtol=rtol, atol=atol, hutchinson_type=hutchinson_type,
+                                                dequantization=dequantization)
+    bpd_offset = _get_bpd_offset(dequantization, num_is)
+    total, count = 0.0, 0
+    for eval_step, batch in enumerate(loader):
+        if max_images and eval_step * batch_size * experiment.world >= max_images:
+            break
+        log_ps, log_qs, aux_loss = [], [], None
+        for _ in range(num_is):
+            rng, likelihood_rng = rng.split()
+            log_p, log_q_eps, aux, _ = likelihood_function(likelihood_rng, batch['images'],
+                                                           deterministic_noise=deterministic_noise)
+            log_ps.append(log_p.cpu().numpy())
+            log_qs.append(None if log_q_eps is None else log_q_eps.cpu().numpy())
+            aux_loss = aux.double().cpu().numpy()
+        log_ps = np.asarray(log_ps)
+        if num_is == 1:
+            iws = log_ps[0]
+        else:
+            if log_qs[0] is None:
+                raise TypeError("importance weighting needs dequantization='tn' (the reference subtracts None here)")
+            iws = _logsumexp0(log_ps - np.asarray(log_qs)) - np.log(num_is)
+        bpd = float(np.mean(-iws + aux_loss) / (32 * 32 * 3 * np.log(2)) + bpd_offset)
+        total += bpd
+        count += 1
+        if experiment.rank == 0:
+            print('Eval step:{}\tcum. bpd: {:.3f}'.format(eval_step, total / count))
+    mean, n = _reduce_mean(total, count, experiment.device)
+    if experiment.rank == 0:
+        print('Num eval steps:', n)
+    return mean
+
+
+def eval_bpd_ode(experiment, config, deterministic_noise, hutchinson_type, dequantization='tn', num_is=1, num_iters=1,
+                 rtol=1e-5, atol=1e-5, max_images=0):
+    """notebook_utils.eval_bpd_ode (:461-477)"""
+    bpd_means = []
+    rng = PRNGKey(0)
+    for i in range(num_iters):
+        rng, iter_rng = rng.split()
+        mean = _eval_bpd_ode(experiment=experiment, config=config, rng=iter_rng, deterministic_noise=deterministic_noise,
+                             hutchinson_type=hutchinson_type, dequantization=dequantization, num_is=num_is, rtol=rtol,
+                             atol=atol, max_images=max_images)
+        if experiment.rank == 0:
+            print(f'[Iter {i}] Test BPD:{mean}')
+        bpd_means.append(mean)
+    return float(np.mean(bpd_means))

@@ -6,12 +6,12 @@ memory and the current HIP stream.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmulan_hip.so")
 
-P, I, F, Z, U, LL = c_void_p, c_int, c_float, c_size_t, c_ulonglong, c_longlong
+P, I, F, Z, U, LL, D = c_void_p, c_int, c_float, c_size_t, c_ulonglong, c_longlong, c_double
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mulan_hip.h
 SIGNATURES = {
@@ -70,13 +70,22 @@ SIGNATURES = {
     "mulan_ancestral_step": [P, P, P, P, P, P, Z, I, I, P],
     "mulan_decode_argmax": [P, P, P, Z, I, P],
     "mulan_rowmean": [P, P, I, I, P],
+    "mulan_ode_drift": [P, P, P, P, P, P, P, Z, I, I, P],
+    "mulan_ode_div": [P, P, P, P, P, I, I, I, I, P],
+    "mulan_rk_combine": [P, P, Z, P, I, D, P, P, Z, P],
+    "mulan_rk_workspace_bytes": [],
+    "mulan_rk_error_norm": [P, P, P, Z, P, D, D, D, P, P, Z, P],
+    "mulan_rk_init_norms": [P, P, P, D, D, P, P, Z, P],
+    "mulan_normal_logp": [P, P, I, I, P],
+    "mulan_noise": [P, Z, U, U, I, F, F, P],
+    "mulan_dequantize": [P, P, P, P, Z, I, F, P],
     "mulan_adamw_ema_step": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P],
     "mulan_randn": [P, Z, U, U, P],
     "mulan_version": [],
     "mulan_set_tuning": [I, I],
     "mulan_set_debug_buffer": [P],
 }
-_RESTYPES = {"mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
+_RESTYPES = {"mulan_rk_workspace_bytes": c_size_t, "mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
              "mulan_conv3x3_pack_f16x3_bytes": c_size_t, "mulan_conv3x3_planes_bytes": c_size_t, "mulan_linear_pack_f16x3_bytes": c_size_t,
              "mulan_linear_wgrad_f16x3_planes_workspace": c_size_t,
              "mulan_conv3x3_wgrad_f16x3_planes_workspace": c_size_t, "mulan_conv3x3_wgrad_f16x3_workspace": c_size_t, "mulan_gemm_workspace": c_size_t, "mulan_version": c_char_p}

@@ -428,6 +428,54 @@ class MulanVDM(_VDMBase):
             return ops.decode_argmax(z_0.reshape(B, D), g_0).view(B, 32, 32, 3)
 
 
+    # ---- probability-flow ODE (ldm/model_mulan_velocity.py:51-53, 393-421; ldm/model_mulan_epsilon.py:459-478) ----
+    def apply_encoder(self, params, images_u8):
+        """VDM.apply_encoder: encoder logits [B, latent_size] of integer images"""
+        x = images_u8.reshape(-1, D).contiguous()
+        with torch.no_grad():
+            return unet_encoder(params["encoder_model"], self.config, encode_images(x), _Drop(None, 0.0))
+
+    def ode_context(self, params, images_u8):
+        """per batch, constant along the ODE: hard top-k embedding of the encoder logits
+        (notebook_utils.logits_to_embeddings), its KL term (_gumbel_kl_loss) and the schedule coefficients"""
+        if not self.config.z_conditioning:
+            raise NotImplementedError("reverse_ode hands the embedding to the score model (z_conditioning=True)")
+        logits = self.apply_encoder(params, images_u8)
+        emb, kl = ops.topk_hard(logits, self.config.latent_k)
+        with torch.no_grad():
+            coeffs = poly_coefficients(params["gamma"], emb)
+        return dict(emb=emb, kl=kl, coeffs=coeffs, logits=logits)
+
+    def _ode_mode(self):
+        if self.parameterization == "velocity":
+            return 1 if self.config.velocity_from_epsilon else 0
+        return 2
+
+    def reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_out=None):
+        """VDM.reverse_ode at time t for x [B, 3072]; with `hutch` also the Hutchinson estimate
+        hutch^T (d drift / d x) hutch per sample (notebook_utils._get_value_div_fn): returns (drift, div | None)"""
+        cfg = self.config
+        B = x.shape[0]
+        a, b, c = ctx["coeffs"]
+        tt = torch.full((B,), float(np.float32(t)), device=x.device, dtype=torch.float32)
+        with torch.no_grad():
+            _, _, gt, gp = ops.poly_gamma(a, b, c, tt, cfg.gamma_min, cfg.gamma_max)
+            g_in = gt.view(B, HW, 3) if cfg.unet_type == 'ldm' else ops.rowmean(gt)
+        xin = x.detach().reshape(B, D).contiguous()
+        if hutch is None:
+            with torch.no_grad():
+                net = score_unet(params["score_model"], cfg, xin.view(B, HW, 3), g_in, ctx["emb"], _Drop(None, 0.0))
+                drift, _ = ops.ode_drift(net.reshape(B, D), xin, gt, gp, None, self._ode_mode(), drift_out)
+            return drift, None
+        xin.requires_grad_(True)
+        with torch.enable_grad():
+            net = score_unet(params["score_model"], cfg, xin.view(B, HW, 3), g_in, ctx["emb"], _Drop(None, 0.0))
+        drift, cot = ops.ode_drift(net.detach().reshape(B, D), xin.detach(), gt, gp, hutch, self._ode_mode(), drift_out)
+        (gx,) = torch.autograd.grad(net, xin, cot.view_as(net))
+        div = ops.ode_div(gx.reshape(B, D), gt, gp, hutch, self._ode_mode(), div_out)
+        return drift, div
+
+
 class PlainVDM(_VDMBase):
     """model_vdm.VDM (ldm/model_vdm.py:95-180): scalar noise schedule, epsilon prediction, T = 0 or T > 0
     with reparam_type 'noise' | 'input'.  gamma_type in {'fixed', 'learnable_scalar'}."""
@@ -522,6 +570,43 @@ def _plain_generate_x(self, params, z_0, coeffs=None):
         return ops.decode_argmax(z_0.reshape(B, D), g_0.contiguous()).view(B, 32, 32, 3)
 
 
+def _plain_apply_encoder(self, params, images_u8):
+    """model_vdm.VDM.apply_encoder (ldm/model_vdm.py:240-241): zeros"""
+    return torch.zeros((images_u8.reshape(-1, D).shape[0], 50), device=images_u8.device, dtype=torch.float32)
+
+
+def _plain_ode_context(self, params, images_u8):
+    logits = self.apply_encoder(params, images_u8)
+    emb, kl = ops.topk_hard(logits, 15)          # all-equal logits: every entry >= the 15th largest -> ones; KL = 0
+    return dict(emb=emb, kl=kl, coeffs=None, logits=logits)
+
+
+def _plain_reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_out=None):
+    """model_vdm.VDM.reverse_ode (ldm/model_vdm.py:243-260): drift - 0.5 g^2 score with score = -eps_hat / sigma;
+    the score model is conditioned on embeddings[:, :1] like the reference"""
+    cfg = self.config
+    B = x.shape[0]
+    with torch.no_grad():
+        gt, gp = self._gamma(params, torch.full((B,), float(np.float32(t)), device=x.device))
+        gt, gp = gt.contiguous(), gp.contiguous()
+    cond = ctx["emb"][:, :1].contiguous()
+    xin = x.detach().reshape(B, D).contiguous()
+    if hutch is None:
+        with torch.no_grad():
+            net = score_unet(params["score_model"], cfg, xin.view(B, HW, 3), gt, cond, _Drop(None, 0.0))
+            drift, _ = ops.ode_drift(net.reshape(B, D), xin, gt, gp, None, 2, drift_out)
+        return drift, None
+    xin.requires_grad_(True)
+    with torch.enable_grad():
+        net = score_unet(params["score_model"], cfg, xin.view(B, HW, 3), gt, cond, _Drop(None, 0.0))
+    drift, cot = ops.ode_drift(net.detach().reshape(B, D), xin.detach(), gt, gp, hutch, 2, drift_out)
+    (gx,) = torch.autograd.grad(net, xin, cot.view_as(net))
+    return drift, ops.ode_div(gx.reshape(B, D), gt, gp, hutch, 2, div_out)
+
+
+PlainVDM.apply_encoder = _plain_apply_encoder
+PlainVDM.ode_context = _plain_ode_context
+PlainVDM.reverse_ode = _plain_reverse_ode
 PlainVDM.sample = _plain_sample
 PlainVDM.generate_x = _plain_generate_x
 PlainVDM.sample_coefficients = lambda self, params, embedding: None

@@ -1092,3 +1092,89 @@ def rowmean(x):
     out = torch.empty(rows, device=x.device, dtype=torch.float32)
     call("mulan_rowmean", ptr(x), ptr(out), rows, x.numel() // rows, stream())
     return out
+
+
+# ----------------------------------------------------------------------------- exact-likelihood ODE (eval only)
+def topk_hard(logits, k):
+    """(k-hot embedding of the plain logits, KL(softmax(logits) || uniform)): notebook_utils.logits_to_embeddings and
+    _gumbel_kl_loss (ldm/notebook_utils.py:548-551, 222-229)"""
+    logits = _c(logits)
+    B, L = logits.shape
+    emb = torch.empty_like(logits)
+    kl = torch.empty(B, device=logits.device, dtype=torch.float32)
+    call("mulan_topk_fwd", ptr(logits), None, ptr(emb), ptr(kl), None, None, B, L, int(k), 0.0, stream())
+    return emb, kl
+
+
+def ode_drift(net, x, gt, gp, hutch, mode, drift_out=None, want_cot=True):
+    """(drift, cotangent for net) of VDM.reverse_ode; gamma per element or per sample"""
+    net, x, gt, gp = _c(net), _c(x), _c(gt), _c(gp)
+    hutch = _c(hutch) if hutch is not None else None
+    drift = drift_out if drift_out is not None else torch.empty_like(net)
+    cot = torch.empty_like(net) if (want_cot and hutch is not None) else None
+    per = net.numel() // gt.numel()
+    call("mulan_ode_drift", ptr(net), ptr(x), ptr(gt), ptr(gp), ptr(hutch) if hutch is not None else None, ptr(drift),
+         ptr(cot), net.numel(), int(mode), 0 if per == 1 else per, stream())
+    return drift, cot
+
+
+def ode_div(gx, gt, gp, hutch, mode, div_out=None):
+    gx, gt, gp, hutch = _c(gx), _c(gt), _c(gp), _c(hutch)
+    B = gx.shape[0]
+    d = gx.numel() // B
+    div = div_out if div_out is not None else torch.empty(B, device=gx.device, dtype=torch.float32)
+    call("mulan_ode_div", ptr(gx), ptr(gt), ptr(gp), ptr(hutch), ptr(div), B, d, int(mode),
+         0 if gt.numel() == gx.numel() else d, stream())
+    return div
+
+
+def _coef(values):
+    import ctypes
+    return (ctypes.c_double * 7)(*(list(values) + [0.0] * (7 - len(values))))
+
+
+def rk_combine(y, K, coef, h, out=None, out32=None):
+    """out = y + h sum_j coef_j K[j] as float64 and / or fp32; K [7, n] fp32"""
+    call("mulan_rk_combine", ptr(y), ptr(K), K.stride(0), _coef(coef), len(coef), float(h), ptr(out), ptr(out32),
+         y.numel(), stream())
+
+
+def rk_workspace(device):
+    from .lib import load
+    return torch.empty(load().mulan_rk_workspace_bytes() // 8, device=device, dtype=torch.float64)
+
+
+def rk_error_norm(y, ynew, K, e, h, rtol, atol, ws, out):
+    call("mulan_rk_error_norm", ptr(y), ptr(ynew), ptr(K), K.stride(0), _coef(e), float(h), float(rtol), float(atol),
+         ptr(ws), ptr(out), y.numel(), stream())
+
+
+def rk_init_norms(y0, f0, f1, rtol, atol, ws, out3):
+    call("mulan_rk_init_norms", ptr(y0), ptr(f0), ptr(f1) if f1 is not None else None, float(rtol), float(atol), ptr(ws),
+         ptr(out3), y0.numel(), stream())
+
+
+def normal_logp(x):
+    x = _c(x)
+    rows = x.shape[0]
+    out = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("mulan_normal_logp", ptr(x), ptr(out), rows, x.numel() // rows, stream())
+    return out
+
+
+def noise(shape, seed, offset, device, kind, lo=-3.0, hi=3.0):
+    """kind: 'uniform' U[0,1) | 'rademacher' +-1 | 'truncated_normal' on [lo, hi]"""
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("mulan_noise", ptr(out), out.numel(), int(seed) & (2**64 - 1), int(offset),
+         {"uniform": 0, "rademacher": 1, "truncated_normal": 2}[kind], float(lo), float(hi), stream())
+    return out
+
+
+def dequantize(x_u8, u, uniform, scale=1.0):
+    """(data = encode(x) + noise as fp32, the re-quantised uint8 image the encoder sees)"""
+    x_u8, u = _c(x_u8), _c(u)
+    data = torch.empty(x_u8.shape, device=x_u8.device, dtype=torch.float32)
+    rq = torch.empty_like(x_u8)
+    call("mulan_dequantize", ptr(x_u8), ptr(u), ptr(data), ptr(rq), x_u8.numel(), 1 if uniform else 0, float(scale),
+         stream())
+    return data, rq

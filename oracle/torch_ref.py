@@ -317,6 +317,147 @@ def plain_sample_loop(params, cfg, z_init, eps_list, gmin=GAMMA_MIN, gmax=GAMMA_
     return z, decode_argmax(z, g_0)
 
 
+# ------------------------------------------------------------------------------ exact likelihood (ODE)
+def logits_to_embeddings(logits, k=15):
+    """ldm/notebook_utils.py:548-551"""
+    kth = torch.topk(logits, k, dim=-1).values[:, -1:]
+    return (logits >= kth).to(logits.dtype)
+
+
+def gumbel_kl_loss(logits):
+    """ldm/notebook_utils.py:222-229"""
+    q, logq = torch.softmax(logits, dim=-1), torch.log_softmax(logits, dim=-1)
+    return (q * (logq - math.log(1.0 / logits.shape[-1]))).sum(dim=-1)
+
+
+def ode_drift(net, x, g_t, g_p, kind):
+    """the closed form around the network in VDM.reverse_ode: kind 'velocity' / 'vfe' (velocity_from_epsilon)
+    (ldm/model_mulan_velocity.py:403-421), 'epsilon' (ldm/model_mulan_epsilon.py:471-478)"""
+    sigma = torch.sqrt(torch.sigmoid(g_t))
+    if kind == "epsilon":
+        return 0.5 * (-sigma * x + net) * sigma * g_p
+    v_hat = net
+    if kind == "vfe":
+        v_hat = -torch.exp(0.5 * g_t) * x + torch.sqrt(1 + torch.exp(g_t)) * net
+    alpha = torch.sqrt(1 - torch.sigmoid(g_t))
+    return v_hat * (0.5 * alpha * sigma * g_p)
+
+
+def reverse_ode(params, cfg, x, emb, t):
+    """VDM.reverse_ode (ldm/model_mulan_velocity.py:393-421 incl. velocity_from_epsilon; ldm/model_mulan_epsilon.py:
+    459-478), high_precision False; x [B,32,32,3], t float"""
+    B = x.shape[0]
+    a, b, c = poly_coefficients(emb, params["gamma"])
+    tt = torch.full((B,), float(t), dtype=x.dtype)
+    g_t = poly_gamma(a, b, c, tt).reshape(x.shape)
+    g_p = poly_gamma_grad_t(a, b, c, tt).reshape(x.shape)
+    per_pixel = cfg.get("unet_type", "vdm") == "ldm"
+    g_in = g_t if per_pixel else g_t.reshape(B, -1).mean(dim=1)
+    net = score_unet(x, g_in, emb, params["score_model"], cfg["n_embd"], cfg["n_layer"], per_pixel)
+    if cfg["vdm_type"] == "mulan_velocity":
+        return ode_drift(net, x, g_t, g_p, "vfe" if cfg.get("velocity_from_epsilon", False) else "velocity")
+    return ode_drift(net, x, g_t, g_p, "epsilon")
+
+
+def plain_reverse_ode(params, cfg, x, emb, t, gmin=GAMMA_MIN, gmax=GAMMA_MAX):
+    """model_vdm.VDM.reverse_ode + sde (ldm/model_vdm.py:229-260)"""
+    B = x.shape[0]
+    if "gamma" in params:
+        w, b0 = torch.abs(params["gamma"]["w"]), params["gamma"]["b"]
+        g_t, g_p = (b0 + w * t).reshape(()), w.reshape(())
+    else:
+        g_t, g_p = torch.tensor(gmin + (gmax - gmin) * t, dtype=x.dtype), torch.tensor(gmax - gmin, dtype=x.dtype)
+    drift = -0.5 * torch.sigmoid(g_t) * g_p * x
+    diffusion_sqr = torch.sigmoid(g_t) * g_p
+    eps_hat = score_unet(x, g_t * torch.ones(B, dtype=x.dtype), emb[:, :1], params["score_model"], cfg["n_embd"],
+                         cfg["n_layer"], gmin=gmin, gmax=gmax)
+    score_hat = -eps_hat / torch.sqrt(torch.sigmoid(g_t))
+    return drift - 0.5 * diffusion_sqr * score_hat
+
+
+def value_div(fn, x, hutch):
+    """notebook_utils._get_value_div_fn (:203-215): (f(x), sum_i (d sum(f * hutch) / d x)_i hutch_i per sample)"""
+    x = x.detach().requires_grad_(True)
+    f = fn(x)
+    (g,) = torch.autograd.grad((f * hutch).sum(), x)
+    return f.detach(), (g * hutch).reshape(x.shape[0], -1).sum(dim=1)
+
+
+def prior_logp(z):
+    """notebook_utils._prior_logp (:218-221)"""
+    n = z[0].numel()
+    return -0.5 * n * math.log(2 * math.pi) - 0.5 * (z.reshape(z.shape[0], -1) ** 2).sum(dim=1)
+
+
+def bpd_offset(dequantization, num_is):
+    """notebook_utils._get_bpd_offset (:446-458)"""
+    if dequantization == "uniform":
+        return math.log2(128)
+    gt = -13.3
+    log_sigma = 0.5 * (gt - math.log1p(math.exp(gt)))
+    extra = 0.5 * (1 + math.log(2 * math.pi)) - 0.01522 if num_is == 1 else 0.0
+    return -(extra + log_sigma) / math.log(2)
+
+
+def dopri5_fixed(fun, y0, t_grid):
+    """Dormand-Prince 5(4) steps (the tableau of scipy's RK45 = Dormand & Prince 1980) on a prescribed grid, 5th
+    order solution, no error control; fun(t, y) -> dy/dt (numpy float64)"""
+    import numpy as np
+    c = [0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1]
+    a = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9],
+         [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+         [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]]
+    b = [35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84]
+    y = np.asarray(y0, dtype=np.float64)
+    for t, t_new in zip(t_grid[:-1], t_grid[1:]):
+        h = t_new - t
+        k = [fun(t, y)]
+        for s in range(1, 6):
+            k.append(fun(t + c[s] * h, y + h * sum(a[s][j] * k[j] for j in range(s))))
+        y = y + h * sum(b[j] * k[j] for j in range(6))
+    return y
+
+
+def ode_likelihood(drift_fn, encoder_fn, x_u8, u, probes, dequantization="tn", rtol=1e-5, atol=1e-5,
+                   dtype=torch.float64, t_grid=None):
+    """likelihood_fn of get_ode_likelihood_fn (ldm/notebook_utils.py:303-371) with the dequantisation noise `u`
+    (U[0,1) for 'uniform', truncated normal for 'tn') and the Hutchinson probes (callable, one per function
+    evaluation) given.  drift_fn(x, emb, t) = reverse_ode, encoder_fn(images_int) = apply_encoder.  Integrated by
+    scipy.integrate.solve_ivp(method='RK45') exactly like the reference.
+    Returns (log_p [B], log_q_eps [B] | None, aux_loss [B], nfev)"""
+    import numpy as np
+    from scipy import integrate
+    B = x_u8.shape[0]
+    shp = (B, 32, 32, 3)
+    data = encode(x_u8.reshape(shp).to(dtype))
+    u = u.reshape(shp).to(dtype)
+    if dequantization == "uniform":
+        noise, log_q_eps = 2 * (u - 0.5) / 256, None
+    else:
+        log_q_eps = prior_logp(u) - 3072 * math.log(0.9974613)
+        noise = u * math.exp(0.5 * -13.3)
+    data = data + noise
+    logits = encoder_fn(torch.round(torch.clamp(128 * (data + 1) - 0.5, 0, 255)))
+    aux = gumbel_kl_loss(logits)
+    emb = logits_to_embeddings(logits)
+
+    def ode_func(t, y):
+        # the reference hands the network the fp32-rounded state (_from_flattened_numpy, notebook_utils.py:198-200)
+        xt = torch.tensor(y[:-B], dtype=torch.float32).to(dtype).reshape(shp)
+        f, div = value_div(lambda xx: drift_fn(xx, emb, t), xt, probes().reshape(shp).to(dtype))
+        return np.concatenate([f.reshape(-1).numpy(), div.numpy()])
+
+    init = np.concatenate([data.reshape(-1).numpy(), np.zeros(B)])
+    if t_grid is not None:          # test hook: fixed steps instead of the adaptive controller
+        zp, nfev = dopri5_fixed(ode_func, init, t_grid), 6 * (len(t_grid) - 1)
+    else:
+        sol = integrate.solve_ivp(ode_func, (0, 1), init, rtol=rtol, atol=atol, method="RK45")
+        zp, nfev = sol.y[:, -1], sol.nfev
+    z = torch.tensor(zp[:-B], dtype=dtype).reshape(shp)
+    log_p = prior_logp(z) + torch.tensor(zp[-B:], dtype=dtype)
+    return log_p, log_q_eps, aux, nfev
+
+
 # ------------------------------------------------------------------------------ parameter trees
 def tree_map(fn, tree):
     return {k: tree_map(fn, v) if isinstance(v, dict) else fn(v) for k, v in tree.items()}

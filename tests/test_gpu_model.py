@@ -281,6 +281,14 @@ def test_cli_train_checkpoint_and_dense_eval(tmp_path):
     importlib.reload(ldm.eval_bpd)
     ldm.eval_bpd.main(common + ["--config.data.dataset=npz:" + str(tmp_path / "test.npz"),
                                 "--checkpoint_directory=" + ckdirs[0], "--checkpoint=1", "--bpd_eval_method=sparse"])
+    # the reference's default method: exact likelihood by the probability-flow ODE (2 importance samples, loose
+    # tolerances to keep the run short)
+    importlib.reload(ldm.eval_bpd)
+    ldm.eval_bpd.main(common + ["--config.data.dataset=npz:" + str(tmp_path / "test.npz"),
+                                "--checkpoint_directory=" + ckdirs[0], "--n_is=2", "--rtol=1e-2", "--atol=1e-2",
+                                "--max_images=2"])
+    # sample grids written at the evaluation point of the training run
+    assert any(f.startswith("samples_") and f.endswith(".ppm") for dp, _, fs in os.walk(tmp_path / "run") for f in fs)
 
 
 def test_gradient_sink_equals_autograd_accumulation():

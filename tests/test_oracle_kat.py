@@ -225,3 +225,67 @@ def test_sample_loop_runs_and_is_deterministic_given_noise():
     z1, x1 = tr.mulan_sample_loop(P, cfg, z, eps)
     assert torch.equal(z0, z1) and torch.equal(x0, x1) and x0.shape == (1, 32, 32, 3)
     assert int(x0.min()) >= 0 and int(x0.max()) <= 255 and torch.isfinite(z0).all()
+
+
+def test_ode_drift_forms_agree_on_exact_targets():
+    """the velocity, velocity-from-epsilon and epsilon forms of reverse_ode are the same ODE when each network
+    output is its own exact target (v = alpha eps - sigma x0 = (eps - sigma z) / alpha; the vfe network predicts eps)"""
+    rng = np.random.default_rng(1)
+    n = 2048
+    z, eps = torch.tensor(rng.standard_normal(n)), torch.tensor(rng.standard_normal(n))
+    g_t, g_p = torch.tensor(rng.uniform(-13.3, 5.0, n)), torch.tensor(rng.uniform(1.0, 30.0, n))
+    alpha = torch.sqrt(torch.sigmoid(-g_t))
+    sigma = torch.sqrt(torch.sigmoid(g_t))
+    d_eps = tr.ode_drift(eps, z, g_t, g_p, "epsilon")
+    d_vel = tr.ode_drift((eps - sigma * z) / alpha, z, g_t, g_p, "velocity")
+    d_vfe = tr.ode_drift(eps, z, g_t, g_p, "vfe")
+    assert torch.allclose(d_vel, d_eps, rtol=1e-9, atol=1e-12)
+    # the reference's vfe transform -e^{g/2} x + sqrt(1 + e^g) eps equals (eps - sigma z) / alpha
+    assert torch.allclose(d_vfe, d_eps, rtol=1e-6, atol=1e-9)
+
+
+def test_hutchinson_is_exact_for_a_diagonal_jacobian():
+    rng = np.random.default_rng(2)
+    a = torch.tensor(rng.standard_normal((3, 4, 4, 3)))
+    x = torch.tensor(rng.standard_normal((3, 4, 4, 3)))
+    h = torch.tensor(rng.integers(0, 2, (3, 4, 4, 3)) * 2.0 - 1.0)
+    f, div = tr.value_div(lambda xx: a * xx + torch.sin(xx), x, h)
+    assert torch.allclose(f, a * x + torch.sin(x))
+    assert torch.allclose(div, (a + torch.cos(x)).reshape(3, -1).sum(dim=1), rtol=1e-12)
+
+
+def test_ode_likelihood_of_a_gaussian_is_exact():
+    """KAT for the whole likelihood machinery (dequantisation, flattening, solve_ivp, Hutchinson, prior): for data
+    ~ N(0, s^2 I) under a variance-preserving schedule the exact eps-prediction is sigma z / var_t with
+    var_t = s^2 + (1 - s^2) sigma_t^2; the flow is z_1 = z_0 sqrt(var_1 / var_0) and
+    log p = log N(z_1; 0, I) + (D / 2) log(var_1 / var_0)."""
+    import math
+    s2 = 0.25
+    gmin, gmax = -13.3, 5.0
+
+    def drift(x, emb, t):
+        g = torch.tensor(gmin + (gmax - gmin) * t, dtype=x.dtype)
+        var = s2 + (1 - s2) * torch.sigmoid(g)
+        eps_hat = torch.sqrt(torch.sigmoid(g)) * x / var
+        return tr.ode_drift(eps_hat, x, g, torch.tensor(gmax - gmin, dtype=x.dtype), "epsilon")
+
+    rng = np.random.default_rng(3)
+    B = 2
+    x_u8 = torch.tensor(rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8))
+    u = torch.tensor(rng.uniform(0, 1, (B, 3072)))
+    probe = torch.tensor(rng.integers(0, 2, (B, 3072)) * 2.0 - 1.0)
+    log_p, log_q, aux, nfev = tr.ode_likelihood(drift, lambda img: torch.zeros(B, 50, dtype=torch.float64), x_u8, u,
+                                                lambda: probe, dequantization="uniform", rtol=1e-8, atol=1e-8)
+    data = tr.encode(x_u8.double()).reshape(B, -1) + 2 * (u - 0.5) / 256
+    var0 = s2 + (1 - s2) / (1 + math.exp(-gmin))
+    var1 = s2 + (1 - s2) / (1 + math.exp(-gmax))
+    expect = tr.prior_logp(data * math.sqrt(var1 / var0)) + 0.5 * 3072 * math.log(var1 / var0)
+    assert log_q is None and torch.allclose(aux, torch.zeros(B, dtype=torch.float64), atol=1e-12) and nfev > 10
+    assert torch.allclose(log_p, expect, rtol=1e-7)
+    # offsets of the reference: uniform -> log2(128) = 7 bits; tn, num_is = 1 includes the entropy correction
+    assert tr.bpd_offset("uniform", 1) == 7.0
+    ls = 0.5 * (-13.3 - math.log1p(math.exp(-13.3)))
+    assert abs(tr.bpd_offset("tn", 20) + ls / math.log(2)) < 1e-12
+    assert abs(tr.bpd_offset("tn", 1) + (0.5 * (1 + math.log(2 * math.pi)) - 0.01522 + ls) / math.log(2)) < 1e-12
+    emb = tr.logits_to_embeddings(torch.tensor(rng.standard_normal((4, 50))))
+    assert torch.equal(emb.sum(dim=1), torch.full((4,), 15.0, dtype=torch.float64))
