@@ -1,4 +1,4 @@
-"""Exact-likelihood evaluator throughput at the flagship configuration (cifar10-conditioned: E = 256, 32-block U-Nets):
+"""Exact-likelihood evaluator throughput at the flagship configuration (cifar10-conditioned: E = 128, 32-block U-Nets):
 time per function evaluation of the probability-flow ODE (U-Net forward + input-gradient pass + drift / divergence
 kernels) and per Dormand-Prince step incl. the controller's one scalar read-back.
     python tools/ode_bench.py [--batch 64] [--steps 3]"""

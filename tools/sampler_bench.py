@@ -1,4 +1,4 @@
-"""Ancestral sampler throughput at the flagship configuration (cifar10-conditioned: E = 256, 32 + 32 U-Net blocks):
+"""Ancestral sampler throughput at the flagship configuration (cifar10-conditioned: E = 128, sm_n_layer = 32):
 reverse steps per second and images per second for a batch of B samples, T timed steps (the reference runs 1000).
     python tools/sampler_bench.py [--batch 64] [--steps 20]"""
 import argparse
