@@ -35,6 +35,39 @@ __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long s
   v[3] = (r.w < thr) ? v[3] * inv : 0.f;
 }
 
+// 4 keep-bits (bit e = element e kept) of one float4: same Philox draw and integer compare as drop4
+__device__ __forceinline__ unsigned drop_bits4(uint32_t thr, unsigned long long seed, unsigned long long ctr) {
+  const Philox4 r = philox4x32_10(seed, ctr, 0ull);
+  return (r.x < thr ? 1u : 0u) | (r.y < thr ? 2u : 0u) | (r.z < thr ? 4u : 0u) | (r.w < thr ? 8u : 0u);
+}
+// v = kept ? v * inv : 0 from precomputed keep-bits (bit position `pos` is a compile-time constant after unrolling)
+__device__ __forceinline__ float apply_bit(float v, float inv, unsigned bits, int pos) {
+  const int m = (int)(bits << (31 - pos)) >> 31;                 // all ones / zero
+  return __uint_as_float(__float_as_uint(v * inv) & (unsigned)m);
+}
+// sigmoid / SiLU / SiLU' on the hardware exp2 and reciprocal (1 ulp each): the accurate expf + IEEE division cost
+// ~25 VALU slots per element, which made these HBM-shaped kernels VALU-bound (19 us of memory time + 26 us of
+// arithmetic per launch, measured); relative error ~3e-7
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
+__device__ __forceinline__ float silu_grad_fast(float x) {
+  const float sg = sigmoid_fast(x);
+  return sg * (1.f + x * (1.f - sg));
+}
+
+// two-wide arithmetic: clang lowers <2 x float> mul / add / fma to v_pk_*_f32 (one issue slot for two elements)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lo2(const f32x4& v) { return f32x2{v[0], v[1]}; }
+__device__ __forceinline__ f32x2 hi2(const f32x4& v) { return f32x2{v[2], v[3]}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 sigmoid_fast2(f32x2 x) {
+  const f32x2 t = x * -1.4426950408889634f;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
+  return f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
 // Sums `a`,`b` over all threads of the block that share quad-group id gq = quad / qpg.
 // red: 2 * 4 * 8 floats.  Returns the group totals for this thread's group.
 __device__ __forceinline__ void group_reduce2(float& a, float& b, int quad, int qpg, float* red) {
@@ -69,8 +102,22 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   f32x4 v[NP];
   float s1 = 0.f, s2 = 0.f;
 #pragma clang loop unroll(full)
+  for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(prow + 32 * i) * ld);
+  // the dropout mask does not depend on the data: draw it (10 Philox rounds per float4, quarter-rate integer
+  // multiplies) while the slab is still in flight, 4 bits per float4
+  unsigned mb[NP / 8];
+  const bool dropping = p.keep < 1.f;
+  if (dropping) {
+    const uint32_t thr = (uint32_t)((double)p.keep * 4294967296.0);
+#pragma clang loop unroll(full)
+    for (int i = 0; i < NP; ++i) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + (prow + 32 * i)) * Ct + (c0 + quad * 4)) >> 2;
+      const unsigned bits = drop_bits4(thr, p.seed, p.offset + idx4) << ((i & 7) * 4);
+      mb[i >> 3] = (i & 7) ? (mb[i >> 3] | bits) : bits;
+    }
+  }
+#pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) {
-    v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(prow + 32 * i) * ld);
     s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     s2 += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
   }
@@ -86,18 +133,23 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
   float* dst = p.y + (size_t)b * HW * Ct + c;
   unsigned amax = 0;
+  const float inv_keep = 1.f / p.keep;
+  const f32x2 sc_lo = lo2(ga) * rstd, sc_hi = hi2(ga) * rstd;
 #pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) {
     const int px = prow + 32 * i;
     f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float u = (v[i][e] - mean) * (rstd * ga[e]) + be[e];
-      o[e] = p.act ? silu_f(u) : u;
+    {
+      f32x2 u0 = fma2(lo2(v[i]) - mean, sc_lo, lo2(be)), u1 = fma2(hi2(v[i]) - mean, sc_hi, hi2(be));
+      if (p.act) {
+        u0 = u0 * sigmoid_fast2(u0);
+        u1 = u1 * sigmoid_fast2(u1);
+      }
+      o = f32x4{u0[0], u0[1], u1[0], u1[1]};
     }
-    if (p.keep < 1.f) {
-      const unsigned long long idx4 = (((unsigned long long)b * HW + px) * Ct + c) >> 2;
-      drop4(o, p.keep, p.seed, p.offset + idx4);
+    if (dropping) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = apply_bit(o[e], inv_keep, mb[i >> 3], (i & 7) * 4 + e);
     }
     *reinterpret_cast<f32x4*>(dst + (size_t)px * Ct) = o;
 #pragma unroll
@@ -248,29 +300,46 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     xh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)px * ld));
     gq[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct));
   }
-  float s1 = 0.f, s2 = 0.f;
-  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+  // the forward pass's dropout mask, re-drawn while the two slabs are in flight (see gn_fwd_kernel)
+  unsigned mb[NPB / 8];
+  const bool dropping = p.keep < 1.f;
+  const float inv_keep = 1.f / p.keep;
+  if (dropping) {
+    const uint32_t thr = (uint32_t)((double)p.keep * 4294967296.0);
 #pragma unroll
-  for (int i = 0; i < NPB; ++i) {
-    const int px = prow + 64 * i;
-    if (p.keep < 1.f) {
-      const unsigned long long idx4 = (((unsigned long long)b * HW + px) * Ct + c) >> 2;
-      drop4(gq[i], p.keep, p.seed, p.offset + idx4);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xhat = (xh[i][e] - mean) * rstd;
-      const float u = xhat * ga[e] + be[e];
-      const float gu = p.act ? gq[i][e] * silu_grad_f(u) : gq[i][e];
-      dg[e] += gu * xhat;
-      db[e] += gu;
-      const float dxh = gu * ga[e];
-      s1 += dxh;
-      s2 += dxh * xhat;
-      xh[i][e] = xhat;
-      gq[i][e] = dxh;
+    for (int i = 0; i < NPB; ++i) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + (prow + 64 * i)) * Ct + c) >> 2;
+      const unsigned bits = drop_bits4(thr, p.seed, p.offset + idx4) << ((i & 7) * 4);
+      mb[i >> 3] = (i & 7) ? (mb[i >> 3] | bits) : bits;
     }
   }
+  f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f}, dg_lo = {0.f, 0.f}, dg_hi = {0.f, 0.f}, db_lo = {0.f, 0.f}, db_hi = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NPB; ++i) {
+    if (dropping) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gq[i][e] = apply_bit(gq[i][e], inv_keep, mb[i >> 3], (i & 7) * 4 + e);
+    }
+    {
+      f32x2 xa = (lo2(xh[i]) - mean) * rstd, xb = (hi2(xh[i]) - mean) * rstd;
+      f32x2 ga_ = lo2(gq[i]), gb_ = hi2(gq[i]);
+      if (p.act) {
+        const f32x2 ua = fma2(xa, lo2(ga), lo2(be)), ub = fma2(xb, hi2(ga), hi2(be));
+        const f32x2 sa = sigmoid_fast2(ua), sb = sigmoid_fast2(ub);
+        ga_ = ga_ * (sa * fma2(ua, 1.f - sa, f32x2{1.f, 1.f}));      // g * silu'(u)
+        gb_ = gb_ * (sb * fma2(ub, 1.f - sb, f32x2{1.f, 1.f}));
+      }
+      dg_lo = fma2(ga_, xa, dg_lo); dg_hi = fma2(gb_, xb, dg_hi);
+      db_lo += ga_; db_hi += gb_;
+      const f32x2 da = ga_ * lo2(ga), dbv = gb_ * hi2(ga);
+      s1v += da + dbv;
+      s2v = fma2(da, xa, fma2(dbv, xb, s2v));
+      xh[i] = f32x4{xa[0], xa[1], xb[0], xb[1]};
+      gq[i] = f32x4{da[0], da[1], dbv[0], dbv[1]};
+    }
+  }
+  float s1 = s1v[0] + s1v[1], s2 = s2v[0] + s2v[1];
+  f32x4 dg = {dg_lo[0], dg_lo[1], dg_hi[0], dg_hi[1]}, db = {db_lo[0], db_lo[1], db_hi[0], db_hi[1]};
   // reduce over the 64 prow lanes: inside the wave (lane bits 3..5), then across the 8 waves through LDS
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) {
@@ -307,8 +376,10 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
   for (int i = 0; i < NPB; ++i) {
     const int px = prow + 64 * i;
     f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = rstd * (gq[i][e] - m1 - xh[i][e] * m2);
+    {
+      const f32x2 oa = (lo2(gq[i]) - m1 - lo2(xh[i]) * m2) * rstd, ob = (hi2(gq[i]) - m1 - hi2(xh[i]) * m2) * rstd;
+      o = f32x4{oa[0], oa[1], ob[0], ob[1]};
+    }
     float* dp = dxp + (size_t)px * ld;
     if (p.accumulate) {
       const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
