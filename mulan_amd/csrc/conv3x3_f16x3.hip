@@ -412,6 +412,10 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
 
   const bool stamp = p.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
   if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
+  // dev-only timeline: [64 + 2 blk] = start, [65 + 2 blk] = end of every block in 100 MHz ticks (tools/kbench.py timeline)
+  const unsigned tl_blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool tl = p.stamps && threadIdx.x == 0 && tl_blk < 1024;
+  if (tl) p.stamps[64 + 2 * tl_blk] = __builtin_amdgcn_s_memrealtime();
   f16x8 bq[3][NT][2];
   f16x8 afc[MT][2], afn[MT][2];
   gload_patch(0);
@@ -538,6 +542,7 @@ __global__ __launch_bounds__(256) void conv3x3_f16x3_v2_kernel(ConvArgsH p) {
     if (part == 0 && tid >= nparts && tid < 16) p.ymax[b * 16 + tid] = 0u;
   }
   if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+  if (tl) p.stamps[65 + 2 * tl_blk] = __builtin_amdgcn_s_memrealtime();
 }
 
 // out[r][c] = fp32 bits of the maximum |x| over part c of row r (16 parts per row; non-negative floats order like

@@ -132,6 +132,37 @@ def stamps(batch, C=128, N=128, tune="", mode=None):
           f"(pure MFMA per chunk = 18432 cyc per wave); in-kernel clock {(t[23] - t[0]) / max(1, (t[31] - t[30])) * 0.1:.3f} GHz")
 
 
+def timeline(batch=128, C=128, N=128):
+    """dev: start / end of every block of one conv3x3 launch (s_memrealtime, 10 ns ticks)"""
+    import numpy as np
+    ops.lib.load()
+    buf = torch.zeros(64 + 2048, dtype=torch.int64, device="cuda")
+    x, w = torch.randn(batch, 1024, C, device="cuda"), torch.randn(3, 3, C, N, device="cuda") * 0.05
+    bias, cb, res = torch.randn(N, device="cuda"), torch.randn(batch, N, device="cuda"), torch.randn(batch, 1024, N, device="cuda")
+    for _ in range(30):
+        ops.conv3x3_raw(x, w, bias, cb, res)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    call("mulan_set_debug_buffer", ptr(buf))
+    e0.record()
+    ops.conv3x3_raw(x, w, bias, cb, res)
+    e1.record()
+    torch.cuda.synchronize()
+    call("mulan_set_debug_buffer", None)
+    t = buf.cpu().numpy()[64:].reshape(-1, 2)
+    t = t[t[:, 0] > 0]
+    st, en = (t[:, 0] - t[:, 0].min()) * 0.01, (t[:, 1] - t[:, 0].min()) * 0.01      # us
+    order = np.argsort(st)
+    n = len(st)
+    dur = en - st
+    print(f"timeline B={batch} C={C} N={N}: {n} blocks, events {e0.elapsed_time(e1) * 1e3:.1f} us (incl. maxima/pack launches)")
+    print(f"  starts: first gen (0..{n // 2 - 1}) min {st[order[0]]:.1f} p50 {st[order[n // 4]]:.1f} max {st[order[n // 2 - 1]]:.1f} us;"
+          f" second gen min {st[order[n // 2]]:.1f} p50 {st[order[3 * n // 4]]:.1f} max {st[order[-1]]:.1f} us")
+    print(f"  block duration: min {dur.min():.1f} p50 {np.median(dur):.1f} max {dur.max():.1f} us; first-gen p50 "
+          f"{np.median(dur[order[:n // 2]]):.1f}, second-gen p50 {np.median(dur[order[n // 2:]]):.1f}")
+    print(f"  ends: first {en.min():.1f} p50 {np.median(en):.1f} last {en.max():.1f} us")
+
+
 def wstamps(batch=128, C=128, N=128):
     ops.lib.load()
     ops.CONV_MODE = "f16x3"
@@ -163,7 +194,11 @@ def wstamps(batch=128, C=128, N=128):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "wstamps":
+    if len(sys.argv) > 1 and sys.argv[1] == "timeline":
+        timeline()
+        timeline(batch=64)
+        timeline(C=256)
+    elif len(sys.argv) > 1 and sys.argv[1] == "wstamps":
         wstamps()
         wstamps(C=256)
     elif len(sys.argv) > 1 and sys.argv[1] == "stamps":
