@@ -1,6 +1,6 @@
 """world_size-2 gloo tests (CPU) of the N>1 path: the bucketed gradient reducer over the flat buffer equals the
 big-batch gradient, scalar metrics are averaged like lax.pmean, and the sharded dense-eval reduction is
-partition invariant.  (RCCL is the same torch.distributed API with backend 'nccl'.)"""
+partition invariant, the sampler's all-gather concatenates in rank order.  (RCCL is the same torch.distributed API with backend 'nccl'.)"""
 import os
 import socket
 import sys
@@ -67,6 +67,10 @@ def _worker(rank, world, port, q):
     mine = vals[rank::world]
     mean, n = _reduce_mean(sum(mine), len(mine), "cpu")
     ok = ok and n == 10 and abs(mean - 4.5) < 1e-12
+    # sample grids: every rank ends up with the samples of all ranks in rank order (jax.lax.all_gather of the reference)
+    mine_u8 = torch.full((3, 2, 2, 3), rank + 1, dtype=torch.uint8)
+    allg = parallel.all_gather_tensor(mine_u8)
+    ok = ok and allg.shape == (3 * world, 2, 2, 3) and all(int(allg[3 * r].max()) == r + 1 for r in range(world))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
