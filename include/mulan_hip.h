@@ -126,6 +126,18 @@ size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int
 int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
                                     float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
                                     mulan_stream_t stream);
+/* The attention products (lax.dot_general in dot_product_attention, model_vdm.py:775-796, and their autodiff) on the
+ * same kernels, one operand per image:  y[b] = x[b] @ W[b] (+ res) with W[b] packed by the batched pack (w: batch
+ * operands [K, N], or [N, K] with transpose = 1; wmax [batch][16] = mulan_absmax_rows(w, batch rows)) at
+ * wp + b * K * N * 4 bytes;  out[b] = x[b]^T @ dy[b] ([C, N] per image) from the planes the forward products hand on
+ * (S = Q K^T, O = P V, dP = dO V^T, dQ = dS K by the first form; dV = P^T dO, dK = dS^T Q by the second). */
+int mulan_linear_pack_f16x3_batched(const float* w, void* wp, const unsigned* wmax, int K, int N, int transpose,
+                                    int batch, mulan_stream_t stream);
+int mulan_linear_f16x3_batched(const float* x, const unsigned* xmax, int K, const void* wp, const unsigned* wmax,
+                               const float* res, float* y, void* xs, int N, int M, int rows_per_img,
+                               mulan_stream_t stream);
+int mulan_bmm_tn_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax, float* out,
+                              int B, int H, int W, int C, int N, mulan_stream_t stream);
 
 /* ---- batched GEMM:  C[b] = alpha * op(A[b]) op(B[b]) + bias[n] + beta * R[b] ------------------
  * nn.Dense / nn.DenseGeneral and lax.dot_general call sites: nin_shortcut (model_vdm.py:652-653),
@@ -172,6 +184,11 @@ int mulan_colsum_pair(const float* x, float* out0, float* out1, int seg, int C, 
 /* row softmax of the attention weights (model_vdm.py:786) and its backward */
 int mulan_softmax_fwd(const float* x, float* y, size_t rows, int cols, mulan_stream_t stream);
 int mulan_softmax_bwd(const float* p, const float* dp, float* ds, size_t rows, int cols, mulan_stream_t stream);
+/* softmax(alpha x) and its gradient w.r.t. x (the 1/sqrt(C) of dot_product_attention, model_vdm.py:775-779, folded in);
+ * rowmax: optional [rows] receiving max |ds| of each row (mulan_absmax_rows over it yields per-image maxima) */
+int mulan_softmax_scaled_fwd(const float* x, float* y, size_t rows, int cols, float alpha, mulan_stream_t stream);
+int mulan_softmax_scaled_bwd(const float* p, const float* dp, float* ds, size_t rows, int cols, float alpha,
+                             float* rowmax, mulan_stream_t stream);
 /* Base2FourierFeatures(start=6, stop=8) + concat, padded to 16 channels (model_vdm.py:341-343,812-829) */
 int mulan_fourier_fwd(const float* z, float* out, size_t npix, mulan_stream_t stream);
 int mulan_fourier_bwd(const float* z, const float* dout, float* dz, size_t npix, int accumulate,

@@ -1321,3 +1321,22 @@ MULAN_API int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xm
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
   MULAN_CHECK_LAUNCH();
 }
+
+// out[b] = x[b]^T @ dy[b] per image:  [C, N] = sum over the H * 32 rows of image b of x[row, :]^T dy[row, :], both
+// operands as split planes (the by-products of mulan_linear_f16x3 / _batched) scaled with xmax[b] / dymax[b].  The
+// attention core's dV = P^T dO and dK = dS^T Q (autodiff of ldm/model_vdm.py:775-796) on the dense weight-gradient
+// kernel with one slab per image and no slab reduction.
+MULAN_API int mulan_bmm_tn_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
+                                        float* out, int B, int H, int W, int C, int N, hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0 || !xs || !dys || !xmax || !dymax || !out ||
+      (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
+    return (int)hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+  if (e != hipSuccess) return (int)e;
+  WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, out,
+               B, H, C, N, B, g_mulan_debug_buffer};
+  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<1>, dim3(B, 1, (C / WG3_T) * (N / WG3_T)), dim3(256),
+                     WG3_SMEM + 64, stream, a);
+  MULAN_CHECK_LAUNCH();
+}

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
 }
 
 // y[row] = softmax(x[row]) over `cols` (<= 4096, multiple of 4); one 256-thread block per row.
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int cols) {
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int cols,
+                                                          float alpha) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   const float* xr = x + row * cols;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   for (int i = 0; i < 4; ++i) {
     const int q = threadIdx.x + i * 256;
     if (q < nv) {
-      v[i] = *reinterpret_cast<const f32x4*>(xr + q * 4);
+      v[i] = *reinterpret_cast<const f32x4*>(xr + q * 4) * alpha;
       mx = fmaxf(mx, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
     }
   }
@@ -123,8 +124,12 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
   }
 }
 // ds = p * (dp - sum_j dp_j p_j)
+// ds = alpha p (dp - sum p dp)  (gradient w.r.t. the unscaled logits of softmax(alpha x)); rowmax (optional):
+// [rows] maximum of |ds| of each row (mulan_absmax_rows over it gives the per-image maxima; atomics on a handful of
+// addresses cost 0.5 ms here, measured)
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
-                                                          float* __restrict__ ds, int cols) {
+                                                          float* __restrict__ ds, int cols, float alpha,
+                                                          float* __restrict__ rowmax) {
   __shared__ float red[4];
   const size_t row = blockIdx.x;
   const float* pr = p + row * cols;
@@ -143,15 +148,23 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     }
   }
   dot = block_sum_256(dot, red);
+  unsigned amax = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = threadIdx.x + i * 256;
     if (q < nv) {
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = pv[i][e] * (dv[i][e] - dot);
+      for (int e = 0; e < 4; ++e) {
+        o[e] = alpha * (pv[i][e] * (dv[i][e] - dot));
+        amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+      }
       *reinterpret_cast<f32x4*>(sr + q * 4) = o;
     }
+  }
+  if (rowmax) {
+    const float m = block_max_256(__uint_as_float(amax), red);
+    if (threadIdx.x == 0) rowmax[row] = m;
   }
 }
 
@@ -286,13 +299,28 @@ MULAN_API int mulan_colsum_pair(const float* x, float* out0, float* out1, int se
 }
 MULAN_API int mulan_softmax_fwd(const float* x, float* y, size_t rows, int cols, hipStream_t stream) {
   if (cols % 4 != 0 || cols > 4096 || rows == 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, y, cols);
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, y, cols, 1.f);
   MULAN_CHECK_LAUNCH();
 }
 MULAN_API int mulan_softmax_bwd(const float* p, const float* dp, float* ds, size_t rows, int cols,
                                 hipStream_t stream) {
   if (cols % 4 != 0 || cols > 4096 || rows == 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, p, dp, ds, cols);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, p, dp, ds, cols, 1.f,
+                     static_cast<float*>(nullptr));
+  MULAN_CHECK_LAUNCH();
+}
+// softmax(alpha x) and its gradient w.r.t. x (the 1/sqrt(C) of dot_product_attention, ldm/model_vdm.py:775-779, folded
+// in); rowmax: optional [rows] receiving max |ds| of each row
+MULAN_API int mulan_softmax_scaled_fwd(const float* x, float* y, size_t rows, int cols, float alpha,
+                                       hipStream_t stream) {
+  if (cols % 4 != 0 || cols > 4096 || rows == 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, x, y, cols, alpha);
+  MULAN_CHECK_LAUNCH();
+}
+MULAN_API int mulan_softmax_scaled_bwd(const float* p, const float* dp, float* ds, size_t rows, int cols, float alpha,
+                                       float* rowmax, hipStream_t stream) {
+  if (cols % 4 != 0 || cols > 4096 || rows == 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, stream, p, dp, ds, cols, alpha, rowmax);
   MULAN_CHECK_LAUNCH();
 }
 MULAN_API int mulan_fourier_fwd(const float* z, float* out, size_t npix, hipStream_t stream) {

@@ -53,6 +53,8 @@ struct LinArgs {
   float* y1; float* y2;                        // [M, N1], [M, N2]
   int M, K1, K2, N1, N2, rows_per_img;
   unsigned char* xs;                           // optional by-product: split planes of [x1 | x2], [B][K/16][rows][2][16] fp16
+  size_t wp_img_stride;                        // bytes between the packed weights of consecutive images (0: shared)
+  int wmax_per_img;                            // wmax is [B][16] (one maximum per image) instead of [1][16]
 };
 
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
   if (p.x2) mb = max(mb, row_max16(p.x2max, b));
   float sx, inv_x, sw, inv_w;
   scale_of(mb, sx, inv_x);
-  scale_of(row_max16(p.wmax, 0), sw, inv_w);
+  scale_of(row_max16(p.wmax, p.wmax_per_img ? b : 0), sw, inv_w);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
     }
   };
   // weight fragments of a stage: [k step j][n tile][plane]
-  const unsigned char* bbase = p.wp + (size_t)(n0 + wn * 64 + li) * 64 + lh * 16;
+  const unsigned char* bbase = p.wp + (size_t)b * p.wp_img_stride + (size_t)(n0 + wn * 64 + li) * 64 + lh * 16;
   const size_t chunk_stride = (size_t)N * 64;
   auto gload_b = [&](f16x8 (&bs)[2][NT][2], int s) {
 #pragma unroll
@@ -218,11 +220,14 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
 
 // wp[cc][o][plane][k] = split2( s_w * Wl[cc*16 + k][o] ),  Wl[kin][o] = w[kin][o] (w row-major [Kin, Nout]) or, with
 // transpose, w[o][kin] (w row-major [Nout, Kin]: the weight of the input-gradient product dy @ w^T)
+// blockIdx.y = image of a batched call (one [Kin, Nout] operand and one maximum per image)
 __global__ void linear_pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp,
                                          const unsigned* __restrict__ wmax, int Kin, int Nout, int transpose) {
   const size_t total = (size_t)Kin * Nout;
+  w += (size_t)blockIdx.y * total;
+  wp += (size_t)blockIdx.y * total * 2;
   float sw, inv_w;
-  scale_of(row_max16(wmax, 0), sw, inv_w);
+  scale_of(row_max16(wmax, blockIdx.y), sw, inv_w);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % 16);
     const size_t r = i / 16;
@@ -258,17 +263,47 @@ MULAN_API int mulan_linear_pack_f16x3(const float* w, void* wp, const unsigned* 
 // K1 % 32 == 0, K2 % 32 == 0, N1 % 128 == 0, N2 % 128 == 0 (x2 / y2 optional: K2 = 0 / N2 = 0); res only with N2 = 0.
 // xs (optional, M * (K1 + K2) * 4 bytes): receives the split planes of [x1 | x2] (scaled with max(x1max, x2max) per
 // image), the input format of mulan_linear_wgrad_f16x3_planes.
-MULAN_API int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1,
-                                 int K2, const void* wp, const unsigned* wmax, const float* bias, const float* res,
-                                 float* y1, float* y2, void* xs, int N1, int N2, int M, int rows_per_img,
-                                 hipStream_t stream) {
+static int linear_f16x3_launch(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1,
+                               int K2, const void* wp, const unsigned* wmax, const float* bias, const float* res,
+                               float* y1, float* y2, void* xs, int N1, int N2, int M, int rows_per_img,
+                               size_t wp_img_stride, int wmax_per_img, hipStream_t stream) {
   if (M <= 0 || M % TM != 0 || rows_per_img <= 0 || rows_per_img % TM != 0 || M % rows_per_img != 0 || K1 <= 0 ||
       K1 % SK != 0 || K2 < 0 || K2 % SK != 0 || N1 <= 0 || N1 % TN != 0 || N2 < 0 || N2 % TN != 0 || !x1 || !x1max ||
       !wp || !wmax || !y1 || (K2 > 0 && (!x2 || !x2max)) || (N2 > 0 && (!y2 || res)))
     return (int)hipErrorInvalidValue;
   if (xs && (size_t)M * (K1 + K2) * 4 >= 0x80000000ull) return (int)hipErrorInvalidValue;
   LinArgs a{x1, K2 > 0 ? x2 : nullptr, x1max, x2max, static_cast<const unsigned char*>(wp), wmax, bias, res, y1, y2,
-            M, K1, K2, N1, N2, rows_per_img, static_cast<unsigned char*>(xs)};
+            M, K1, K2, N1, N2, rows_per_img, static_cast<unsigned char*>(xs), wp_img_stride, wmax_per_img};
   hipLaunchKernelGGL(linear_f16x3_kernel, dim3(M / TM, (N1 + N2) / TN), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, const unsigned* x2max, int K1,
+                                 int K2, const void* wp, const unsigned* wmax, const float* bias, const float* res,
+                                 float* y1, float* y2, void* xs, int N1, int N2, int M, int rows_per_img,
+                                 hipStream_t stream) {
+  return linear_f16x3_launch(x1, x1max, x2, x2max, K1, K2, wp, wmax, bias, res, y1, y2, xs, N1, N2, M, rows_per_img, 0, 0,
+                             stream);
+}
+
+// Batched form for the attention products (ldm/model_vdm.py:775-796): image b (rows_per_img rows of x) is multiplied
+// by its own operand, packed by mulan_linear_pack_f16x3_batched at wp + b * K * N * 4 bytes, with its own maximum
+// wmax[b][16]:  y[b] = x[b] @ W[b]  (+ res).  xs as in mulan_linear_f16x3.
+MULAN_API int mulan_linear_f16x3_batched(const float* x, const unsigned* xmax, int K, const void* wp,
+                                         const unsigned* wmax, const float* res, float* y, void* xs, int N, int M,
+                                         int rows_per_img, hipStream_t stream) {
+  return linear_f16x3_launch(x, xmax, nullptr, nullptr, K, 0, wp, wmax, nullptr, res, y, nullptr, xs, N, 0, M,
+                             rows_per_img, (size_t)K * N * 4, 1, stream);
+}
+
+// batch operands w[b] ([K, N], or [N, K] with transpose) -> packed operands of mulan_linear_f16x3_batched;
+// wmax [batch][16] = mulan_absmax_rows(w, batch rows)
+MULAN_API int mulan_linear_pack_f16x3_batched(const float* w, void* wp, const unsigned* wmax, int K, int N, int transpose,
+                                              int batch, hipStream_t stream) {
+  if (K <= 0 || N <= 0 || K % 16 != 0 || !wmax || batch <= 0 || batch > 65535) return (int)hipErrorInvalidValue;
+  const size_t total = (size_t)K * N;
+  const int blocks = (int)((total + 255) / 256 > 256 ? 256 : (total + 255) / 256);
+  hipLaunchKernelGGL(linear_pack_f16x3_kernel, dim3(blocks, batch), dim3(256), 0, stream, w, static_cast<_Float16*>(wp),
+                     wmax, K, N, transpose);
   MULAN_CHECK_LAUNCH();
 }

@@ -50,6 +50,11 @@ SIGNATURES = {
     "mulan_colsum_pair": [P, P, P, I, I, P],
     "mulan_softmax_fwd": [P, P, Z, I, P],
     "mulan_softmax_bwd": [P, P, P, Z, I, P],
+    "mulan_softmax_scaled_fwd": [P, P, Z, I, F, P],
+    "mulan_softmax_scaled_bwd": [P, P, P, Z, I, F, P, P],
+    "mulan_linear_pack_f16x3_batched": [P, P, P, I, I, I, I, P],
+    "mulan_linear_f16x3_batched": [P, P, I, P, P, P, P, P, I, I, I, P],
+    "mulan_bmm_tn_f16x3_planes": [P, P, P, P, P, I, I, I, I, I, P],
     "mulan_fourier_fwd": [P, P, Z, P],
     "mulan_fourier_bwd": [P, P, P, Z, I, P],
     "mulan_temb_fwd": [P, P, I, I, I, I, P],

@@ -748,21 +748,79 @@ def group_norm_skip(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=
 
 
 # ----------------------------------------------------------------------------- attention core
+ATTN_F16X3 = True      # attention products on the split-operand kernels in f16x3 mode (else the exact-fp32 MFMA GEMM)
+
+
+def _attn_fast_ok(q):
+    B, S, C = q.shape
+    return CONV_MODE == "f16x3" and ATTN_F16X3 and S == HW and C % 128 == 0 and B * S * S * 4 < 2 ** 31
+
+
+def _const_max(B, value, device):
+    """[B,16] maxima array holding an a-priori bound (softmax outputs are <= 1): the split scheme is accurate relative
+    to each element, so a loose bound costs nothing until values fall 2^-24 below it"""
+    import struct
+    return torch.full((B, MAX_PARTS), struct.unpack('<i', struct.pack('<f', float(value)))[0], device=device,
+                      dtype=torch.int32)
+
+
+def _pack_batched(w, transpose, wmax):
+    """w [B, K, N] (or [B, N, K] with transpose) -> packed per-image operands of linear_batched_raw"""
+    B = w.shape[0]
+    K, N = (w.shape[2], w.shape[1]) if transpose else (w.shape[1], w.shape[2])
+    wp = torch.empty(B * K * N * 4, device=w.device, dtype=torch.uint8)
+    call("mulan_linear_pack_f16x3_batched", ptr(w), ptr(wp), ptr(wmax), K, N, int(transpose), B, stream())
+    return wp
+
+
+def linear_batched_raw(x, xmax, wp, wmax, N, planes=False):
+    """y[b] = x[b] @ W[b]: x [B, 1024, K]; returns y [B, 1024, N] (+ the split planes of x when planes=True)"""
+    B, R, K = x.shape
+    y = torch.empty((B, R, N), device=x.device, dtype=torch.float32)
+    xs = torch.empty(B * R * K * 4, device=x.device, dtype=torch.uint8) if planes else None
+    _timed("linear_f16x3_kernel(batched)", 2.0 * B * R * K * N,
+           lambda: call("mulan_linear_f16x3_batched", ptr(x), ptr(xmax), K, ptr(wp), ptr(wmax), None, ptr(y), ptr(xs), N,
+                        B * R, R, stream()))
+    return (y, xs) if planes else y
+
+
+def bmm_tn_planes_raw(xs, xmax, dys, dymax, B, C, N):
+    """out[b] = x[b]^T @ dy[b] -> [B, C, N] from split planes"""
+    out = torch.empty((B, C, N), device=xs.device, dtype=torch.float32)
+    _timed("bmm_tn_f16x3_planes", 2.0 * B * HW * C * N,
+           lambda: call("mulan_bmm_tn_f16x3_planes", ptr(xs), ptr(xmax), ptr(dys), ptr(dymax), ptr(out), B, H, W, C, N,
+                        stream()))
+    return out
+
+
 class AttentionFn(torch.autograd.Function):
-    """softmax((q / sqrt(C)) k^T) v for one head over 1024 positions (ldm/model_vdm.py:679-683,704-802)."""
+    """softmax((q / sqrt(C)) k^T) v for one head over 1024 positions (ldm/model_vdm.py:679-683,704-802).
+    f16x3 mode: S = q k^T, O = P v, dP = dO v^T and dQ = dS k run on the split-operand kernel with one packed operand
+    per image; the 1/sqrt(C) is folded into the softmax kernels."""
 
     @staticmethod
     def forward(ctx, q, k, v):
         q, k, v = _c(q), _c(k), _c(v)
         B, S, C = q.shape
         alpha = 1.0 / math.sqrt(C)
-        s = gemm_raw(q, k, S, S, C, transB=True, alpha=alpha, batch=B, sA=S * C, sB=S * C)
+        ctx.fast = _attn_fast_ok(q)
+        if not ctx.fast:
+            s = gemm_raw(q, k, S, S, C, transB=True, alpha=alpha, batch=B, sA=S * C, sB=S * C)
+            p = torch.empty_like(s)
+            call("mulan_softmax_fwd", ptr(s), ptr(p), B * S, S, stream())
+            del s
+            o = gemm_raw(p, v, S, C, S, batch=B, sA=S * S, sB=S * C)
+            ctx.save_for_backward(q, k, v, p)
+            return o.view(B, S, C)
+        qm, km, vm = cached_absmax(q), cached_absmax(k), cached_absmax(v)
+        s = linear_batched_raw(q, qm, _pack_batched(k, True, km), km, S)                   # q @ k^T
         p = torch.empty_like(s)
-        call("mulan_softmax_fwd", ptr(s), ptr(p), B * S, S, stream())
+        call("mulan_softmax_scaled_fwd", ptr(s), ptr(p), B * S, S, alpha, stream())
         del s
-        o = gemm_raw(p, v, S, C, S, batch=B, sA=S * S, sB=S * C)
+        o = linear_batched_raw(p, _const_max(B, 1.0, q.device), _pack_batched(v, False, vm), vm, C)   # P @ v
         ctx.save_for_backward(q, k, v, p)
-        return o.view(B, S, C)
+        ctx.aux = (km, vm)
+        return o
 
     @staticmethod
     @once_differentiable
@@ -771,13 +829,30 @@ class AttentionFn(torch.autograd.Function):
         do = _c(do)
         B, S, C = q.shape
         alpha = 1.0 / math.sqrt(C)
-        dv = gemm_raw(p, do, S, C, S, transA=True, batch=B, sA=S * S, sB=S * C).view(B, S, C)
-        dp = gemm_raw(do, v, S, S, C, transB=True, batch=B, sA=S * C, sB=S * C)
+        if not ctx.fast:
+            dv = gemm_raw(p, do, S, C, S, transA=True, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+            dp = gemm_raw(do, v, S, S, C, transB=True, batch=B, sA=S * C, sB=S * C)
+            ds = torch.empty_like(dp)
+            call("mulan_softmax_bwd", ptr(p), ptr(dp), ptr(ds), B * S, S, stream())
+            del dp
+            dq = gemm_raw(ds, k, S, C, S, alpha=alpha, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+            dk = gemm_raw(ds, q, S, C, S, transA=True, alpha=alpha, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+            return dq, dk, dv
+        # The four products whose long operand is read once (S, O, dP, dQ) run on the split-operand kernel.  The two
+        # transposed ones (dV = P^T dO, dK = dS^T q) would need P and dS as split planes (mulan_bmm_tn_f16x3_planes):
+        # writing and re-reading those 4 B S^2-byte tensors costs as much as the exact-fp32 GEMM they would replace
+        # (measured at B = 128: 203 us + 150 us of plane traffic against 338 us), so they stay on the fp32 MFMA GEMM.
+        km, vm = ctx.aux
+        ctx.aux = None
+        dv = gemm_raw(p, do, S, C, S, transA=True, batch=B, sA=S * S, sB=S * C).view(B, S, C)      # P^T @ dO
+        dp = linear_batched_raw(do, cached_absmax(do), _pack_batched(v, True, vm), vm, S)          # dO @ v^T
         ds = torch.empty_like(dp)
-        call("mulan_softmax_bwd", ptr(p), ptr(dp), ptr(ds), B * S, S, stream())
+        rowmax = torch.empty((B, S), device=q.device, dtype=torch.float32)
+        call("mulan_softmax_scaled_bwd", ptr(p), ptr(dp), ptr(ds), B * S, S, alpha, ptr(rowmax), stream())
+        dsm = absmax_rows(rowmax)
         del dp
-        dq = gemm_raw(ds, k, S, C, S, alpha=alpha, batch=B, sA=S * S, sB=S * C).view(B, S, C)
-        dk = gemm_raw(ds, q, S, C, S, transA=True, alpha=alpha, batch=B, sA=S * S, sB=S * C).view(B, S, C)
+        dq = linear_batched_raw(ds, dsm, _pack_batched(k, False, km), km, C)                       # dS @ k
+        dk = gemm_raw(ds, q, S, C, S, transA=True, batch=B, sA=S * S, sB=S * C).view(B, S, C)      # dS^T @ q
         return dq, dk, dv
 
 

@@ -391,3 +391,84 @@ def test_f16x3_dense_weight_gradient_from_planes(ops, B, K1, K2, N):
         else:
             mag = np.einsum("bpk,bpn->kn", np.abs(f32(x)), np.abs(f32(dy)))
             assert float((np.abs(dw - ref) / mag).max()) < 3e-6
+
+
+# ------------------------------------------------------------------------------------------------ attention products
+@pytest.mark.parametrize("B,K,N,transpose", [(3, 128, 1024, True), (2, 1024, 128, False), (2, 256, 1024, True)])
+def test_f16x3_batched_linear_exact_on_integers(ops, B, K, N, transpose):
+    """y[b] = x[b] @ W[b] with one packed operand and one scale per image (the attention products): bit-exact on
+    integers, images of very different magnitude keep their own precision, the planes of x are handed on"""
+    rng = np.random.default_rng(K + N)
+    x = rng.integers(-4, 5, (B, 1024, K)).astype(np.float64)
+    w = rng.integers(-3, 4, (B, K, N)).astype(np.float64)
+    x[1] *= 2.0 ** 20                               # per-image scales: exactness must survive
+    w[1] *= 2.0 ** -30
+    ws = np.ascontiguousarray(w.transpose(0, 2, 1)) if transpose else w            # stored [B, N, K] when transposed
+    xd, wd = dev(x), dev(ws)
+    xm, wm = ops.absmax_rows(xd), ops.absmax_rows(wd)
+    y, xs = ops.linear_batched_raw(xd, xm, ops._pack_batched(wd, transpose, wm), wm, N, planes=True)
+    ref = np.einsum("brk,bkn->brn", x, w)
+    assert np.array_equal(y.cpu().double().numpy(), ref)
+    # out[b] = x[b]^T @ g[b] from the planes (dV = P^T dO / dK = dS^T q shapes need C, N multiples of 128)
+    if K % 128 == 0:
+        g = rng.integers(-3, 4, (B, 1024, 128)).astype(np.float64)
+        gd = dev(g)
+        gm = ops.absmax_rows(gd)
+        ident = dev(np.broadcast_to(np.eye(128), (B, 128, 128)).copy())
+        im = ops.absmax_rows(ident)
+        _, gs = ops.linear_batched_raw(gd, gm, ops._pack_batched(ident, False, im), im, 128, planes=True)
+        out = ops.bmm_tn_planes_raw(xs, xm, gs, gm, B, K, 128)
+        assert np.array_equal(out.cpu().double().numpy(), np.einsum("brk,brn->bkn", x, g))
+
+
+def test_scaled_softmax_and_gradient_maxima(ops):
+    rng = np.random.default_rng(3)
+    B, S = 2, 1024
+    alpha = 1.0 / math.sqrt(128)
+    s = rng.standard_normal((B * S, S)) * 30
+    dp = rng.standard_normal((B * S, S))
+    st = torch.tensor(s, requires_grad=True)
+    pt = torch.softmax(st * alpha, dim=-1)
+    pt.backward(torch.tensor(dp))
+    p = torch.empty(B * S, S).cuda()
+    ops.call("mulan_softmax_scaled_fwd", ops.ptr(dev(s)), ops.ptr(p), B * S, S, alpha, ops.stream())
+    assert np.abs(p.cpu().double().numpy() - pt.detach().numpy()).max() < 1e-6
+    g = torch.empty(B * S, S).cuda()
+    rm = torch.empty(B * S).cuda()
+    ops.call("mulan_softmax_scaled_bwd", ops.ptr(p), ops.ptr(dev(dp)), ops.ptr(g), B * S, S, alpha, ops.ptr(rm),
+             ops.stream())
+    ref = st.grad.numpy()
+    assert np.abs(g.cpu().double().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    assert np.array_equal(rm.cpu().numpy(), np.abs(g.cpu().numpy()).max(axis=1))
+
+
+@pytest.mark.parametrize("C", [128, 256])
+def test_attention_on_split_kernels(ops, monkeypatch, C):
+    """the f16x3 attention path against float64 autograd (same bar as the fp32 GEMM path, tests/test_gpu_kernels.py)
+    and against that path; one image 2^12 times larger than the other"""
+    rng = np.random.default_rng(C)
+    B, S = 2, 1024
+    q, k, v = (rng.standard_normal((B, S, C)) for _ in range(3))
+    v[1] *= 4096.0
+    do = rng.standard_normal((B, S, C))
+    qt, kt, vt = (torch.tensor(a, requires_grad=True) for a in (q, k, v))
+    o = torch.einsum("bqk,bkc->bqc", torch.softmax(torch.einsum("bqc,bkc->bqk", qt / math.sqrt(C), kt), -1), vt)
+    o.backward(torch.tensor(do))
+    rel = lambda a, r: float(np.abs(a - r).max() / np.abs(r).max())
+    outs = {}
+    for fast in (True, False):
+        monkeypatch.setattr(ops, "ATTN_F16X3", fast)
+        g = [dev(a).requires_grad_() for a in (q, k, v)]
+        out = ops.attention(*g)
+        out.backward(dev(do))
+        outs[fast] = [out.detach().cpu().double().numpy()] + [a.grad.cpu().double().numpy() for a in g]
+    refs = [o.detach().numpy(), qt.grad.numpy(), kt.grad.numpy(), vt.grad.numpy()]
+    for b in range(B):                                   # per image: the small image is not drowned by the large one
+        for got_fast, got_f32, r in zip(outs[True], outs[False], refs):
+            assert rel(got_fast[b], r[b]) < 1e-5
+            assert rel(got_fast[b], r[b]) < 2.0 * rel(got_f32[b], r[b]) + 2e-6
+    # inference: no planes are produced, same output
+    monkeypatch.setattr(ops, "ATTN_F16X3", True)
+    with torch.no_grad():
+        o2 = ops.attention(dev(q), dev(k), dev(v))
+    assert np.array_equal(o2.cpu().double().numpy(), outs[True][0])
