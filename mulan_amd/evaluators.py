@@ -169,6 +169,44 @@ def get_ode_likelihood_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, a
     return likelihood_fn
 
 
+def get_sample_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5, method='RK45', high_precision=False):
+    """get_sample_fn (ldm/notebook_utils.py:376-443): samples by integrating the probability-flow ODE from the prior
+    at t = 1 down to t = 0, conditioned on the hard top-k embedding of random normal logits.  Returns
+    sample_fn(rng, deterministic_noise=False, sample_size=32, t_grid=None) -> (z [sample_size, 32, 32, 3] fp32, nfev).
+    The reference evaluates the Hutchinson divergence at every step and throws it away; only the drift is computed
+    here (so hutchinson_type / deterministic_noise have no effect on the result, as in the reference)."""
+    from . import ops
+    from .ode import solve_fixed, solve_rk45
+    if method != 'RK45':
+        raise NotImplementedError("the reference only ever passes method='RK45'")
+    model, params, dev = experiment.model, experiment.orig_params, experiment.device
+    packer = experiment.state.param_packer("ema") if params is experiment.state.ema_params else None
+
+    def sample_fn(rng, deterministic_noise=False, sample_size=32, t_grid=None):
+        rng, logits_rng = rng.split()
+        emb, _ = ops.topk_hard(logits_rng.normal((sample_size, 50), dev), 15)
+        rng, _hutchinson_rng = rng.split()
+        rng, prior_rng = rng.split()
+        prior = prior_rng.normal((sample_size, 3072), dev)
+        if packer is not None:
+            packer.refresh()
+        try:
+            ctx = model.ode_context_from_embedding(params, emb)
+
+            def ode_func(t, y32, out):
+                model.reverse_ode(params, y32.view(sample_size, 3072), ctx, t, None, drift_out=out.view(sample_size, 3072))
+
+            y0 = prior.reshape(-1).double()
+            sol = (solve_rk45(ode_func, y0, (1.0, 0.0), rtol=rtol, atol=atol) if t_grid is None
+                   else solve_fixed(ode_func, y0, t_grid))
+        finally:
+            if packer is not None:
+                packer.invalidate()
+        return sol.y.float().view(sample_size, 32, 32, 3), sol.nfev
+
+    return sample_fn
+
+
 def _get_bpd_offset(dequantization, num_is):
     """notebook_utils._get_bpd_offset (:446-458)"""
     if dequantization == 'uniform':

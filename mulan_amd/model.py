@@ -446,6 +446,11 @@ class MulanVDM(_VDMBase):
             coeffs = poly_coefficients(params["gamma"], emb)
         return dict(emb=emb, kl=kl, coeffs=coeffs, logits=logits)
 
+    def ode_context_from_embedding(self, params, emb):
+        """the same context for a given k-hot embedding (the ODE sampler draws it from random logits)"""
+        with torch.no_grad():
+            return dict(emb=emb, kl=None, coeffs=poly_coefficients(params["gamma"], emb), logits=None)
+
     def _ode_mode(self):
         if self.parameterization == "velocity":
             return 1 if self.config.velocity_from_epsilon else 0
@@ -604,6 +609,7 @@ def _plain_reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_
     return drift, ops.ode_div(gx.reshape(B, D), gt, gp, hutch, 2, div_out)
 
 
+PlainVDM.ode_context_from_embedding = lambda self, params, emb: dict(emb=emb, kl=None, coeffs=None, logits=None)
 PlainVDM.apply_encoder = _plain_apply_encoder
 PlainVDM.ode_context = _plain_ode_context
 PlainVDM.reverse_ode = _plain_reverse_ode

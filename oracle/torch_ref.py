@@ -458,6 +458,22 @@ def ode_likelihood(drift_fn, encoder_fn, x_u8, u, probes, dequantization="tn", r
     return log_p, log_q_eps, aux, nfev
 
 
+def ode_sample(drift_fn, emb, prior, rtol=1e-5, atol=1e-5, dtype=torch.float64):
+    """sample_fn of get_sample_fn (ldm/notebook_utils.py:411-441) with the embedding and the prior draw given:
+    solve_ivp over (1, 0) of the drift alone (the reference's divergence value is discarded).  -> (z, nfev)"""
+    import numpy as np
+    from scipy import integrate
+    shp = (prior.shape[0], 32, 32, 3)
+
+    def ode_func(t, y):
+        xt = torch.tensor(y, dtype=torch.float32).to(dtype).reshape(shp)
+        with torch.no_grad():
+            return drift_fn(xt, emb, t).reshape(-1).numpy()
+
+    sol = integrate.solve_ivp(ode_func, (1, 0), prior.reshape(-1).to(dtype).numpy(), rtol=rtol, atol=atol, method="RK45")
+    return torch.tensor(sol.y[:, -1], dtype=dtype).reshape(shp), sol.nfev
+
+
 # ------------------------------------------------------------------------------ parameter trees
 def tree_map(fn, tree):
     return {k: tree_map(fn, v) if isinstance(v, dict) else fn(v) for k, v in tree.items()}
