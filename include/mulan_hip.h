@@ -216,6 +216,9 @@ int mulan_ancestral_step(const float* zt, const float* net, const float* gt, con
  * 256 decoder bins of EncDec.decode (model_vdm.py:282-296) at z_0 / sqrt(1 - sigmoid(g_0)). */
 int mulan_decode_argmax(const float* z0, const float* g0, unsigned char* out, size_t n, int g_per_sample,
                         mulan_stream_t stream);
+/* sample_softmax = True: jax.random.categorical over the same logits (Gumbel-max with Philox4x32-10 draws) */
+int mulan_decode_sample(const float* z0, const float* g0, unsigned char* out, size_t n, int g_per_sample,
+                        unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
 /* out[r] = mean(x[r, :])  (VDM._get_score_model_gt, model_mulan_velocity.py:141-146) */
 int mulan_rowmean(const float* x, float* out, int rows, int cols, mulan_stream_t stream);
 
@@ -246,7 +249,7 @@ int mulan_rk_init_norms(const double* y0, const float* f0, const float* f1, doub
                         double* out3, size_t n, mulan_stream_t stream);
 /* out[r] = log N(x[r, :]; 0, I)   (notebook_utils._prior_logp, :218-221) */
 int mulan_normal_logp(const float* x, float* out, int rows, int cols, mulan_stream_t stream);
-/* Philox4x32-10 draws: kind 0 U[0,1), 1 Rademacher +-1, 2 standard normal truncated to [lo, hi] (stand in for
+/* Philox4x32-10 draws: kind 0 U[0,1), 1 Rademacher +-1, 2 standard normal truncated to [lo, hi], 3 Gumbel (stand in for
  * jax.random.uniform / randint / truncated_normal, notebook_utils.py:243-260, 318-330) */
 int mulan_noise(float* out, size_t n, unsigned long long seed, unsigned long long offset, int kind, float lo, float hi,
                 mulan_stream_t stream);
@@ -289,7 +292,8 @@ int mulan_diffloss_bwd(int mode, const unsigned char* x, const float* gt, const 
                        const float* dloss, float* dnet, float* dgt, float* dgprime, float* dzt, int B, int d,
                        mulan_stream_t stream);
 /* _topk_embedding_and_loss + _gamma_noise + _gumbel_kl_loss (model_mulan_velocity.py:78-120).
- * gnoise: [10,B,L] raw Gamma(1/k,1) draws. */
+ * gnoise: [10,B,L] raw Gamma(1/k,1) draws; tau < 0: gnoise is [B,L] additive noise (topk_noise_type 'gumbel',
+ * model_mulan_epsilon.py:236-239); gnoise = NULL: hard k-hot of the plain logits (soft / nrm may be NULL). */
 int mulan_topk_fwd(const float* logits, const float* gnoise, float* emb, float* kl, float* soft, float* nrm,
                    int B, int L, int k, float tau, mulan_stream_t stream);
 int mulan_topk_bwd(const float* logits, const float* soft, const float* nrm, const float* demb, const float* dkl,

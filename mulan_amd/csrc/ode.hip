@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void normal_logp_kernel(const float* __restric
   if (threadIdx.x == 0) out[blockIdx.x] = -0.5f * (float)cols * 1.8378770664093453f - 0.5f * s;
 }
 
-// kind 0: U[0,1);  1: Rademacher +-1;  2: standard normal truncated to [lo, hi] by inverse CDF
+// kind 0: U[0,1);  1: Rademacher +-1;  2: standard normal truncated to [lo, hi] by inverse CDF;  3: standard Gumbel
 __global__ void noise_kernel(float* __restrict__ out, size_t n, unsigned long long seed, unsigned long long offset,
                              int kind, float lo, float hi) {
   const size_t n4 = (n + 3) >> 2;
@@ -184,6 +184,8 @@ __global__ void noise_kernel(float* __restrict__ out, size_t n, unsigned long lo
         const float u = (float)(w[e] >> 8) * 5.9604644775390625e-08f;      // 24 bits, [0, 1)
         if (kind == 0) {
           v = u;
+        } else if (kind == 3) {
+          v = -logf(-logf(u + 2.98023223876953125e-08f));                   // u in (0, 1)
         } else {
           const float p = plo + (phi - plo) * (u + 2.98023223876953125e-08f);
           v = fminf(fmaxf(1.41421356237309505f * erfinvf(2.f * p - 1.f), lo), hi);
@@ -268,7 +270,7 @@ MULAN_API int mulan_normal_logp(const float* x, float* out, int rows, int cols, 
 
 MULAN_API int mulan_noise(float* out, size_t n, unsigned long long seed, unsigned long long offset, int kind, float lo,
                           float hi, hipStream_t stream) {
-  if (n == 0 || kind < 0 || kind > 2 || (kind == 2 && !(lo < hi))) return (int)hipErrorInvalidValue;
+  if (n == 0 || kind < 0 || kind > 3 || (kind == 2 && !(lo < hi))) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(noise_kernel, dim3(grid_for((n + 3) >> 2)), dim3(256), 0, stream, out, n, seed, offset, kind, lo, hi);
   MULAN_CHECK_LAUNCH();
 }

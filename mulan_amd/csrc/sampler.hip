@@ -30,19 +30,34 @@ __global__ void ancestral_step_kernel(const float* __restrict__ zt, const float*
 // x = argmax_j of the 256-bin decoder logits of EncDec.decode (ldm/model_vdm.py:282-296) at
 // z_0 / sqrt(1 - sigmoid(g_0)):  logits_j = -0.5 ((z - v_j) exp(-0.5 g_0))^2,  v_j = 2 (j + 0.5) / 256 - 1
 // (first maximum wins, like jnp.argmax)
+// sample != 0: jax.random.categorical(logits) instead of the argmax (sample_softmax = True), drawn by the Gumbel-max
+// trick with Philox noise: counter (offset + 64 i + j / 4) so every (element, bin) has its own draw
 __global__ void decode_argmax_kernel(const float* __restrict__ z0, const float* __restrict__ g0,
-                                     unsigned char* __restrict__ out, size_t n, int g_per_sample) {
+                                     unsigned char* __restrict__ out, size_t n, int g_per_sample, int sample,
+                                     unsigned long long seed, unsigned long long offset) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float g = g0[g_per_sample ? i / (size_t)g_per_sample : i];
     const float z = z0[i] / sqrtf(1.f - sigmoid_f(g));
     const float inv_stdev = expf(-0.5f * g);
     float best = -INFINITY;
     int arg = 0;
-    for (int j = 0; j < 256; ++j) {
-      const float v = 2.f * (((float)j + 0.5f) / 256.f) - 1.f;
-      const float d = (z - v) * inv_stdev;
-      const float l = -0.5f * d * d;
-      if (l > best) { best = l; arg = j; }
+    for (int j4 = 0; j4 < 64; ++j4) {
+      float gum[4] = {0.f, 0.f, 0.f, 0.f};
+      if (sample) {
+        const Philox4 r = philox4x32_10(seed, offset + (unsigned long long)i * 64ull + j4, 0ull);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          gum[e] = -logf(-logf(((float)(w[e] >> 8) + 0.5f) * 5.9604644775390625e-08f));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j4 * 4 + e;
+        const float v = 2.f * (((float)j + 0.5f) / 256.f) - 1.f;
+        const float d = (z - v) * inv_stdev;
+        const float l = -0.5f * d * d + gum[e];
+        if (l > best) { best = l; arg = j; }
+      }
     }
     out[i] = (unsigned char)arg;
   }
@@ -74,7 +89,16 @@ MULAN_API int mulan_ancestral_step(const float* zt, const float* net, const floa
 MULAN_API int mulan_decode_argmax(const float* z0, const float* g0, unsigned char* out, size_t n, int g_per_sample,
                                   hipStream_t stream) {
   if (n == 0 || g_per_sample < 0) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(decode_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, stream, z0, g0, out, n, g_per_sample);
+  hipLaunchKernelGGL(decode_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, stream, z0, g0, out, n, g_per_sample, 0, 0ull,
+                     0ull);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_decode_sample(const float* z0, const float* g0, unsigned char* out, size_t n, int g_per_sample,
+                                  unsigned long long seed, unsigned long long offset, hipStream_t stream) {
+  if (n == 0 || g_per_sample < 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(decode_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, stream, z0, g0, out, n, g_per_sample, 1, seed,
+                     offset);
   MULAN_CHECK_LAUNCH();
 }
 

@@ -278,7 +278,9 @@ __global__ __launch_bounds__(64) void topk_fwd_kernel(TkArgs p) {
   const float klv = wave_sum(on ? q * (logq - logf(1.0f / (float)L)) : 0.f);
   // sum-of-gammas noise (model_mulan_velocity.py:94-104)
   float s = 0.f;
-  if (on && p.gnoise) {
+  if (on && p.gnoise && p.tau < 0.f) {
+    s = p.gnoise[(size_t)b * L + j];     // topk_noise_type 'gumbel' (model_mulan_epsilon.py:236-239): additive [B, L] noise
+  } else if (on && p.gnoise) {
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
       const float beta = (float)p.k / (float)(i + 1);

@@ -272,7 +272,7 @@ class Experiment_VDM(Experiment):
                     coeffs = self.model.sample_coefficients(params, self.model.deterministic_embedding(B, self.device))
                 for i in range(T):
                     z = self.model.sample(params, i, T, z, conditioning, rng, coeffs)
-                samples = self.model.generate_x(params, z, coeffs)
+                samples = self.model.generate_x(params, z, coeffs, rng=rng.fold_in(T))
             finally:
                 if packer is not None:
                     packer.invalidate()

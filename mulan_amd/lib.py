@@ -74,6 +74,7 @@ SIGNATURES = {
     "mulan_topk_bwd": [P, P, P, P, P, P, I, I, P],
     "mulan_ancestral_step": [P, P, P, P, P, P, Z, I, I, P],
     "mulan_decode_argmax": [P, P, P, Z, I, P],
+    "mulan_decode_sample": [P, P, P, Z, I, U, U, P],
     "mulan_rowmean": [P, P, I, I, P],
     "mulan_ode_drift": [P, P, P, P, P, P, P, Z, I, I, P],
     "mulan_ode_div": [P, P, P, P, P, I, I, I, I, P],

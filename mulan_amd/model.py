@@ -265,28 +265,37 @@ class _VDMBase:
         (ldm/model_mulan_velocity.py:195, :95-96 via :210, :223, :235) unless given explicitly."""
         noise = dict(noise or {})
         key = rngs.get("sample") if rngs else None
-        if any(k not in noise for k in ("t0", "eps_0", "eps")) or (need_gamma and "gamma_raw" not in noise):
+        gkey = "gumbel" if self.config.topk_noise_type == 'gumbel' else "gamma_raw"
+        tkey = "t0" if self.config.antithetic_time_sampling else "t"
+        if any(k not in noise for k in (tkey, "eps_0", "eps")) or (need_gamma and gkey not in noise):
             if key is None:
                 raise ValueError("VDM.apply needs rngs={'sample': Key} or explicit noise")
             k_t, k_g, k_0, k_e = key.split(4)
             noise.setdefault("t0", k_t.uniform())
+            if not self.config.antithetic_time_sampling:    # t ~ U[0,1)^B (ldm/model_mulan_velocity.py:199-200)
+                noise.setdefault("t", ops.noise((B,), k_t.v, 0, device, "uniform"))
             if need_gamma:
                 cfg = self.config
-                noise.setdefault("gamma_raw", k_g.gamma(1.0 / cfg.latent_k, (10, B, cfg.latent_size), device))
+                if cfg.topk_noise_type == 'gumbel':
+                    noise.setdefault("gumbel", ops.noise((B, cfg.latent_size), k_g.v, 0, device, "gumbel"))
+                else:
+                    noise.setdefault("gamma_raw", k_g.gamma(1.0 / cfg.latent_k, (10, B, cfg.latent_size), device))
             noise.setdefault("eps_0", k_0.normal((B, D), device))
             noise.setdefault("eps", k_e.normal((B, D), device))
         return noise
 
-    def _times(self, t0, B, device):
+    def _times(self, noise, B, device):
         cfg = self.config
+        T = cfg.sm_n_timesteps
         if not cfg.antithetic_time_sampling:
-            raise NotImplementedError("antithetic_time_sampling=False")
+            t = noise["t"].to(device=device, dtype=torch.float32).reshape(B)
+            return torch.ceil(t * T) / T if T > 0 else t
+        t0 = noise["t0"]
         # t = mod(t0 + arange(0, 1, 1/B), 1)  (ldm/model_mulan_velocity.py:196-198), built in fp32 like jnp
         # (evaluated on the device: the same IEEE fp32 multiply / add / floor as on the host, and no blocking
         # host-to-device copy, which would make the host wait for the whole previous step)
         t = torch.remainder(torch.arange(B, dtype=torch.float32, device=device) * float(np.float32(1.0 / B))
                             + float(np.float32(t0)), 1.0)
-        T = cfg.sm_n_timesteps
         if T > 0:
             t = torch.ceil(t * T) / T
         return t
@@ -307,8 +316,9 @@ class MulanVDM(_VDMBase):
             raise NotImplementedError(
                 "hot path covers latent_type=topk, encoder=unet, gamma_type=poly_fixedend (the shipped configs); "
                 f"got {c.latent_type}/{c.encoder}/{c.gamma_type}")
-        if c.topk_noise_type != 'gamma':
-            raise NotImplementedError("topk_noise_type=gumbel")
+        if c.topk_noise_type not in ('gamma', 'gumbel') or (c.topk_noise_type == 'gumbel' and parameterization != "epsilon"):
+            raise ValueError("topk_noise_type: 'gamma' (both models) or 'gumbel' (model_mulan_epsilon only, "
+                             "ldm/model_mulan_epsilon.py:236-239)")
         if parameterization == "velocity" and c.sm_n_timesteps != 0:
             raise AssertionError("model_mulan_velocity asserts T == 0 (ldm/model_mulan_velocity.py:255)")
 
@@ -336,7 +346,7 @@ class MulanVDM(_VDMBase):
             x = torch.round(x).to(torch.uint8)
         B = x.shape[0]
         noise = self._noise(rngs, noise, B, dev, cfg.reparam_type == 'true')
-        t = self._times(noise["t0"], B, dev)
+        t = self._times(noise, B, dev)
         f = encode_images(x)
         drop_key = None if deterministic else (rngs or {}).get("dropout")
         if not deterministic and drop_key is None:
@@ -344,7 +354,10 @@ class MulanVDM(_VDMBase):
         k_enc, k_score = drop_key.split(2) if drop_key is not None else (None, None)
         if cfg.reparam_type == 'true':
             logits = unet_encoder(params["encoder_model"], cfg, f, _Drop(k_enc, cfg.sm_pdrop))
-            emb, kl_z = ops.topk_embedding(logits, noise["gamma_raw"], cfg.latent_k)
+            if cfg.topk_noise_type == 'gumbel':
+                emb, kl_z = ops.topk_embedding(logits, noise["gumbel"], cfg.latent_k, tau=-1.0)
+            else:
+                emb, kl_z = ops.topk_embedding(logits, noise["gamma_raw"], cfg.latent_k)
         else:   # ldm/model_mulan_velocity.py:212-214
             emb = torch.nn.functional.one_hot(labels.long(), 10).to(torch.float32)
             kl_z = torch.zeros(B, device=dev)
@@ -416,15 +429,18 @@ class MulanVDM(_VDMBase):
         emb = self.deterministic_embedding(z_t.shape[0], z_t.device)
         return self.conditional_sample(params, i, T, z_t, emb, conditioning, rng, coeffs)
 
-    def generate_x(self, params, z_0, coeffs=None):
+    def generate_x(self, params, z_0, coeffs=None, rng=None):
+        """argmax of the decoder logits, or with sample_softmax a categorical draw (rng: the 'sample' Key)"""
         cfg = self.config
-        if cfg.sample_softmax:
-            raise NotImplementedError("sample_softmax=True (categorical sampling of the output bins)")
+        if cfg.sample_softmax and rng is None:
+            raise ValueError("sample_softmax=True needs rng (the reference's make_rng('sample'))")
         with torch.no_grad():
             B = z_0.shape[0]
             if coeffs is None:
                 coeffs = self.sample_coefficients(params, self.deterministic_embedding(B, z_0.device))
             g_0 = self._gamma_at(coeffs, 0.0, B, z_0.device)
+            if cfg.sample_softmax:
+                return ops.decode_sample(z_0.reshape(B, D), g_0, rng.v).view(B, 32, 32, 3)
             return ops.decode_argmax(z_0.reshape(B, D), g_0).view(B, 32, 32, 3)
 
 
@@ -524,7 +540,7 @@ class PlainVDM(_VDMBase):
             x = torch.round(x).to(torch.uint8)
         B = x.shape[0]
         noise = self._noise(rngs, noise, B, dev, False)
-        t = self._times(noise["t0"], B, dev)
+        t = self._times(noise, B, dev)
         ones = torch.ones(B, device=dev)
         g0, _ = self._gamma(params, 0.0 * ones)
         g1, _ = self._gamma(params, ones)
@@ -566,12 +582,14 @@ def _plain_sample(self, params, i, T, z_t, conditioning, rng, coeffs=None):
     return z_s.view(z_t.shape)
 
 
-def _plain_generate_x(self, params, z_0, coeffs=None):
-    if self.config.sample_softmax:
-        raise NotImplementedError("sample_softmax=True (categorical sampling of the output bins)")
+def _plain_generate_x(self, params, z_0, coeffs=None, rng=None):
+    if self.config.sample_softmax and rng is None:
+        raise ValueError("sample_softmax=True needs rng (the reference's make_rng('sample'))")
     with torch.no_grad():
         B = z_0.shape[0]
         g_0, _ = self._gamma(params, torch.zeros(B, device=z_0.device))
+        if self.config.sample_softmax:
+            return ops.decode_sample(z_0.reshape(B, D), g_0.contiguous(), rng.v).view(B, 32, 32, 3)
         return ops.decode_argmax(z_0.reshape(B, D), g_0.contiguous()).view(B, 32, 32, 3)
 
 

@@ -1161,6 +1161,16 @@ def decode_argmax(z0, g0):
     return out
 
 
+def decode_sample(z0, g0, seed, offset=0):
+    """uint8 categorical draw over the 256 decoder bins (VDM.generate_x with sample_softmax=True)"""
+    z0, g0 = _c(z0), _c(g0)
+    out = torch.empty(z0.shape, device=z0.device, dtype=torch.uint8)
+    per = z0.numel() // g0.numel()
+    call("mulan_decode_sample", ptr(z0), ptr(g0), ptr(out), z0.numel(), 0 if per == 1 else per,
+         int(seed) & (2**64 - 1), int(offset), stream())
+    return out
+
+
 def rowmean(x):
     x = _c(x)
     rows = x.shape[0]
@@ -1241,7 +1251,7 @@ def noise(shape, seed, offset, device, kind, lo=-3.0, hi=3.0):
     """kind: 'uniform' U[0,1) | 'rademacher' +-1 | 'truncated_normal' on [lo, hi]"""
     out = torch.empty(shape, device=device, dtype=torch.float32)
     call("mulan_noise", ptr(out), out.numel(), int(seed) & (2**64 - 1), int(offset),
-         {"uniform": 0, "rademacher": 1, "truncated_normal": 2}[kind], float(lo), float(hi), stream())
+         {"uniform": 0, "rademacher": 1, "truncated_normal": 2, "gumbel": 3}[kind], float(lo), float(hi), stream())
     return out
 
 

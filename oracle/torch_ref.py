@@ -164,14 +164,18 @@ def poly_gamma_grad_t(a, b, c, t, gmin=GAMMA_MIN, gmax=GAMMA_MAX):
     return (gmax - gmin) * poly / scale
 
 
-def topk_embedding_and_loss(logits, raw_gamma, k, tau=10.0):
-    """ldm/model_mulan_velocity.py:78-120"""
+def topk_embedding_and_loss(logits, raw_gamma, k, tau=10.0, gumbel=None):
+    """ldm/model_mulan_velocity.py:78-120; gumbel given: topk_noise_type 'gumbel' (ldm/model_mulan_epsilon.py:236-239),
+    the noise is added as it is"""
     L = logits.shape[1]
     q = torch.softmax(logits, dim=1)
     kl = torch.sum(q * (torch.log_softmax(logits, dim=1) - math.log(1.0 / L)), dim=1)
-    beta = k / torch.arange(1., 11., dtype=logits.dtype)
-    s = (raw_gamma / beta[:, None, None]).sum(dim=0) - math.log(10.0)
-    l = logits + tau * (s / k)
+    if gumbel is not None:
+        l = logits + gumbel
+    else:
+        beta = k / torch.arange(1., 11., dtype=logits.dtype)
+        s = (raw_gamma / beta[:, None, None]).sum(dim=0) - math.log(10.0)
+        l = logits + tau * (s / k)
     l = l - l.mean(dim=1, keepdim=True)
     soft = l / torch.linalg.norm(l, dim=1, keepdim=True)
     thr = torch.topk(l, k, dim=1).values[:, -1]
@@ -180,17 +184,18 @@ def topk_embedding_and_loss(logits, raw_gamma, k, tau=10.0):
 
 
 def mulan_forward(params, cfg, x_u8, t0, raw_gamma, eps_0, eps, enc_masks=None, score_masks=None, keep=1.0,
-                  dtype=torch.float64):
+                  dtype=torch.float64, t=None, gumbel=None):
     """VDM.__call__ (ldm/model_mulan_velocity.py:188-268, ldm/model_mulan_epsilon.py:280-363, T = 0) +
     Experiment_VDM.loss_fn BPD (ldm/experiment_vdm.py:62-66)."""
     B = x_u8.shape[0]
     x = x_u8.reshape(B, 32, 32, 3)
-    t = torch.remainder(t0 + torch.arange(B, dtype=dtype) / B, 1.)
+    if t is None:                       # antithetic_time_sampling (ldm/model_mulan_velocity.py:196-198); else t given
+        t = torch.remainder(t0 + torch.arange(B, dtype=dtype) / B, 1.)
     if cfg.get("n_timesteps", 0) > 0:   # ldm/model_mulan_epsilon.py:295-297
         t = torch.ceil(t * cfg["n_timesteps"]) / cfg["n_timesteps"]
     f = encode(x.to(dtype))
     logits = unet_encoder(f, params["encoder_model"], cfg["n_embd"], cfg["forward_n_layer"], enc_masks, keep)
-    emb, kl_z = topk_embedding_and_loss(logits, raw_gamma, cfg["latent_k"])
+    emb, kl_z = topk_embedding_and_loss(logits, raw_gamma, cfg["latent_k"], gumbel=gumbel)
     a, b, c = poly_coefficients(emb, params["gamma"])
     shp = f.shape
     g_0 = poly_gamma(a, b, c, torch.zeros(B, dtype=dtype)).reshape(shp)

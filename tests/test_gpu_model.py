@@ -251,6 +251,45 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
             assert rel(params["gamma"][k].grad.cpu().double().numpy(), ref_params["gamma"][k].grad.numpy()) < 5e-3
 
 
+def test_independent_times_and_gumbel_topk_noise():
+    """antithetic_time_sampling=False (t ~ U[0,1)^B given explicitly) and topk_noise_type='gumbel' (epsilon model,
+    ldm/model_mulan_epsilon.py:236-239, 299-300) against the oracle: forward terms and BPD"""
+    import dataclasses
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, ocfg = make_cfg("mulan_epsilon")
+    cfg = dataclasses.replace(cfg, antithetic_time_sampling=False, topk_noise_type='gumbel')
+    B = 4
+    rng = np.random.default_rng(23)
+    ref_params = tr.init_params(ocfg, seed=3, dtype=torch.float64)
+    vdm = M.make_vdm("mulan_epsilon", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
+    to_device_tree(M.tree_map(lambda t: t.detach().float(), ref_params), params)
+    x = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    t = rng.uniform(0.02, 0.98, B)
+    gum = rng.gumbel(size=(B, 50))
+    e0, e = rng.standard_normal((B, 3072)), rng.standard_normal((B, 3072))
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32).cuda()
+    noise = dict(t=f32(t), gumbel=f32(gum), eps_0=f32(e0), eps=f32(e))
+    ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), 0.0, None, torch.tensor(e0).view(B, 32, 32, 3),
+                           torch.tensor(e).view(B, 32, 32, 3), t=torch.tensor(t.astype(np.float32).astype(np.float64)),
+                           gumbel=torch.tensor(gum.astype(np.float32).astype(np.float64)))
+    out, aux = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs=None, deterministic=True, noise=noise,
+                         return_aux=True)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+    assert np.array_equal(np.round(aux["emb"].cpu().numpy()), np.round(ref["aux"]["emb"].detach().numpy()))
+    assert rel(out.loss_diff.cpu().numpy(), ref["loss_diff"].detach().numpy()) < 5e-4
+    assert rel(out.loss_klz.cpu().numpy(), ref["loss_klz"].detach().numpy()) < 1e-4
+    r = 1.0 / (3072 * np.log(2.0))
+    bpd = float((out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) * r)
+    assert abs(bpd - float(ref["bpd"])) < 1e-3 * abs(float(ref["bpd"]))
+    # drawn from the key when not given: shapes / ranges only
+    out2 = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs={"sample": PRNGKey(5)}, deterministic=True)
+    assert bool(torch.isfinite(out2.loss_diff).all())
+    with pytest.raises(ValueError):
+        M.make_vdm("mulan_velocity", cfg)          # the velocity model has no gumbel variant
+
+
 def test_cli_train_checkpoint_and_dense_eval(tmp_path):
     """H2: python -m ldm.main (2 optimiser steps, synthetic data, checkpoint) then python -m ldm.eval_bpd dense and
     sparse on an npz test set through the same flag surface as the reference."""

@@ -1,6 +1,7 @@
 """Ancestral sampler: the HIP step / decode kernels and the whole T-step loop of
 Experiment_VDM.sample_fn against the float64 oracle restatement (oracle/torch_ref.py) on the same noise."""
 import dataclasses
+import math
 
 import numpy as np
 import pytest
@@ -197,12 +198,30 @@ def test_plain_vdm_sampler_loop_matches_oracle(gamma_type, reparam):
               lambda zi, eps: tr.plain_sample_loop(ref_params, ocfg, zi, eps, trajectory=True))
 
 
-def test_sample_softmax_is_refused():
-    from mulan_amd import model as M
+def test_sample_softmax_draws_from_the_decoder_distribution():
+    """sample_softmax=True: generate_x draws from softmax(logits) (jax.random.categorical): empirical bin frequencies
+    of 200 000 draws at one latent value against the oracle's decoder probabilities; needs the 'sample' key"""
+    from mulan_amd import model as M, ops
+    from mulan_amd.rng import PRNGKey
     cfg, _ = make_cfg()
     vdm = M.make_vdm("mulan_velocity", dataclasses.replace(cfg, sample_softmax=True))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         vdm.generate_x({}, torch.zeros(1, 3072, device="cuda"))
+    n = 200_000
+    g0 = -4.0                                  # sigma_0 = 0.13: about 40 bins carry mass
+    z = 0.3137
+    out = ops.decode_sample(torch.full((n,), z, device="cuda"), torch.full((n,), g0, device="cuda"), PRNGKey(4).v)
+    freq = np.bincount(out.cpu().numpy(), minlength=256) / n
+    zz = torch.tensor([z], dtype=torch.float64) / torch.sqrt(torch.sigmoid(torch.tensor(-g0, dtype=torch.float64)))
+    vals = tr.encode(torch.arange(256, dtype=torch.float64))
+    probs = torch.softmax(-0.5 * ((zz - vals) * math.exp(-0.5 * g0)) ** 2, dim=0).numpy()
+    assert 0.5 * np.abs(freq - probs).sum() < 0.01                    # total variation
+    assert abs((freq * np.arange(256)).sum() - (probs * np.arange(256)).sum()) < 0.1
+    # different keys give different draws, the same key the same draws; sample=0 path unchanged
+    a = ops.decode_sample(torch.full((64,), z, device="cuda"), torch.full((64,), g0, device="cuda"), 1)
+    b = ops.decode_sample(torch.full((64,), z, device="cuda"), torch.full((64,), g0, device="cuda"), 1)
+    c = ops.decode_sample(torch.full((64,), z, device="cuda"), torch.full((64,), g0, device="cuda"), 2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
 
 
 def test_experiment_sample_fn():
