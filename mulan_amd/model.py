@@ -122,17 +122,21 @@ def _attn_init(gen, C):
             "proj_out": _dense(gen, C, C, zero=True)}
 
 
-def _unet_init(gen, E, n_layers, cond_in, out_ch, with_up):
+def _unet_init(gen, E, n_layers, cond_in, out_ch, with_up, with_attention=False):
     p = {"dense0": _dense(gen, cond_in, 4 * E), "dense1": _dense(gen, 4 * E, 4 * E),
          "conv_in": _conv(gen, 15, E, pad_in=1)}
     for i in range(n_layers):
         p[f"down.block_{i}"] = _resblock_init(gen, E, E, 4 * E)
+        if with_attention:                      # AttnBlock after every block (ldm/model_vdm.py:356-357, 371-372)
+            p[f"down.attn_{i}"] = _attn_init(gen, E)
     p["mid.block_1"] = _resblock_init(gen, E, E, 4 * E)
     p["mid.attn_1"] = _attn_init(gen, E)
     p["mid.block_2"] = _resblock_init(gen, E, E, 4 * E)
     if with_up:
         for i in range(n_layers + 1):
             p[f"up.block_{i}"] = _resblock_init(gen, 2 * E, E, 4 * E)
+            if with_attention:
+                p[f"up.attn_{i}"] = _attn_init(gen, E)
     p["GroupNorm_0"] = _gn(E)
     p["conv_out"] = _conv(gen, E, out_ch, zero=True)
     return p
@@ -328,8 +332,8 @@ class MulanVDM(_VDMBase):
         E = c.sm_n_embd
         K = c.latent_size if c.z_conditioning else 1
         temb = 3 * E if c.unet_type == 'ldm' else E
-        score = _unet_init(gen, E, c.sm_n_layer, temb + K, 3, True)
-        enc = _unet_init(gen, E, c.forward_n_layer, E + 1, 1, False)
+        score = _unet_init(gen, E, c.sm_n_layer, temb + K, 3, True, c.with_attention)
+        enc = _unet_init(gen, E, c.forward_n_layer, E + 1, 1, False, c.with_attention)
         enc["dense_layer_final"] = _dense(gen, HW, c.latent_size)
         lat = c.latent_size if c.reparam_type == 'true' else 10
         gamma = {"dense_1": _dense(gen, lat, D), "dense_2": _dense(gen, D, D),
@@ -517,7 +521,7 @@ class PlainVDM(_VDMBase):
         c = self.config
         gen = torch.Generator().manual_seed(rng.v & ((1 << 63) - 1))
         E = c.sm_n_embd
-        p = {"score_model": _unet_init(gen, E, c.sm_n_layer, E + 1, 3, True)}
+        p = {"score_model": _unet_init(gen, E, c.sm_n_layer, E + 1, 3, True, c.with_attention)}
         if c.gamma_type == 'learnable_scalar':   # NoiseSchedule_Scalar, ldm/model_vdm.py:418-431
             p["gamma"] = {"w": torch.tensor([c.gamma_max - c.gamma_min], dtype=torch.float32),
                           "b": torch.tensor([c.gamma_min], dtype=torch.float32)}

@@ -98,6 +98,8 @@ def unet_stem(z, t, conditioning, p, n_embd, n_layers, per_pixel=False, masks=No
     for i in range(n_layers):
         n = f"down.block_{i}"
         h = resnet_block(hs[-1], cond, p[n], masks.get(n), keep)
+        if f"down.attn_{i}" in p:               # config.with_attention (ldm/model_vdm.py:356-357)
+            h = attn_block(h, p[f"down.attn_{i}"])
         hs.append(h)
     h = resnet_block(hs[-1], cond, p["mid.block_1"], masks.get("mid.block_1"), keep)
     h = attn_block(h, p["mid.attn_1"])
@@ -114,6 +116,8 @@ def score_unet(z, g_t, conditioning, p, n_embd, n_layers, per_pixel=False, gmin=
     for i in range(n_layers + 1):
         n = f"up.block_{i}"
         h = resnet_block(torch.cat([h, hs.pop()], dim=-1), cond, p[n], masks.get(n), keep)
+        if f"up.attn_{i}" in p:                 # config.with_attention (ldm/model_vdm.py:371-372)
+            h = attn_block(h, p[f"up.attn_{i}"])
     h = swish(group_norm(h, p["GroupNorm_0"]))
     return conv3x3(h, p["conv_out"]) + z
 
@@ -550,12 +554,16 @@ def init_params(cfg, seed=0, dtype=torch.float64, zero_init=False, latent=50):
              "conv_in": {"kernel": rnd(3, 3, 15, E), "bias": rnd(E, scale=0.1)}}
         for i in range(n_layers):
             p[f"down.block_{i}"] = block(E, E, 4 * E)
+            if cfg.get("with_attention", False):
+                p[f"down.attn_{i}"] = attn(E)
         p["mid.block_1"] = block(E, E, 4 * E)
         p["mid.attn_1"] = attn(E)
         p["mid.block_2"] = block(E, E, 4 * E)
         if with_up:
             for i in range(n_layers + 1):
                 p[f"up.block_{i}"] = block(2 * E, E, 4 * E)
+                if cfg.get("with_attention", False):
+                    p[f"up.attn_{i}"] = attn(E)
         p["GroupNorm_0"] = gn(E)
         p["conv_out"] = {"kernel": z_or_r(3, 3, E, out_ch), "bias": rnd(out_ch, scale=0.1)}
         return p

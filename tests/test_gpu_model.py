@@ -11,16 +11,16 @@ from oracle import mulan_np as onp
 from oracle import torch_ref as tr
 
 
-def make_cfg(vdm_type="mulan_velocity", unet_type="vdm", vfe=False, n_layer=1, fwd_layers=1, E=128):
+def make_cfg(vdm_type="mulan_velocity", unet_type="vdm", vfe=False, n_layer=1, fwd_layers=1, E=128, with_attention=False):
     from mulan_amd.model import VDMConfig
     return VDMConfig(vocab_size=256, sample_softmax=False, antithetic_time_sampling=True, with_fourier_features=True,
-                     with_attention=False, gamma_type='poly_fixedend', gamma_min=-13.3, gamma_max=5.0,
+                     with_attention=with_attention, gamma_type='poly_fixedend', gamma_min=-13.3, gamma_max=5.0,
                      sm_n_timesteps=0, sm_n_embd=E, sm_n_layer=n_layer, sm_pdrop=0.1, forward_n_layer=fwd_layers,
                      latent_size=50, latent_k=15, encoder='unet', latent_type='topk', z_conditioning=True,
                      reparam_type='true', unet_type=unet_type, velocity_from_epsilon=vfe, condition='input',
                      sigma_type='no_blur', sigma_prior=1.0), dict(
         vdm_type=vdm_type, n_embd=E, n_layer=n_layer, forward_n_layer=fwd_layers, latent_k=15, unet_type=unet_type,
-        velocity_from_epsilon=vfe)
+        velocity_from_epsilon=vfe, with_attention=with_attention)
 
 
 def oracle_masks(names, key, B, C, keep):
@@ -42,11 +42,11 @@ def to_device_tree(flax_tree, like):
     return M.from_flax_layout(flax_tree, like)
 
 
-def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0):
+def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=False):
     """tol scales the fp32-vs-float64 bars (E = 256 doubles / quadruples every contraction length)"""
     from mulan_amd import model as M
     from mulan_amd.rng import PRNGKey
-    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe, E=E)
+    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe, E=E, with_attention=with_attention)
     B = 4
     rng = np.random.default_rng(17)
     ref_params = tr.init_params(ocfg, seed=3, dtype=torch.float64)
@@ -249,6 +249,12 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
     if gamma_type == "learnable_scalar":
         for k in ("w", "b"):
             assert rel(params["gamma"][k].grad.cpu().double().numpy(), ref_params["gamma"][k].grad.numpy()) < 5e-3
+
+
+def test_with_attention_after_every_block():
+    """config.with_attention=True: an AttnBlock after each down / up ResnetBlock of both U-Nets
+    (ldm/model_vdm.py:356-357, 371-372; ldm/model_mulan_epsilon.py:133-134): losses and every parameter gradient"""
+    run_case("mulan_velocity", "vdm", False, True, with_attention=True)
 
 
 def test_independent_times_and_gumbel_topk_noise():
