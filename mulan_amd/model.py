@@ -503,14 +503,16 @@ class MulanVDM(_VDMBase):
 
 class PlainVDM(_VDMBase):
     """model_vdm.VDM (ldm/model_vdm.py:95-180): scalar noise schedule, epsilon prediction, T = 0 or T > 0
-    with reparam_type 'noise' | 'input'.  gamma_type in {'fixed', 'learnable_scalar'}."""
+    with reparam_type 'noise' | 'input'.  gamma_type in {'fixed', 'learnable_scalar', 'learnable_nnet'}."""
+
+    N_FEATURES = 1024      # NoiseSchedule_NNet.n_features
 
     def __init__(self, config: VDMConfig):
         super().__init__(config)
-        if config.gamma_type not in ('fixed', 'learnable_scalar'):
+        if config.gamma_type not in ('fixed', 'learnable_scalar', 'learnable_nnet'):
             raise NotImplementedError(f"model_vdm.VDM gamma_type={config.gamma_type} "
-                                      "(supported: fixed, learnable_scalar; reference raises on poly_fixedend, "
-                                      "ldm/model_vdm.py:101-108)")
+                                      "(supported: fixed, learnable_scalar, learnable_nnet; the reference raises on "
+                                      "poly_fixedend, ldm/model_vdm.py:101-108)")
         if config.unet_type != 'vdm':
             raise NotImplementedError("model_vdm.VDM always uses ScoreUNet")
         if config.sm_n_timesteps > 0 and config.reparam_type not in ('noise', 'input'):
@@ -525,12 +527,30 @@ class PlainVDM(_VDMBase):
         if c.gamma_type == 'learnable_scalar':   # NoiseSchedule_Scalar, ldm/model_vdm.py:418-431
             p["gamma"] = {"w": torch.tensor([c.gamma_max - c.gamma_min], dtype=torch.float32),
                           "b": torch.tensor([c.gamma_min], dtype=torch.float32)}
+        elif c.gamma_type == 'learnable_nnet':   # NoiseSchedule_NNet, ldm/model_vdm.py:471-509 (normal init: stddev 0.01)
+            F = self.N_FEATURES
+            p["gamma"] = {"l1": {"kernel": torch.full((1, 1), c.gamma_max - c.gamma_min, dtype=torch.float32),
+                                 "bias": torch.tensor([c.gamma_min], dtype=torch.float32)},
+                          "l2": {"kernel": torch.randn((1, F), generator=gen) * 0.01, "bias": torch.zeros(F)},
+                          "l3": {"kernel": torch.randn((F, 1), generator=gen) * 0.01}}
         return p
 
     def _gamma(self, params, t):
+        """(gamma(t), d gamma / d t) for t [B]"""
         c = self.config
         if c.gamma_type == 'fixed':
             return c.gamma_min + (c.gamma_max - c.gamma_min) * t, torch.full_like(t, c.gamma_max - c.gamma_min)
+        if c.gamma_type == 'learnable_nnet':
+            # monotone network of one scalar input (DenseMonotone = |kernel|): [B, 1024] host-side autograd glue like the
+            # two scalars below; the derivative the reference takes by jax.jvp is written out
+            g = params["gamma"]
+            F = self.N_FEATURES
+            t2 = t.reshape(-1, 1)
+            w1, w2, w3 = torch.abs(g["l1"]["kernel"]), torch.abs(g["l2"]["kernel"]), torch.abs(g["l3"]["kernel"])
+            sg = torch.sigmoid((2.0 * (t2 - 0.5)) * w2 + g["l2"]["bias"])
+            h = t2 * w1 + g["l1"]["bias"] + ((2.0 * (sg - 0.5)) @ w3) / F
+            dh = w1 + ((4.0 * sg * (1.0 - sg) * w2) @ w3) / F
+            return h.reshape(-1), dh.reshape(-1)
         w, b = params["gamma"]["w"], params["gamma"]["b"]
         aw = torch.abs(w)     # tiny [1]-element host-side autograd glue for the 2 schedule scalars
         return b + aw * t, aw.expand_as(t)

@@ -581,6 +581,16 @@ def init_params(cfg, seed=0, dtype=torch.float64, zero_init=False, latent=50):
     return {"score_model": score, "encoder_model": enc, "gamma": gamma}
 
 
+def nnet_gamma(p, t):
+    """NoiseSchedule_NNet.__call__ (ldm/model_vdm.py:492-509) with DenseMonotone = |kernel| (:581-598); t [B]"""
+    t2 = t.reshape(-1, 1)
+    h = t2 @ torch.abs(p["l1"]["kernel"]) + p["l1"]["bias"]
+    _h = (2. * (t2 - .5)) @ torch.abs(p["l2"]["kernel"]) + p["l2"]["bias"]
+    _h = 2 * (torch.sigmoid(_h) - .5)
+    _h = (_h @ torch.abs(p["l3"]["kernel"])) / p["l2"]["kernel"].shape[1]
+    return (h + _h).squeeze(-1)
+
+
 def plain_vdm_forward(params, cfg, x_u8, t0, eps_0, eps, gmin=GAMMA_MIN, gmax=GAMMA_MAX, dtype=torch.float64):
     """model_vdm.VDM.__call__ (ldm/model_vdm.py:110-180) with gamma_type 'fixed' (:462-468) or 'learnable_scalar'
     (:418-431), epsilon prediction, T = 0 (:158-161) or T > 0 with the 'noise' weighting (:162-170)."""
@@ -590,7 +600,12 @@ def plain_vdm_forward(params, cfg, x_u8, t0, eps_0, eps, gmin=GAMMA_MIN, gmax=GA
     t = torch.remainder(t0 + torch.arange(B, dtype=dtype) / B, 1.)
     if T > 0:
         t = torch.ceil(t * T) / T
-    if "gamma" in params:
+    if "gamma" in params and "l1" in params["gamma"]:          # gamma_type learnable_nnet
+        gamma = lambda tt: nnet_gamma(params["gamma"], tt)
+        # jax.jvp(self.gamma, (t,), (ones,)) (ldm/model_vdm.py:160): the t-derivative, differentiable in the parameters
+        tt_ = t.detach().clone().requires_grad_(True)
+        slope = torch.autograd.grad(gamma(tt_).sum(), tt_, create_graph=True)[0]
+    elif "gamma" in params:
         w, b = torch.abs(params["gamma"]["w"]), params["gamma"]["b"]
         gamma = lambda tt: b + w * tt
         slope = w.expand(B)

@@ -206,7 +206,7 @@ def test_mulan_epsilon_discrete_time_T1000():
     assert rel(g, rg) < 2e-3
 
 
-@pytest.mark.parametrize("gamma_type,T", [("fixed", 0), ("learnable_scalar", 0), ("fixed", 1000)])
+@pytest.mark.parametrize("gamma_type,T", [("fixed", 0), ("learnable_scalar", 0), ("fixed", 1000), ("learnable_nnet", 0)])
 def test_plain_vdm_matches_oracle(gamma_type, T):
     """BASELINE config #1 model (ldm/model_vdm.py:95-180): scalar schedule VDM, forward + schedule / U-Net grads."""
     import dataclasses
@@ -222,6 +222,13 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
     ref_params["score_model"]["dense0"]["kernel"] = ref_params["score_model"]["dense0"]["kernel"][:129].clone()
     if gamma_type == "learnable_scalar":
         ref_params["gamma"] = {"w": torch.tensor([-17.0], dtype=torch.float64), "b": torch.tensor([-12.5], dtype=torch.float64)}
+    if gamma_type == "learnable_nnet":      # NoiseSchedule_NNet (ldm/model_vdm.py:471-509), strongly non-linear on purpose
+        gg = torch.Generator().manual_seed(8)
+        ref_params["gamma"] = {
+            "l1": {"kernel": torch.tensor([[-16.0]], dtype=torch.float64), "bias": torch.tensor([-12.0], dtype=torch.float64)},
+            "l2": {"kernel": torch.randn(1, 1024, generator=gg, dtype=torch.float64) * 3,
+                   "bias": torch.randn(1024, generator=gg, dtype=torch.float64)},
+            "l3": {"kernel": torch.randn(1024, 1, generator=gg, dtype=torch.float64) * 2}}
     for _, leaf in tr.tree_leaves(ref_params):
         leaf.requires_grad_(True)
     vdm = M.make_vdm("vdm", cfg)
@@ -249,6 +256,9 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
     if gamma_type == "learnable_scalar":
         for k in ("w", "b"):
             assert rel(params["gamma"][k].grad.cpu().double().numpy(), ref_params["gamma"][k].grad.numpy()) < 5e-3
+    if gamma_type == "learnable_nnet":
+        for l, k in (("l1", "kernel"), ("l1", "bias"), ("l2", "kernel"), ("l2", "bias"), ("l3", "kernel")):
+            assert rel(params["gamma"][l][k].grad.cpu().double().numpy(), ref_params["gamma"][l][k].grad.numpy()) < 5e-3, (l, k)
 
 
 def test_with_attention_after_every_block():
