@@ -282,12 +282,14 @@ def test_ode_likelihood_matches_oracle(vdm_type, vfe, deq):
         assert _rel(log_q.cpu().numpy(), lq_ref.numpy()) < 1e-6
     else:
         assert log_q is None and lq_ref is None
+    assert abs(_get_bpd_offset(deq, 1) - tr.bpd_offset(deq, 1)) < 1e-12
+    assert abs(_get_bpd_offset("tn", 20) - tr.bpd_offset("tn", 20)) < 1e-12
+    if deq != "tn":          # the adaptive comparison once is enough (each oracle solve costs ~1 min of CPU)
+        return
     log_p, _, _, info = fn(PRNGKey(0), img.cuda(), deterministic_noise=True, u=u, probes=lambda: probe)
     lp_ref, _, _, nfev = oracle()
     assert abs(info["nfev"] - nfev) <= 6, (info["nfev"], nfev)
     assert _rel(log_p.cpu().numpy(), lp_ref.numpy()) < 0.05, (log_p, lp_ref)
-    assert abs(_get_bpd_offset(deq, 1) - tr.bpd_offset(deq, 1)) < 1e-12
-    assert abs(_get_bpd_offset("tn", 20) - tr.bpd_offset("tn", 20)) < 1e-12
 
 
 def test_ode_sampler_matches_oracle():
