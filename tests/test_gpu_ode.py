@@ -161,10 +161,10 @@ def test_normal_logp_and_hard_topk():
 
 
 # ------------------------------------------------------------------------------------------------ model level
-def _setup(vdm_type, unet_type, vfe, seed=5):
+def _setup(vdm_type, unet_type, vfe, seed=5, E=128):
     from mulan_amd import model as M
     from mulan_amd.rng import PRNGKey
-    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe)
+    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe, E=E)
     ref_params = tr.init_params(ocfg, seed=seed, dtype=torch.float64)
     vdm = M.make_vdm(vdm_type, cfg)
     params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
@@ -270,7 +270,7 @@ def test_ode_likelihood_matches_oracle(vdm_type, vfe, deq):
         lambda x, emb, t: tr.reverse_ode(ref_params, ocfg, x, emb, t),
         lambda im: tr.unet_encoder(tr.encode(im), ref_params["encoder_model"], E, FL),
         img, u.cpu().double(), lambda: probe.cpu().double(), dequantization=deq, rtol=1e-3, atol=1e-3, **kw)
-    grid = [0.0, 0.03, 0.1, 0.22, 0.38, 0.55, 0.72, 0.88, 1.0]
+    grid = [0.0, 0.04, 0.14, 0.32, 0.55, 0.8, 1.0]
     log_p, log_q, aux, info = fn(PRNGKey(0), img.cuda(), deterministic_noise=True, u=u, probes=lambda: probe, t_grid=grid)
     lp_ref, lq_ref, aux_ref, nfev = oracle(t_grid=grid)
     # log p ~ -3e3 nats; 1 nat = 4.7e-4 bits/dim, a tenth of the +-0.005 BPD bar (measured: 0.09 ... 0.5 nat)
