@@ -310,8 +310,16 @@ int plan_ksplit(int M, int N, int K, int batch, int* kchunk) {
   } else {
     // a handful of tiles with a few hundred k steps each (the [B,512] x [512,128] FiLM projections of every
     // ResnetBlock) would run as one latency-bound wavefront per tile: cut K into 64-deep pieces
-    if (tiles > 8 || K < 256) return 1;
-    s = K / 64;
+    if (K < 256) return 1;
+    if (tiles > 8) {
+      // the M = batch GEMMs of the gamma MLP ([128, 3072] x [3072, 3072]: 96 tiles of 64 x 64, each streaming a
+      // 786 KB weight panel): too few workgroups to pull the 37.7 MB of weights at HBM speed; cut K to fill the CUs
+      if (tiles >= 128 || K < 1024) return 1;
+      s = (int)((768 + tiles - 1) / tiles);      // measured on [128, 3072] x [3072, 3072]: 98 us unsplit, 53 us at
+      if (s > K / 256) s = K / 256;              // 3 splits, 36.6 us at 8, 37.5 us at 16
+    } else {
+      s = K / 64;
+    }
   }
   if (s < 2) return 1;
   int kc = ((K + s - 1) / s + 15) / 16 * 16;

@@ -132,7 +132,8 @@ def test_gemm_exact(ops, M, N, K, ta, tb):
 
 
 @pytest.mark.parametrize("M,N,K,ta", [(256, 128, 131072, 1), (128, 128, 8192, 1), (50, 1024, 4096, 0), (128, 3, 65536, 1),
-                                      (128, 128, 512, 0), (128, 128, 512, 1), (64, 256, 320, 0), (2, 128, 512, 0)])
+                                      (128, 128, 512, 0), (128, 128, 512, 1), (64, 256, 320, 0), (2, 128, 512, 0),
+                                      (128, 3072, 3072, 0), (128, 1024, 1024, 0)])
 def test_gemm_split_k_exact(ops, M, N, K, ta):
     """long-K weight-gradient shapes, and few-tile shapes with a few hundred k steps (the FiLM projections), take the
     split-K path (slab + fixed-order reduce): still bit exact"""
