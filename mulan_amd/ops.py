@@ -71,6 +71,16 @@ def cached_absmax(x):
     return m
 
 
+def view_keep_absmax(x, *shape):
+    """x.view(shape) that keeps the maxima found on x (a view is a new Python object and would lose them; the
+    per-image maxima do not depend on how the trailing dimensions are folded as long as dim 0 stays the batch)"""
+    v = x.view(*shape)
+    c = getattr(x, "_absmax", None)
+    if c is not None and c[1] == x._version and v.shape[0] == c[0].shape[0]:
+        v._absmax = (c[0], v._version)
+    return v
+
+
 class ParamPacker:
     """Once-per-step weight preparation (f16x3 mode): maxima and both packed operands of every eligible parameter
     leaf of a TrainState in two launches; the leaves carry views of the result (`_prepacked`), valid until the
@@ -462,7 +472,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.fast:
                 wpt, _ = linear_pack(w, True, ctx.wmax)
-                dx = linear_f16x3_raw(dy.view(-1, HW, N), None, wpt, ctx.wmax, K, 0)[0].view(xshape)
+                dx = linear_f16x3_raw(view_keep_absmax(dy, -1, HW, N), None, wpt, ctx.wmax, K, 0)[0].view(xshape)
             else:
                 dx = gemm_raw(dy2, w, M, K, N, transB=True).view(xshape)
         gvw, gvb = ctx.gv
@@ -587,7 +597,7 @@ class Linear2Fn(torch.autograd.Function):
         dy2 = dy.reshape(M, N)
         if ctx.fast and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
             wpt, _ = linear_pack(w, True, ctx.wmax)          # dy @ w^T, split into the two inputs' gradients on the way out
-            dx1, dx2 = linear_f16x3_raw(dy.view(-1, HW, N), None, wpt, ctx.wmax, K1, K2)
+            dx1, dx2 = linear_f16x3_raw(view_keep_absmax(dy, -1, HW, N), None, wpt, ctx.wmax, K1, K2)
             dx1, dx2 = dx1.view(*ctx.shape, K1), dx2.view(*ctx.shape, K2)
         else:
             dx1 = gemm_raw(dy2, w[:K1], M, K1, N, transB=True).view(*ctx.shape, K1) if ctx.needs_input_grad[0] else None
