@@ -71,6 +71,11 @@ int mulan_conv3x3_wgrad_bf16x6(const float* x, const float* dy, float* dw, float
  * wmax[16] = mulan_absmax_rows(w, 1 row); wp from mulan_conv3x3_pack_f16x3 (flip as above).
  * Needs C % 16 == 0 and N % 128 == 0. */
 int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, mulan_stream_t stream);
+/* c = a + b (c may alias a or b) with out = mulan_absmax_rows(c) in the same pass: the gradient sum autograd forms for
+ * a tensor with two consumers (the U-Net skip connections, model_vdm.py:351-372) fused with the maxima pass of the
+ * convolution that receives it */
+int mulan_add_absmax_rows(const float* a, const float* b, float* c, unsigned* out, int rows, size_t row_len,
+                          mulan_stream_t stream);
 size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N);
 int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int C, int N, int flip,
                              mulan_stream_t stream);

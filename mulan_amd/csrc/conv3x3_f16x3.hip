@@ -576,6 +576,31 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
   if (threadIdx.x == 0) out[(size_t)blockIdx.x * kMaxParts + blockIdx.y] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
+// c = a + b with the maxima of c as above: the sum autograd would form for a tensor with two consumers (the U-Net skip
+// connections) and the maxima pass of the convolution that takes c as its dy, in one pass over the data
+__global__ __launch_bounds__(256) void add_absmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ c, unsigned* __restrict__ out,
+                                                              size_t row_len4) {
+  __shared__ unsigned red[4];
+  const size_t base = (size_t)blockIdx.x * row_len4;
+  const f32x4* ra = reinterpret_cast<const f32x4*>(a) + base;
+  const f32x4* rb = reinterpret_cast<const f32x4*>(b) + base;
+  f32x4* rc = reinterpret_cast<f32x4*>(c) + base;
+  unsigned m = 0;
+  const size_t stride = (size_t)kMaxParts * 256;
+  for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < row_len4; i += stride) {
+    const f32x4 v = ra[i] + rb[i];
+    rc[i] = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(size_t)blockIdx.x * kMaxParts + blockIdx.y] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
 // wp[t][cc][o][plane][k] = split2( s_w * Wl[t][cc*16 + k][o] ),  Wl = w (flip = 0) or the tap-flipped,
 // channel-transposed weights of the input-gradient convolution (flip = 1: Wl[t][k][o] = w[8-t][o][k]).
 __global__ void conv3x3_pack_f16x3_kernel(const float* __restrict__ w, _Float16* __restrict__ wp,
@@ -1152,6 +1177,15 @@ __global__ __launch_bounds__(256) void param_pack_kernel(const float* __restrict
 MULAN_API int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, hipStream_t stream) {
   if (rows <= 0 || row_len == 0 || row_len % 4 != 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(absmax_rows_kernel, dim3(rows, kMaxParts), dim3(256), 0, stream, x, out, row_len / 4);
+  MULAN_CHECK_LAUNCH();
+}
+
+// c = a + b (rows x row_len, c may alias a or b) and out = mulan_absmax_rows(c): gradient accumulation of a tensor with
+// two consumers fused with the maxima pass of the layer behind it
+MULAN_API int mulan_add_absmax_rows(const float* a, const float* b, float* c, unsigned* out, int rows, size_t row_len,
+                                    hipStream_t stream) {
+  if (rows <= 0 || row_len == 0 || row_len % 4 != 0 || !a || !b || !c || !out) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_absmax_rows_kernel, dim3(rows, kMaxParts), dim3(256), 0, stream, a, b, c, out, row_len / 4);
   MULAN_CHECK_LAUNCH();
 }
 

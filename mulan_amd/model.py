@@ -186,7 +186,7 @@ def attn_block(p, x):
     return ops.linear(o, p["proj_out"]["kernel"], p["proj_out"]["bias"], res=x)
 
 
-def _unet_stem(p, z, t, conditioning, E, n_layers, per_pixel, with_attention, drop):
+def _unet_stem(p, z, t, conditioning, E, n_layers, per_pixel, with_attention, drop, with_skips=True):
     """conv_in .. mid.block_2 shared by ScoreUNet, ldm UNet and UnetEncoder."""
     if per_pixel:
         # ldm_unet.py:82-90: temb over t.reshape(-1) -> [B,32,32,3E]; dense0(concat[temb, c]) is evaluated as
@@ -203,13 +203,17 @@ def _unet_stem(p, z, t, conditioning, E, n_layers, per_pixel, with_attention, dr
     if per_pixel:
         cond = cond.view(z.shape[0], HW, -1)
     h = ops.conv3x3(ops.fourier_features(z), p["conv_in"]["kernel"], p["conv_in"]["bias"])
-    hs = [h]
+    # every level output feeds the next block and (in the U-Nets with an up path) a skip connection: ops.tee hands
+    # out one alias per consumer so that the two gradients are summed by mulan_add_absmax_rows
+    h, skip = ops.tee(h) if with_skips else (h, h)
+    hs = [skip]
     for i in range(n_layers):
-        h = resnet_block(p[f"down.block_{i}"], hs[-1], None, cond, drop)
+        h = resnet_block(p[f"down.block_{i}"], h, None, cond, drop)
         if with_attention:
             h = attn_block(p[f"down.attn_{i}"], h)
-        hs.append(h)
-    h = resnet_block(p["mid.block_1"], hs[-1], None, cond, drop)
+        h, skip = ops.tee(h) if with_skips else (h, h)
+        hs.append(skip)
+    h = resnet_block(p["mid.block_1"], h, None, cond, drop)
     h = attn_block(p["mid.attn_1"], h)
     h = resnet_block(p["mid.block_2"], h, None, cond, drop)
     return h, hs, cond
@@ -237,7 +241,7 @@ def unet_encoder(p, cfg, f, drop):
     E = cfg.sm_n_embd
     t = torch.zeros(B, device=f.device)
     conditioning = torch.zeros((B, 1), device=f.device)
-    h, _, _ = _unet_stem(p, f, t, conditioning, E, cfg.forward_n_layer, False, cfg.with_attention, drop)
+    h, _, _ = _unet_stem(p, f, t, conditioning, E, cfg.forward_n_layer, False, cfg.with_attention, drop, with_skips=False)
     h = ops.group_norm(h, None, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
     h = ops.conv3x3(h, p["conv_out"]["kernel"], p["conv_out"]["bias"])          # [B,1024,1]
     h = ops.silu(h.view(B, HW))

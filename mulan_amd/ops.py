@@ -81,6 +81,42 @@ def view_keep_absmax(x, *shape):
     return v
 
 
+class TeeFn(torch.autograd.Function):
+    """(x, x) for a tensor with two consumers (a U-Net skip connection): the backward pass forms the sum of the two
+    gradients itself, in one kernel that also leaves the maxima of the sum for the convolution behind it (instead of
+    autograd's elementwise add followed by a separate maxima pass)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        a, b = x.view_as(x), x.view_as(x)
+        for v in (a, b):
+            c = getattr(x, "_absmax", None)
+            if c is not None and c[1] == x._version:
+                v._absmax = (c[0], v._version)
+        return a, b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return gb if ga is None else ga
+        ga, gb = _c(ga), _c(gb)
+        if CONV_MODE != "f16x3" or ga.dim() < 2 or (ga.numel() // ga.shape[0]) % 4 != 0:
+            return ga + gb
+        out = torch.empty_like(ga)
+        m = torch.empty((ga.shape[0], MAX_PARTS), device=ga.device, dtype=torch.int32)
+        call("mulan_add_absmax_rows", ptr(ga), ptr(gb), ptr(out), ptr(m), ga.shape[0], ga.numel() // ga.shape[0], stream())
+        out._absmax = (m, out._version)
+        return out
+
+
+def tee(x):
+    """two aliases of x for its two consumers; see TeeFn"""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return TeeFn.apply(x)
+
+
 class ParamPacker:
     """Once-per-step weight preparation (f16x3 mode): maxima and both packed operands of every eligible parameter
     leaf of a TrainState in two launches; the leaves carry views of the result (`_prepacked`), valid until the
