@@ -261,6 +261,40 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
             assert rel(params["gamma"][l][k].grad.cpu().double().numpy(), ref_params["gamma"][l][k].grad.numpy()) < 5e-3, (l, k)
 
 
+def test_full_depth_forward_bpd_parity():
+    """the shipped depth (sm_n_layer = 32: 67 ResnetBlocks in the score U-Net, forward_n_layer = 4 in the encoder) in
+    evaluation mode against the float64 oracle: the north-star bar is +-0.005 bits/dim; the split-operand kernels
+    must not accumulate error over 140 chained convolutions"""
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, ocfg = make_cfg("mulan_velocity", "vdm", True, n_layer=32, fwd_layers=4)
+    B = 2
+    rng = np.random.default_rng(31)
+    ref_params = tr.init_params(ocfg, seed=9, dtype=torch.float64)
+    vdm = M.make_vdm("mulan_velocity", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
+    to_device_tree(M.tree_map(lambda t: t.detach().float(), ref_params), params)
+    x = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    raw = rng.gamma(1.0 / 15, size=(10, B, 50))
+    e0, e = rng.standard_normal((B, 3072)), rng.standard_normal((B, 3072))
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32).cuda()
+    noise = dict(t0=0.41, gamma_raw=f32(raw), eps_0=f32(e0), eps=f32(e))
+    with torch.no_grad():
+        ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), 0.41, torch.tensor(raw),
+                               torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3))
+        out, aux = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs=None, deterministic=True,
+                             noise=noise, return_aux=True)
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+    assert np.array_equal(np.round(aux["emb"].cpu().numpy()), np.round(ref["aux"]["emb"].numpy()))
+    net_err = rel(aux["net"].cpu().numpy(), ref["aux"]["net"].numpy().reshape(B, -1))
+    r = 1.0 / (3072 * np.log(2.0))
+    bpd = float((out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) * r)
+    print(f"full depth: net rel err {net_err:.2e}, bpd hip {bpd:.6f} oracle {float(ref['bpd']):.6f}")
+    assert net_err < 2e-3, net_err
+    assert abs(bpd - float(ref["bpd"])) < 0.005 and abs(bpd - float(ref["bpd"])) < 1e-3 * abs(float(ref["bpd"])), \
+        (bpd, float(ref["bpd"]), net_err)
+
+
 def test_with_attention_after_every_block():
     """config.with_attention=True: an AttnBlock after each down / up ResnetBlock of both U-Nets
     (ldm/model_vdm.py:356-357, 371-372; ldm/model_mulan_epsilon.py:133-134): losses and every parameter gradient"""
