@@ -42,11 +42,12 @@ def to_device_tree(flax_tree, like):
     return M.from_flax_layout(flax_tree, like)
 
 
-def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=False):
+def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=False, n_layer=1, fwd_layers=1):
     """tol scales the fp32-vs-float64 bars (E = 256 doubles / quadruples every contraction length)"""
     from mulan_amd import model as M
     from mulan_amd.rng import PRNGKey
-    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe, E=E, with_attention=with_attention)
+    cfg, ocfg = make_cfg(vdm_type, unet_type, vfe, E=E, with_attention=with_attention, n_layer=n_layer,
+                         fwd_layers=fwd_layers)
     B = 4
     rng = np.random.default_rng(17)
     ref_params = tr.init_params(ocfg, seed=3, dtype=torch.float64)
@@ -72,8 +73,8 @@ def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=Fal
         keep = float(np.float32(0.9))
         dkey = PRNGKey(99)
         k_enc, k_score = dkey.split(2)
-        enc_masks = oracle_masks(block_names(1, False), k_enc, B, E, 0.9)
-        score_masks = oracle_masks(block_names(1, True), k_score, B, E, 0.9)
+        enc_masks = oracle_masks(block_names(fwd_layers, False), k_enc, B, E, 0.9)
+        score_masks = oracle_masks(block_names(n_layer, True), k_score, B, E, 0.9)
         rngs = {"dropout": dkey}
     ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), t0, torch.tensor(raw),
                            torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3),
@@ -293,6 +294,13 @@ def test_full_depth_forward_bpd_parity():
     assert net_err < 2e-3, net_err
     assert abs(bpd - float(ref["bpd"])) < 0.005 and abs(bpd - float(ref["bpd"])) < 1e-3 * abs(float(ref["bpd"])), \
         (bpd, float(ref["bpd"]), net_err)
+
+
+def test_deeper_stack_train_gradients():
+    """8 + 2 layers (19 + 4 ResnetBlocks), training mode with dropout: losses and every parameter gradient against
+    float64 autograd through the whole stack (error growth with depth; the shipped depth is covered forward-only by
+    test_full_depth_forward_bpd_parity)"""
+    run_case("mulan_velocity", "vdm", False, True, n_layer=8, fwd_layers=2)
 
 
 def test_with_attention_after_every_block():
