@@ -77,7 +77,35 @@ def tiny_model():
                         param_seed=11, **out)
 
 
+def sampler_and_ode():
+    """closed forms of the ancestral sampler and of the probability-flow ODE evaluator (oracle/torch_ref.py)"""
+    rng = np.random.default_rng(20240202)
+    n = 512
+    z, net, eps = (torch.tensor(rng.standard_normal(n)) for _ in range(3))
+    g_t = torch.tensor(rng.uniform(-13.3, 5.0, n))
+    g_s = g_t - torch.tensor(rng.uniform(1e-3, 1.0, n))
+    g_p = torch.tensor(rng.uniform(1.0, 40.0, n))
+    out = dict(z=z.numpy(), net=net.numpy(), eps=eps.numpy(), g_t=g_t.numpy(), g_s=g_s.numpy(), g_p=g_p.numpy())
+    for kind in ("velocity", "epsilon", "input"):
+        out[f"step_{kind}"] = tr.ancestral_step(z, net, g_t, g_s, eps, kind).numpy()
+    for kind in ("velocity", "vfe", "epsilon"):
+        out[f"drift_{kind}"] = tr.ode_drift(net, z, g_t, g_p, kind).numpy()
+    z0 = torch.tensor(rng.uniform(-1.2, 1.2, n)) * 0.01
+    g0 = torch.tensor(rng.uniform(-13.3, -9.0, n))
+    out.update(z0=z0.numpy(), g0=g0.numpy(), decoded=tr.decode_argmax(z0, g0).numpy())
+    logits = torch.tensor(rng.standard_normal((6, 50)))
+    out.update(logits=logits.numpy(), hard_topk=tr.logits_to_embeddings(logits).numpy(),
+               kl=tr.gumbel_kl_loss(logits).numpy(), prior_logp=tr.prior_logp(z.reshape(2, 16, 16, 1)).numpy(),
+               bpd_offsets=np.array([tr.bpd_offset("uniform", 1), tr.bpd_offset("tn", 1), tr.bpd_offset("tn", 20)]))
+    # Dormand-Prince on a prescribed grid: y' = -y (1 + t) + sin(3 t)
+    grid = [0.0, 0.1, 0.25, 0.5, 0.8, 1.0]
+    y1 = tr.dopri5_fixed(lambda t, y: -y * (1 + t) + np.sin(3 * t), np.array([1.0, -0.5, 2.0]), grid)
+    out.update(dopri_grid=np.array(grid), dopri_y1=y1)
+    np.savez_compressed(os.path.join(HERE, "sampler_ode.npz"), **out)
+
+
 if __name__ == "__main__":
     closed_forms()
     tiny_model()
+    sampler_and_ode()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

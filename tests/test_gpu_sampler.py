@@ -247,3 +247,21 @@ def test_experiment_sample_fn():
     assert a.shape == (3, 32, 32, 3) and a.dtype == torch.uint8
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert torch.equal(before, exp.state.flat)
+
+
+def test_kernels_against_golden_fixture():
+    """the committed fixture tests/golden/sampler_ode.npz (oracle outputs on seeded inputs) as a file-based target"""
+    import os
+    from mulan_amd import ops
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler_ode.npz"))
+    dev = lambda k: torch.tensor(z[k], dtype=torch.float32).cuda().view(1, -1)
+    for mode, kind in ((0, "velocity"), (1, "epsilon"), (2, "input")):
+        got = ops.ancestral_step(dev("z"), dev("net"), dev("g_t"), dev("g_s"), dev("eps"), mode).cpu().numpy()[0]
+        assert _rel(got, z[f"step_{kind}"]) < (5e-4 if mode == 2 else 2e-6), kind     # 'input' divides by sigma ~ 1e-3
+    for mode, kind in ((0, "velocity"), (1, "vfe"), (2, "epsilon")):
+        got, _ = ops.ode_drift(dev("net"), dev("z"), dev("g_t"), dev("g_p"), None, mode)
+        assert _rel(got.cpu().numpy()[0], z[f"drift_{kind}"]) < 5e-6, kind
+    dec = ops.decode_argmax(dev("z0"), dev("g0")).cpu().numpy()[0]
+    assert np.abs(dec.astype(np.int64) - z["decoded"]).max() <= 1 and (dec != z["decoded"]).mean() < 0.01
+    emb, kl = ops.topk_hard(torch.tensor(z["logits"], dtype=torch.float32).cuda(), 15)
+    assert np.array_equal(emb.cpu().numpy(), z["hard_topk"]) and _rel(kl.cpu().numpy(), z["kl"]) < 1e-5

@@ -289,3 +289,25 @@ def test_ode_likelihood_of_a_gaussian_is_exact():
     assert abs(tr.bpd_offset("tn", 1) + (0.5 * (1 + math.log(2 * math.pi)) - 0.01522 + ls) / math.log(2)) < 1e-12
     emb = tr.logits_to_embeddings(torch.tensor(rng.standard_normal((4, 50))))
     assert torch.equal(emb.sum(dim=1), torch.full((4,), 15.0, dtype=torch.float64))
+
+
+def test_golden_sampler_and_ode_fixture():
+    z = np.load(os.path.join(GOLD, "sampler_ode.npz"))
+    tt = lambda k: torch.tensor(z[k])
+    for kind in ("velocity", "epsilon", "input"):
+        assert np.allclose(tr.ancestral_step(tt("z"), tt("net"), tt("g_t"), tt("g_s"), tt("eps"), kind).numpy(),
+                           z[f"step_{kind}"], rtol=1e-12)
+    for kind in ("velocity", "vfe", "epsilon"):
+        assert np.allclose(tr.ode_drift(tt("net"), tt("z"), tt("g_t"), tt("g_p"), kind).numpy(), z[f"drift_{kind}"], rtol=1e-12)
+    assert np.array_equal(tr.decode_argmax(tt("z0"), tt("g0")).numpy(), z["decoded"])
+    assert np.array_equal(tr.logits_to_embeddings(tt("logits")).numpy(), z["hard_topk"])
+    assert np.allclose(tr.gumbel_kl_loss(tt("logits")).numpy(), z["kl"], rtol=1e-12)
+    assert np.allclose(tr.prior_logp(tt("z").reshape(2, 16, 16, 1)).numpy(), z["prior_logp"], rtol=1e-12)
+    assert np.allclose([tr.bpd_offset("uniform", 1), tr.bpd_offset("tn", 1), tr.bpd_offset("tn", 20)], z["bpd_offsets"])
+    y1 = tr.dopri5_fixed(lambda t, y: -y * (1 + t) + np.sin(3 * t), np.array([1.0, -0.5, 2.0]), list(z["dopri_grid"]))
+    assert np.allclose(y1, z["dopri_y1"], rtol=1e-12)
+    # the fixed-grid Dormand-Prince solution agrees with scipy's adaptive RK45 at a tight tolerance
+    from scipy import integrate
+    ref = integrate.solve_ivp(lambda t, y: -y * (1 + t) + np.sin(3 * t), (0, 1), np.array([1.0, -0.5, 2.0]), rtol=1e-10,
+                              atol=1e-12, method="RK45").y[:, -1]
+    assert np.allclose(y1, ref, rtol=2e-5)
