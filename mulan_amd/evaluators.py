@@ -31,6 +31,57 @@ class Experiment_Colab(Experiment_VDM):
         self.state.load_state_dict({"ema_params": sd["ema_params"]}, strict=True)
         self.orig_params = self.state.ema_params
         self.params = self.orig_params
+        self.rng, sample_rng = self.rng.split()
+        self.rngs = {'sample': sample_rng}
+
+    # ---- samplers of the notebook front end (ldm/notebook_utils.py:54-135) --------------------------------------
+    def _embedding_samples(self, embedding, rng, T):
+        """T ancestral steps of model.conditional_sample under a fixed [B, 50] embedding, then generate_x"""
+        from . import ops  # noqa: F401
+        B = embedding.shape[0]
+        rng = rng.fold_in(self.rank)
+        rng, sample_rng = rng.split()
+        packer = self.state.param_packer("ema")
+        with torch.no_grad():
+            if packer is not None:
+                packer.refresh()
+            try:
+                z = sample_rng.normal((B, 3072), self.device)
+                conditioning = torch.zeros(B, dtype=torch.uint8, device=self.device)
+                coeffs = self.model.sample_coefficients(self.params, embedding)
+                for i in range(T):
+                    z = self.model.conditional_sample(self.params, i, T, z, embedding, conditioning, rng, coeffs)
+                samples = self.model.generate_x(self.params, z, rng=rng.fold_in(T))
+            finally:
+                if packer is not None:
+                    packer.invalidate()
+        return parallel.all_gather_tensor(samples)
+
+    def sample_conditionally(self, embedding, T=1000):
+        """Experiment_Colab.sample_conditionally: an image grid sampled under one 50-dim k-hot embedding"""
+        from . import ops  # noqa: F401
+        B = self.eval_iter.local
+        emb = torch.as_tensor(embedding, dtype=torch.float32, device=self.device).reshape(1, -1)
+        assert emb.shape[1] == 50
+        samples = self._embedding_samples(emb.expand(B, 50).contiguous(), self.rng, T)
+        return ckpt_lib.generate_image_grids(samples).astype(np.uint8)
+
+    def sample_randomly(self, T=1000):
+        """Experiment_Colab.sample_randomly: every image under the hard top-15 embedding of its own random logits"""
+        from . import ops
+        B = self.eval_iter.local
+        _, embeddings_rng = self.rng.fold_in(self.rank).split()
+        emb, _ = ops.topk_hard(embeddings_rng.normal((B, 50), self.device), 15)
+        samples = self._embedding_samples(emb, self.rng, T)
+        return ckpt_lib.generate_image_grids(samples).astype(np.uint8)
+
+    def test(self, loader):
+        """Experiment_Colab.test: mean of the eval scalars over a loader"""
+        eval_metrics = []
+        for eval_step, batch in enumerate(loader):
+            m = self.p_eval_step(self.params, batch, eval_step)
+            eval_metrics.append({k: float(v) for k, v in m['scalars'].items()})
+        return {k: float(np.mean([m[k] for m in eval_metrics])) for k in eval_metrics[0]}
 
 
 def _reduce_mean(total, count, device):

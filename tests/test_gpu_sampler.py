@@ -265,3 +265,39 @@ def test_kernels_against_golden_fixture():
     assert np.abs(dec.astype(np.int64) - z["decoded"]).max() <= 1 and (dec != z["decoded"]).mean() < 0.01
     emb, kl = ops.topk_hard(torch.tensor(z["logits"], dtype=torch.float32).cuda(), 15)
     assert np.array_equal(emb.cpu().numpy(), z["hard_topk"]) and _rel(kl.cpu().numpy(), z["kl"]) < 1e-5
+
+
+def test_colab_front_end_samplers(tmp_path):
+    """Experiment_Colab.sample_conditionally / sample_randomly / test (ldm/notebook_utils.py:54-154) on a checkpoint of
+    a two-step training run: image grids of the right shape, reproducible, different for different embeddings"""
+    import os
+    from mulan_amd import checkpoint as ck
+    from mulan_amd.config import load_config_file
+    from mulan_amd.evaluators import Experiment_Colab
+    from mulan_amd.experiment import Experiment_VDM
+    from mulan_amd import data as dataset
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def cfg():
+        c = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+        c.data.dataset = 'synthetic'
+        c.model.sm_n_layer = 1
+        c.model.forward_n_layer = 1
+        c.training.batch_size_train = 4
+        c.training.batch_size_eval = 4
+        c.training.substeps = 1
+        return c
+    exp = Experiment_VDM(cfg())
+    ck.save(str(tmp_path), exp.state.state_dict())
+    colab = Experiment_Colab(cfg(), str(tmp_path))
+    e1 = np.zeros(50, dtype=np.float32); e1[:15] = 1
+    e2 = np.zeros(50, dtype=np.float32); e2[20:35] = 1
+    a = colab.sample_conditionally(e1, T=3)
+    b = colab.sample_conditionally(e1, T=3)
+    c = colab.sample_conditionally(e2, T=3)
+    assert a.shape == (64, 64, 3) and a.dtype == np.uint8 and np.array_equal(a, b)
+    r = colab.sample_randomly(T=3)
+    assert r.shape == (64, 64, 3)
+    m = colab.test([colab.eval_iter.next() for _ in range(2)])
+    assert np.isfinite(m["eval_bpd"])
+    del c
