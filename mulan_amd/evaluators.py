@@ -258,6 +258,22 @@ def get_sample_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5
     return sample_fn
 
 
+def get_logits(experiment, num_batches=30):
+    """notebook_utils.get_logits (:534-545): encoder logits and the images they belong to, over eval batches"""
+    logits, images = [], []
+    for _ in range(num_batches):
+        batch = experiment.eval_iter.next()
+        logits.append(experiment.model.apply_encoder(experiment.orig_params, batch['images']))
+        images.append(batch['images'])
+    return torch.cat(logits), torch.cat(images)
+
+
+def logits_to_embeddings(logits):
+    """notebook_utils.logits_to_embeddings (:548-551): hard top-15 k-hot"""
+    from . import ops
+    return ops.topk_hard(logits, 15)[0]
+
+
 def _get_bpd_offset(dequantization, num_is):
     """notebook_utils._get_bpd_offset (:446-458)"""
     if dequantization == 'uniform':
