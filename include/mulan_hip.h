@@ -310,6 +310,16 @@ int mulan_topk_bwd(const float* logits, const float* soft, const float* nrm, con
 int mulan_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay,
                          float lr, float b1, float b2, float eps, float weight_decay, int step, float ema_rate,
                          float grad_scale, mulan_stream_t stream);
+/* optax.chain(clip_by_global_norm(c), adamw) (experiment.py:176-178, optional `gradient_clip_norm`):
+ * mulan_global_norm_clip writes out[0] = min(1, c / norm), out[1] = norm with norm = pre_scale * ||g||_2 (pre_scale =
+ * 1 / world: the norm of the rank-averaged gradient); mulan_adamw_ema_step_scaled multiplies the gradient by that
+ * device-resident factor on top of grad_scale, so no host synchronisation is needed. */
+size_t mulan_global_norm_clip_workspace(void);
+int mulan_global_norm_clip(const float* g, size_t n, float clip, float pre_scale, void* workspace, float* out,
+                           mulan_stream_t stream);
+int mulan_adamw_ema_step_scaled(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay,
+                                float lr, float b1, float b2, float eps, float weight_decay, int step, float ema_rate,
+                                float grad_scale, const float* grad_scale_dev, mulan_stream_t stream);
 /* N(0,1) draws: Philox4x32-10 + Box-Muller (stands in for jax.random.normal, model_mulan_velocity.py:223,235) */
 int mulan_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
 

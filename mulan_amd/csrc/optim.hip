@@ -12,11 +12,13 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v; float* ema;
   size_t n, n_decay;
   float lr, b1, b2, eps, wd, bc1, bc2, ema_rate, gscale;
+  const float* gscale_dev;   // optional extra factor computed on the device (global-norm clipping)
 };
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const size_t n4 = a.n >> 2;
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, ome = 1.f - a.ema_rate;
+  if (a.gscale_dev) a.gscale *= a.gscale_dev[0];
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
     const size_t i = q << 2;
     f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
@@ -55,6 +57,35 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   }
 }
 
+// optax.clip_by_global_norm (ldm/experiment.py:176-178): partial sums of squares of the flat gradient, then
+// scale = min(1, clip / (pre * sqrt(sum)))  (pre = 1 / world: the norm is that of the rank-averaged gradient)
+constexpr int kNormParts = 1024;
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double v = (double)g[i];
+    s += v * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void clip_scale_kernel(const double* __restrict__ part, float clip, float pre,
+                                                        float* __restrict__ out) {
+  double s = 0.0;
+  for (int j = threadIdx.x; j < kNormParts; j += 64) s += part[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) {
+    const double norm = (double)pre * sqrt(s);
+    out[0] = (float)fmin(1.0, (double)clip / norm);       // clip * min(1 / norm, 1 / clip)
+    out[1] = (float)norm;
+  }
+}
+
 // out[i] ~ N(0,1): Philox4x32-10(seed, counter = offset + i/4) + Box-Muller.
 __global__ void randn_kernel(float* __restrict__ out, size_t n, unsigned long long seed, unsigned long long offset) {
   const size_t n4 = (n + 3) >> 2;
@@ -77,18 +108,49 @@ __global__ void randn_kernel(float* __restrict__ out, size_t n, unsigned long lo
 
 }  // namespace
 
-MULAN_API int mulan_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n,
-                                   size_t n_decay, float lr, float b1, float b2, float eps, float weight_decay,
-                                   int step, float ema_rate, float grad_scale, hipStream_t stream) {
+static int adamw_launch(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay, float lr,
+                        float b1, float b2, float eps, float weight_decay, int step, float ema_rate, float grad_scale,
+                        const float* grad_scale_dev, hipStream_t stream) {
   if (step < 1) return (int)hipErrorInvalidValue;
   const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!(al(p) && al(g) && al(m) && al(v) && al(ema))) return (int)hipErrorInvalidValue;
   AdamArgs a{p, g, m, v, ema, n, n_decay, lr, b1, b2, eps, weight_decay,
-             (float)(1.0 - pow((double)b1, step)), (float)(1.0 - pow((double)b2, step)), ema_rate, grad_scale};
+             (float)(1.0 - pow((double)b1, step)), (float)(1.0 - pow((double)b2, step)), ema_rate, grad_scale,
+             grad_scale_dev};
   size_t blocks = ((n >> 2) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n,
+                                   size_t n_decay, float lr, float b1, float b2, float eps, float weight_decay,
+                                   int step, float ema_rate, float grad_scale, hipStream_t stream) {
+  return adamw_launch(p, g, m, v, ema, n, n_decay, lr, b1, b2, eps, weight_decay, step, ema_rate, grad_scale, nullptr,
+                      stream);
+}
+
+// The same step with the gradient additionally multiplied by grad_scale_dev[0], a factor that lives on the device
+// (mulan_global_norm_clip): optax.chain(clip_by_global_norm, adamw) of ldm/experiment.py:176-178 without a host sync.
+MULAN_API int mulan_adamw_ema_step_scaled(float* p, const float* g, float* m, float* v, float* ema, size_t n,
+                                          size_t n_decay, float lr, float b1, float b2, float eps, float weight_decay,
+                                          int step, float ema_rate, float grad_scale, const float* grad_scale_dev,
+                                          hipStream_t stream) {
+  if (!grad_scale_dev) return (int)hipErrorInvalidValue;
+  return adamw_launch(p, g, m, v, ema, n, n_decay, lr, b1, b2, eps, weight_decay, step, ema_rate, grad_scale,
+                      grad_scale_dev, stream);
+}
+
+MULAN_API size_t mulan_global_norm_clip_workspace(void) { return (size_t)kNormParts * sizeof(double); }
+
+// out[0] = min(1, clip / norm), out[1] = norm, norm = pre_scale * ||g||_2  (optax.clip_by_global_norm)
+MULAN_API int mulan_global_norm_clip(const float* g, size_t n, float clip, float pre_scale, void* workspace, float* out,
+                                     hipStream_t stream) {
+  if (n == 0 || !(clip > 0.f) || !workspace || !out) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(kNormParts), dim3(256), 0, stream, g, n, static_cast<double*>(workspace));
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(64), 0, stream, static_cast<const double*>(workspace), clip,
+                     pre_scale, out);
   MULAN_CHECK_LAUNCH();
 }
 

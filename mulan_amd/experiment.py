@@ -115,7 +115,8 @@ class Experiment(abc.ABC):
         learning_rate = self.lr_schedule(state.step)
         if packer is not None:
             packer.invalidate()              # the optimizer rewrites the parameters
-        state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate, grad_scale=1.0 / self.world)
+        state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate, grad_scale=1.0 / self.world,
+                              clip_norm=self.config.optimizer.get('gradient_clip_norm', None))
         scalars = parallel.allreduce_mean_scalars(metrics['scalars'], self.device)
         metrics['scalars'] = {'train_' + k: v for k, v in scalars.items()}
         return state, metrics

@@ -87,12 +87,15 @@ SIGNATURES = {
     "mulan_noise": [P, Z, U, U, I, F, F, P],
     "mulan_dequantize": [P, P, P, P, Z, I, F, P],
     "mulan_adamw_ema_step": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P],
+    "mulan_adamw_ema_step_scaled": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P, P],
+    "mulan_global_norm_clip_workspace": [],
+    "mulan_global_norm_clip": [P, Z, F, F, P, P, P],
     "mulan_randn": [P, Z, U, U, P],
     "mulan_version": [],
     "mulan_set_tuning": [I, I],
     "mulan_set_debug_buffer": [P],
 }
-_RESTYPES = {"mulan_rk_workspace_bytes": c_size_t, "mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
+_RESTYPES = {"mulan_rk_workspace_bytes": c_size_t, "mulan_global_norm_clip_workspace": c_size_t, "mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
              "mulan_conv3x3_pack_f16x3_bytes": c_size_t, "mulan_conv3x3_planes_bytes": c_size_t, "mulan_linear_pack_f16x3_bytes": c_size_t,
              "mulan_linear_wgrad_f16x3_planes_workspace": c_size_t,
              "mulan_conv3x3_wgrad_f16x3_planes_workspace": c_size_t, "mulan_conv3x3_wgrad_f16x3_workspace": c_size_t, "mulan_gemm_workspace": c_size_t, "mulan_version": c_char_p}

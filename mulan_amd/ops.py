@@ -1181,9 +1181,19 @@ def topk_embedding(logits, gnoise, k, tau=10.0):
 
 
 # ----------------------------------------------------------------------------- optimiser
-def adamw_ema_step(p, g, m, v, ema, n_decay, lr, b1, b2, eps, wd, step, ema_rate, grad_scale=1.0):
-    call("mulan_adamw_ema_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(lr),
-         float(b1), float(b2), float(eps), float(wd), int(step), float(ema_rate), float(grad_scale), stream())
+def adamw_ema_step(p, g, m, v, ema, n_decay, lr, b1, b2, eps, wd, step, ema_rate, grad_scale=1.0, clip_norm=None):
+    """one AdamW + EMA step on the flat buffers; clip_norm: optax.clip_by_global_norm in front (the factor is
+    computed and applied on the device).  Returns the [2] device tensor (factor, gradient norm) when clipping."""
+    if clip_norm is None:
+        call("mulan_adamw_ema_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(lr),
+             float(b1), float(b2), float(eps), float(wd), int(step), float(ema_rate), float(grad_scale), stream())
+        return None
+    ws = torch.empty(lib.load().mulan_global_norm_clip_workspace() // 8, device=p.device, dtype=torch.float64)
+    out = torch.empty(2, device=p.device, dtype=torch.float32)
+    call("mulan_global_norm_clip", ptr(g), g.numel(), float(clip_norm), float(grad_scale), ptr(ws), ptr(out), stream())
+    call("mulan_adamw_ema_step_scaled", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(lr),
+         float(b1), float(b2), float(eps), float(wd), int(step), float(ema_rate), float(grad_scale), ptr(out), stream())
+    return out
 
 
 # ----------------------------------------------------------------------------- ancestral sampler (eval only)

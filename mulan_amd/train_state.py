@@ -157,12 +157,14 @@ class TrainState:
                     leaf._gview.copy_(g)
                 leaf.grad = leaf._gview
 
-    def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0):
-        """TrainState.apply_gradients (ldm/train_state.py:70-102) on the flat gradient buffer."""
+    def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0, clip_norm=None):
+        """TrainState.apply_gradients (ldm/train_state.py:70-102) on the flat gradient buffer; clip_norm = the optional
+        optimizer.gradient_clip_norm (optax.clip_by_global_norm in front of AdamW, ldm/experiment.py:176-178)."""
         self.step += 1
         o = self.opt
-        ops.adamw_ema_step(self.flat, self.grad, self.mu, self.nu, self.ema, self.n_decay, lr, o["b1"], o["b2"],
-                           o["eps"], o["weight_decay"], self.step, ema_rate, grad_scale)
+        self.last_clip = ops.adamw_ema_step(self.flat, self.grad, self.mu, self.nu, self.ema, self.n_decay, lr, o["b1"],
+                                            o["b2"], o["eps"], o["weight_decay"], self.step, ema_rate, grad_scale,
+                                            clip_norm=clip_norm)
         return self
 
     # -- checkpoint form: {step, params, ema_params, opt_state} (ldm/train_state.py:62-68)

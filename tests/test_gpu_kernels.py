@@ -452,6 +452,30 @@ def test_adamw_ema_matches_oracle(ops):
         assert rel_err(got[:n].cpu().numpy(), ref) < 1e-6
 
 
+@pytest.mark.parametrize("clip", [0.3, 1e6])
+def test_adamw_with_global_norm_clipping(ops, clip):
+    """optax.chain(clip_by_global_norm(c), adamw): g <- g min(1, c / ||g||) with the norm of the rank-averaged
+    gradient (pre-scale 1/world = 0.5 here); clip active and inactive"""
+    rng = np.random.default_rng(13)
+    n, n_decay = 40000, 30000
+    p, g = rng.standard_normal(n), rng.standard_normal(n) * 0.01
+    m, v = 0.01 * rng.standard_normal(n), np.abs(rng.standard_normal(n)) * 1e-4
+    ema = p + 0.01 * rng.standard_normal(n)
+    mask = (np.arange(n) < n_decay).astype(np.float64)
+    gm = 0.5 * g
+    norm = np.sqrt((gm ** 2).sum())
+    factor = min(1.0, clip / norm)
+    rp, rm, rv, re_ = onp.adamw_ema_step(p, gm * factor, m, v, ema, 2e-4, 3, mask)
+    bufs = [dev(a) for a in (p, g, m, v, ema)]
+    out = ops.adamw_ema_step(bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], n_decay, 2e-4, 0.9, 0.99, 1e-8, 0.01, 3,
+                             0.9999, grad_scale=0.5, clip_norm=clip)
+    got_factor, got_norm = out.cpu().numpy()
+    assert abs(got_norm - norm) < 1e-5 * norm and abs(got_factor - factor) < 1e-5
+    assert (factor < 1.0) == (clip < 1.0)
+    for got, ref in zip((bufs[0], bufs[2], bufs[3], bufs[4]), (rp, rm, rv, re_)):
+        assert rel_err(got.cpu().numpy(), ref) < 2e-6
+
+
 def test_randn_moments(ops):
     z = ops.randn((1 << 20,), 1234, 0, "cuda").cpu().double().numpy()
     assert abs(z.mean()) < 5e-3 and abs(z.std() - 1) < 5e-3
