@@ -5,6 +5,9 @@ quoted on synthetic batches, so this module provides
   * 'synthetic'  : uniform random uint8 images, seeded per rank (bench / smoke / plumbing);
   * 'cifar10'    : the python-pickle CIFAR-10 archive (cifar-10-batches-py) read from
                    $MULAN_DATA_DIR, test split unshuffled for create_one_time_eval_dataset;
+  * 'imagenet32' : the downsampled-ImageNet 32x32 python pickles (train_data_batch_1..10, val_data: dict with
+                   'data' [N, 3072] uint8 in channel-major order and 'labels') under
+                   $MULAN_DATA_DIR/Imagenet32_train and Imagenet32_val (or both in $MULAN_DATA_DIR/imagenet32);
   * 'npz:<path>' : any .npz with uint8 `images` [N,32,32,3] (e.g. a downsampled-ImageNet-32 dump).
 Batch dict keys follow _preprocess_cifar10 (ldm/dataset.py:310-322): images u8, labels, conditioning.
 """
@@ -27,6 +30,30 @@ def _cifar_split(root, train):
     return np.concatenate(xs), np.concatenate(ys)
 
 
+def _imagenet32_split(root, train):
+    """downsampled ImageNet 32x32 as distributed by image-net.org (the source of TFDS downsampled_imagenet/32x32 that
+    the reference reads, ldm/dataset.py:187-199): pickled dicts, images flattened [N, 3 * 32 * 32] channel-major"""
+    cands = [os.path.join(root, "Imagenet32_train" if train else "Imagenet32_val"), os.path.join(root, "imagenet32")]
+    d = next((c for c in cands if os.path.isdir(c)), None)
+    if d is None:
+        raise FileNotFoundError(
+            "ImageNet-32 not found: set MULAN_DATA_DIR to the directory holding Imagenet32_train/ and Imagenet32_val/ "
+            "(train_data_batch_1..10 / val_data pickles), or use --config.data.dataset=npz:<file> / synthetic")
+    names = [f"train_data_batch_{i}" for i in range(1, 11)] if train else ["val_data"]
+    xs, ys = [], []
+    for n in names:
+        path = os.path.join(d, n)
+        if not os.path.isfile(path):
+            if train and xs:
+                break            # a partial download still trains
+            raise FileNotFoundError(path)
+        with open(path, "rb") as f:
+            e = pickle.load(f, encoding="latin1")
+        xs.append(np.asarray(e["data"], dtype=np.uint8).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
+        ys.append(np.asarray(e["labels"], dtype=np.int32) - 1)      # labels are 1-based in the archive
+    return np.concatenate(xs), np.concatenate(ys)
+
+
 def load_arrays(name, train):
     if name == "synthetic":
         return None, None
@@ -42,7 +69,9 @@ def load_arrays(name, train):
                 "CIFAR-10 not found: set MULAN_DATA_DIR to the directory holding cifar-10-batches-py/ "
                 "(or use --config.data.dataset=synthetic)")
         return _cifar_split(root, train)
-    raise NotImplementedError(f"dataset {name!r}: supported are synthetic, cifar10, npz:<file>")
+    if name == "imagenet32":
+        return _imagenet32_split(root, train)
+    raise NotImplementedError(f"dataset {name!r}: supported are synthetic, cifar10, imagenet32, npz:<file>")
 
 
 class BatchStream:

@@ -256,3 +256,29 @@ def test_ode_evaluator_host_logic():
     assert g.shape == (4, 4, 3)
     assert np.array_equal(g[:2, :2], imgs[1]) and np.array_equal(g[:2, 2:], imgs[0])   # rows run right to left
     assert np.array_equal(g[2:, :2], imgs[3]) and np.array_equal(g[2:, 2:], imgs[2])
+
+
+def test_imagenet32_pickle_reader(tmp_path, monkeypatch):
+    """downsampled-ImageNet 32x32 archives: channel-major rows -> [N, 32, 32, 3], 1-based labels, unshuffled
+    validation order for create_one_time_eval_dataset"""
+    import pickle
+    import numpy as np
+    from mulan_amd import data
+    rng = np.random.default_rng(0)
+    val = rng.integers(0, 256, (6, 3072), dtype=np.uint8)
+    tr1 = rng.integers(0, 256, (5, 3072), dtype=np.uint8)
+    (tmp_path / "Imagenet32_val").mkdir()
+    (tmp_path / "Imagenet32_train").mkdir()
+    with open(tmp_path / "Imagenet32_val" / "val_data", "wb") as f:
+        pickle.dump({"data": val, "labels": [1, 2, 3, 4, 5, 1000]}, f)
+    with open(tmp_path / "Imagenet32_train" / "train_data_batch_1", "wb") as f:
+        pickle.dump({"data": tr1, "labels": [7] * 5}, f)
+    monkeypatch.setenv("MULAN_DATA_DIR", str(tmp_path))
+    x, y = data.load_arrays("imagenet32", train=False)
+    assert x.shape == (6, 32, 32, 3) and list(y) == [0, 1, 2, 3, 4, 999]
+    assert np.array_equal(x[2, 5, 7], val[2].reshape(3, 32, 32)[:, 5, 7])
+    xt, yt = data.load_arrays("imagenet32", train=True)          # only the first training shard is present
+    assert xt.shape == (5, 32, 32, 3) and set(yt) == {6}
+    stream = data.BatchStream("imagenet32", 4, train=False, device="cpu", one_pass=True)
+    first = next(iter(stream))
+    assert np.array_equal(first["images"].numpy(), x[:4])
