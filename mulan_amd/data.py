@@ -86,6 +86,9 @@ class BatchStream:
         self.one_pass = one_pass
         self.rank, self.world = rank, world
         self.x, self.y = load_arrays(name, train)
+        # cifar10_aug (ldm/dataset.py:125-131, 358-376): the train stream gets a random left/right flip and a random
+        # rotation by 90 / 180 / 270 degrees, each with probability 1/2; `conditioning` flags augmented images
+        self.augment = train and name == "cifar10_aug"
         self.gen = np.random.default_rng([int(seed), int(rank), int(train)])
         self.pos = 0
         if self.x is not None and not one_pass and train:
@@ -131,10 +134,22 @@ class BatchStream:
         n = self.local * (s or 1)
         img, lab = self._batch(n)
         shape = (s, self.local) if s else (self.local,)
-        images = torch.from_numpy(img.reshape(*shape, 32, 32, 3)).to(self.device, non_blocking=True)
+        cond = np.zeros(n, dtype=np.uint8)
+        if self.augment:
+            img = img.copy()
+            flip = self.gen.random(n) > 0.5
+            k = np.ceil(3.0 * self.gen.random(n)).astype(np.int64)
+            rot = self.gen.random(n) > 0.5
+            for i in range(n):
+                if flip[i]:
+                    img[i] = img[i][:, ::-1]
+                if rot[i]:
+                    img[i] = np.rot90(img[i], k=int(k[i]), axes=(0, 1))
+            cond = (flip | rot).astype(np.uint8)
+        images = torch.from_numpy(np.ascontiguousarray(img).reshape(*shape, 32, 32, 3)).to(self.device, non_blocking=True)
         labels = torch.from_numpy(lab.reshape(*shape)).to(self.device)
         return {"images": images, "labels": labels,
-                "conditioning": torch.zeros(shape, dtype=torch.uint8, device=self.device)}
+                "conditioning": torch.from_numpy(cond.reshape(*shape)).to(self.device)}
 
     next = __next__
 

@@ -282,3 +282,37 @@ def test_imagenet32_pickle_reader(tmp_path, monkeypatch):
     stream = data.BatchStream("imagenet32", 4, train=False, device="cpu", one_pass=True)
     first = next(iter(stream))
     assert np.array_equal(first["images"].numpy(), x[:4])
+
+
+def test_cifar10_aug_stream_flags_augmented_images(tmp_path, monkeypatch):
+    """cifar10_aug (ldm/dataset.py:358-376): flips / 90-degree rotations on the train stream only, conditioning = 1 for
+    augmented images, which are then a flip / rotation of an archive image; the eval stream is untouched"""
+    import pickle
+    import numpy as np
+    from mulan_amd import data
+    rng = np.random.default_rng(1)
+    d = tmp_path / "cifar-10-batches-py"
+    d.mkdir()
+    raw = rng.integers(0, 256, (10, 3072), dtype=np.uint8)
+    for name in [f"data_batch_{i}" for i in range(1, 6)] + ["test_batch"]:
+        with open(d / name, "wb") as f:
+            pickle.dump({b"data": raw, b"labels": list(range(10))}, f)
+    monkeypatch.setenv("MULAN_DATA_DIR", str(tmp_path))
+    imgs = raw.reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+    variants = {}
+    for i, im in enumerate(imgs):
+        for fl in (False, True):
+            a = im[:, ::-1] if fl else im
+            for k in range(4):
+                variants.setdefault(np.rot90(a, k=k, axes=(0, 1)).tobytes(), []).append((i, fl, k))
+    st = data.BatchStream("cifar10_aug", 8, train=True, device="cpu", seed=3, substeps=2)
+    b = next(st)
+    assert b["images"].shape == (2, 8, 32, 32, 3) and b["conditioning"].dtype == torch.uint8
+    x, c = b["images"].reshape(-1, 32, 32, 3).numpy(), b["conditioning"].reshape(-1).numpy()
+    assert 0 < c.sum() < len(c)
+    for im, flag in zip(x, c):
+        hits = variants[im.tobytes()]
+        assert any(bool(fl or k) == bool(flag) for _, fl, k in hits)
+    ev = data.BatchStream("cifar10_aug", 4, train=False, device="cpu")
+    e = next(ev)
+    assert int(e["conditioning"].sum()) == 0 and np.array_equal(e["images"].numpy(), imgs[:4])
