@@ -94,7 +94,8 @@ def _ext_hook(code, data):
 def _unchunk(tree):
     if isinstance(tree, dict):
         if '__msgpack_chunked_array__' in tree:
-            shape = tuple(tree['shape'])
+            sh = tree['shape']       # flax stores the shape as _tuple_to_dict: {'0': d0, '1': d1, ...}
+            shape = tuple(int(sh[str(i)]) for i in range(len(sh))) if isinstance(sh, dict) else tuple(int(d) for d in sh)
             chunks = tree['chunks']
             flat = np.concatenate([np.asarray(chunks[str(i)]).reshape(-1) for i in range(len(chunks))])
             return flat.reshape(shape)
@@ -110,10 +111,36 @@ def load_flax(path):
     return _normalise_flax_state(tree)
 
 
+# The polynomial schedule network declares its layers in setup() as attributes l1, l2, l3_a, l3_b, l3_c AND passes
+# name='dense_1' ... 'dense_out_c' (ldm/model_mulan_epsilon.py:493-512): depending on the Flax version the parameter
+# collection is keyed by the explicit names or by the attribute names.  Both are accepted; the build's canonical names
+# are the explicit ones.
+GAMMA_NET_ALIASES = {"l1": "dense_1", "l2": "dense_2", "l3_a": "dense_out_a", "l3_b": "dense_out_b", "l3_c": "dense_out_c"}
+
+
+def canonical_param_names(tree):
+    """A parameter-shaped tree (params, ema_params, Adam mu / nu) with the gamma network's attribute-style layer names
+    mapped onto the canonical ones, and a single wrapping {'params': ...} level removed."""
+    if not isinstance(tree, dict):
+        return tree
+    if set(tree.keys()) == {"params"} and isinstance(tree["params"], dict):
+        tree = tree["params"]
+    out = dict(tree)
+    g = out.get("gamma")
+    if isinstance(g, dict) and any(k in g for k in GAMMA_NET_ALIASES):
+        clash = [k for k in g if k in GAMMA_NET_ALIASES and GAMMA_NET_ALIASES[k] in g]
+        if clash:
+            raise ValueError(f"gamma network holds both spellings of {clash}")
+        out["gamma"] = {GAMMA_NET_ALIASES.get(k, k): v for k, v in g.items()}
+    return out
+
+
 def _normalise_flax_state(sd):
-    """Maps the reference's opt_state (2-tuple of masked AdamW states, ldm/experiment.py:170-173) onto
-    {'mu','nu'} and leaves params/ema_params/step untouched."""
-    out = {k: sd[k] for k in ("step", "params", "ema_params") if k in sd}
+    """Maps the reference's opt_state (optax.chain of two optax.masked AdamW states, ldm/experiment.py:151-173; as a
+    Flax state dict: {'0': {'inner_state': {'0': {count, mu, nu}, '1': {}, '2': {}}}, '1': {...}} with masked-out
+    leaves serialised as empty nodes) onto {'mu','nu'}, resolves the gamma-network name aliases, and leaves
+    step untouched."""
+    out = {k: canonical_param_names(sd[k]) if k != "step" else sd[k] for k in ("step", "params", "ema_params") if k in sd}
     if "step" in out:
         out["step"] = int(np.asarray(out["step"]))
     opt = sd.get("opt_state")
@@ -130,7 +157,7 @@ def _normalise_flax_state(sd):
     if opt is not None:
         walk(opt)
         if mus:
-            out["opt_state"] = {"mu": mus, "nu": nus}
+            out["opt_state"] = {"mu": canonical_param_names(mus), "nu": canonical_param_names(nus)}
     return out
 
 

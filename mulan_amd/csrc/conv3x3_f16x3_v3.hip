@@ -1,0 +1,370 @@
+// 3x3 convolution, f16x3 arithmetic (see conv3x3_f16x3.hip), third generation: the forward AND input-gradient kernel of
+// the ResnetBlock convolutions (ldm/model_vdm.py:633-650) for C % 32 == 0, N % 128 == 0.
+//
+// What changed against conv3x3_f16x3_v2_kernel, and why (profiles/r02_shape_probe.log, tools/shape_probe.hip):
+//  * TWO co-resident blocks per CU (<= 256 registers, 64 KB of LDS each) with a static priority for every second one.
+//    With one block per CU the epilogue of a tile (15-21 k of 85 k cycles: 128 KB read + 128 KB written per CU, all CUs
+//    at the same moment) leaves the matrix cores idle.  s_setprio is strict for MFMA issue (a prioritised wave runs at
+//    its solo speed, the other one fills every gap), so the prioritised block runs ahead and each block's prologue /
+//    epilogue is covered by the other block's main loop; blocks i and i + 256 share a CU (breadth-first dispatch,
+//    measured; used for speed only).
+//  * v_mfma_f32_16x16x32_f16 instead of 32x32x16: the chip is power limited under this load (a bare 32x32x16 loop holds
+//    1.69 GHz) and holds a ~19 % higher clock on the 16x16 shape at the same operand traffic.
+//  * Roles swapped: A = weights (rows = couts), B = pixels (columns), so a lane's 4 accumulator registers of a tile are
+//    4 consecutive couts of one pixel: the epilogue adds bias / FiLM bias / residual and stores float4s straight from
+//    the accumulator layout, no LDS transpose.
+//
+// K = 32 of one MFMA = two "units" (16-channel chunk, tap): lanes 0-31 carry unit 2s, lanes 32-63 unit 2s + 1 of the
+// sequence u = chunk * 9 + tap; nine steps cover a chunk pair.  Block = 8 image rows x 128 couts, wave = all 8 rows x 32
+// couts = 16 pixel tiles x 2 cout tiles (128 accumulator registers; only 16 registers of weight fragments per step, and
+// no two waves fetch the same weights).  Patches: [plane][row][col][16 ch] fp16, 32 B per
+// pixel and plane (conflict-free for the ds_read_b128 lane groups of this operand layout), three 16-channel buffers in
+// rotation (chunk c, c + 1 being multiplied, c + 2 / c + 3 being filled), two barriers per chunk pair.  Weight
+// fragments come straight from the packed tensor (L1 / L2 resident), one step ahead.
+#include <type_traits>
+#include "common.h"
+#include "f16x3_common.h"
+
+namespace {
+
+using namespace f16x3;
+
+constexpr int TR3 = 8;
+constexpr int P3_ROWS = TR3 + 2;                    // 10
+constexpr int P3_PLANE = P3_ROWS * kPW * 32;        // 10880 B: one plane of one 16-channel chunk
+constexpr int P3_BUF = 2 * P3_PLANE;                // 21760
+constexpr int P3_DUMMY = 3 * P3_BUF;                // 512 B dummy target for the slots past the patch
+constexpr int SMEM3_B = 3 * P3_BUF + 512;           // 65792: two blocks per CU fit the 160 KB
+constexpr int PV3 = 6;                              // float4 patch slots per thread and chunk (1360 of 1536 used)
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// acc += A B in place on accumulator registers ("a" class): the 128 accumulator registers stay out of the compiler's
+// allocation games (with the builtin it rotates them through the vector registers and spills at the 256-register cap).
+// PAD: two wait states in front for a VALU-written operand (the weight-fragment copy at the end of a chunk pair).
+template <bool PAD>
+__device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const f16x3::f16x8& b, bool) {
+  if (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// ABL: dev-only ablation bits (timing only, results wrong): 1 no LDS fragment reads, 2 no weight loads, 4 no patch
+// fills, 8 no barriers in the main loop
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, grp = lane >> 4, sel = lane >> 5, khalf = grp & 1;
+  const int tiles_per_img = p.H / TR3;
+  const int b = blockIdx.x / tiles_per_img;
+  const int h0 = (blockIdx.x % tiles_per_img) * TR3;
+  const int n0 = blockIdx.y * BN;
+  const int C = p.C, N = p.N;
+  const int nchunks = C / CK, npairs = nchunks / 2;
+  // every second block of a CU runs ahead (blocks i and i + 256 share a CU under breadth-first dispatch)
+  if (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+  float sx, inv_x, sw, inv_w;
+  scale_of(row_max16(p.xmax, b), sx, inv_x);
+  scale_of(row_max16(p.wmax, 0), sw, inv_w);
+  // dev-only timeline (mulan_set_debug_buffer; tools/conv_ab.py --timeline): per block start / loop start / loop end / end
+  const unsigned tl_blk = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool tl = p.stamps && tid == 0 && tl_blk < 2048;
+  if (tl) p.stamps[64 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
+
+  f32x4v acc[16][2];                                 // [pixel tile][cout tile]
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x), 0, (int)((size_t)p.B * p.H * kW * C * 4), kBufWord3);
+  const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(p.wp), 0, 9 * C * N * 4, kBufWord3);
+  const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      p.xs + (size_t)b * nchunks * 65536, 0, (p.xs && blockIdx.y == 0) ? nchunks * 65536 : 0, kBufWord3);
+
+  // ---- patch slots: slot = tid + 256 s -> (pixel of the 10 x 34 halo patch, channel quad q = tid & 3).  The slot
+  // geometry is recomputed where it is used (from a laundered tid, so that it is not hoisted into 18 live registers).
+  struct Slot { unsigned goff; int ldst; unsigned emit; };
+  auto slot_of = [&](int t, int s) {
+    const int slot = t + s * 256;
+    const int q = slot & 3, pix = slot >> 2;
+    const int prow = pix / kPW, pcol = pix - prow * kPW;
+    const int hh = h0 + prow - 1, ww = pcol - 1;
+    // (bitwise, not short-circuit: these must stay selects, a branch would split the loop body)
+    const bool inb = slot < P3_ROWS * kPW * 4;
+    const bool ok = inb & ((unsigned)hh < (unsigned)p.H) & ((unsigned)ww < (unsigned)kW);
+    Slot r;
+    const unsigned g = (unsigned)((((b * p.H + hh) * kW + ww) * C + q * 4) * 4);
+    r.goff = ok ? g : 0x80000000u;
+    r.ldst = inb ? pix * 32 + q * 8 : P3_DUMMY + (t & 63) * 8;
+    const bool interior = inb & ((unsigned)(prow - 1) < (unsigned)TR3) & ((unsigned)ww < (unsigned)kW);
+    const unsigned e = (unsigned)(((hh * kW + ww) * 2) * 32 + q * 8);
+    r.emit = interior ? e : 0xffffffffu;
+    return r;
+  };
+  auto load_slot = [&](const Slot& sl, int cc) {
+    return __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, sl.goff, cc * CK * 4, 0);
+  };
+  // split one float4 and store it into patch buffer `pbuf` (byte offset in LDS) and into the plane tensor
+  auto store_slot = [&](int pbuf, const Slot& sl, i32x4 raw, int cc) {
+    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 h, l;
+      split2(v[e] * sx, h, l);
+      hi[e] = h; lo[e] = l;
+    }
+    unsigned char* d = smem + (sl.ldst >= P3_DUMMY ? sl.ldst : pbuf + sl.ldst);
+    *reinterpret_cast<f16x4*>(d) = hi;
+    *reinterpret_cast<f16x4*>(d + (sl.ldst >= P3_DUMMY ? 0 : P3_PLANE)) = lo;
+    const unsigned eo = sl.emit != 0xffffffffu ? sl.emit + (unsigned)cc * 65536u : 0xffffffffu;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), xs_rsrc, eo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo == 0xffffffffu ? eo : eo + 32, 0, 0);
+  };
+
+  // ---- operand addressing
+  // pixel fragments (B operand): lane = pixel l15 of the 16-pixel tile, k group grp: channels khalf * 8 .. + 7 of unit sel
+  const int xlane = l15 * 32 + khalf * 16;
+  // weight fragments (A operand): lane = cout l15 of the 16-cout tile, same k groups
+  const unsigned wlane = (unsigned)((n0 + wave * 32 + l15) * 64 + khalf * 16);
+  const int unit_stride = N * 64;                    // bytes between (tap, chunk) tiles of the packed weights
+
+  f16x8 wf[2][2][2];                                 // [buffer][cout tile][plane]
+  f16x8 xf[3][2];                                    // [ring slot][plane]: fragments are read two pixel tiles ahead
+  auto load_w = [&](f16x8 (&w)[2][2], int uA, int uB) {        // uA / uB: tile index tap * nchunks + chunk of lanes < 32 / >= 32
+    const int umin = min(uA, uB);                                // (offsets stay non-negative: the range check is unsigned)
+    const unsigned vo = wlane + (unsigned)(((sel ? uB : uA) - umin) * unit_stride);
+    const int so = umin * unit_stride;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        w[ct][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wp_rsrc, vo + ct * 1024 + pl * 32, so, 0));
+  };
+  auto load_w1 = [&](f16x8 (&w)[2][2], int uA, int uB, int i, int sl) {  // fragment i = 2 ct + plane of the same
+    const int umin = min(uA, uB);
+    const unsigned vo = wlane + (unsigned)(((sl ? uB : uA) - umin) * unit_stride);
+    w[i >> 1][i & 1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wp_rsrc, vo + (i >> 1) * 1024 + (i & 1) * 32,
+                                                                                      umin * unit_stride, 0));
+  };
+  auto read_x = [&](f16x8 (&x)[2], int xaddr, int pt) {
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      x[pl] = *reinterpret_cast<const f16x8*>(smem + xaddr + ((pt >> 1) * kPW + (pt & 1) * 16) * 32 + pl * P3_PLANE);
+  };
+  // unit u of a chunk pair (0..17): chunk u / 9 of the pair, tap u % 9
+  auto tile_index = [&](int j, int u) { return (u % 9) * nchunks + 2 * j + u / 9; };
+  auto x_unit_off = [&](int bufA, int bufB, int u) {
+    const int tap = u % 9;
+    return (u / 9 ? bufB : bufA) + ((tap / 3) * kPW + tap % 3) * 32;
+  };
+
+  // ---- prologue: chunks 0 and 1 into buffers 0 and 1, weights of step 0
+  int bufA = 0, bufB = P3_BUF, bufC = 2 * P3_BUF;
+  {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      i32x4 r[PV3];
+#pragma unroll
+      for (int s = 0; s < PV3; ++s) r[s] = load_slot(slot_of(tid, s), c);
+#pragma unroll
+      for (int s = 0; s < PV3; ++s) store_slot(c ? bufB : bufA, slot_of(tid, s), r[s], c);
+    }
+  }
+  load_w(wf[0], tile_index(0, 0), tile_index(0, 1));
+  // patch slots in flight: two register sets (A, B) of two slots each, fetched two steps before they are split and
+  // stored (the fetch is an HBM / Infinity-Cache access; one step is ~1.5 k cycles of MFMA issue):
+  //   step:   0        1        2        3        4        5        6        7        8
+  //   store:  A k0 c0  B k1 c0  A k2 c0  -        -        A k0 c1  B k1 c1  A k2 c1  -
+  //   fetch:  A k2 c0  -        -        A k0 c1  B k1 c1  A k2 c1  -        A k0 c0' B k1 c0'
+  // (k: slot pair, c0 / c1: the two chunks being filled, c0': the first chunk of the next pair's fill)
+  i32x4 stgA[2], stgB[2];
+  {
+    const int c2 = nchunks > 2 ? 2 : nchunks - 1;
+    stgA[0] = load_slot(slot_of(tid, 0), c2);
+    stgA[1] = load_slot(slot_of(tid, 1), c2);
+    stgB[0] = load_slot(slot_of(tid, 2), c2);
+    stgB[1] = load_slot(slot_of(tid, 3), c2);
+  }
+  __syncthreads();
+  int xaddr = xlane + (sel ? x_unit_off(bufA, bufB, 1) : x_unit_off(bufA, bufB, 0));   // of the step being multiplied
+  read_x(xf[0], xaddr, 0);
+  read_x(xf[1], xaddr, 1);
+
+  if (tl) p.stamps[65 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long cyc0 = tl ? __builtin_amdgcn_s_memtime() : 0ull;
+  for (int j = 0; j < npairs; ++j) {
+    int t_l = tid;
+    asm volatile("" : "+v"(t_l));                    // launder: slot geometry is recomputed inside the loop
+    const int cfill0 = min(2 * j + 2, nchunks - 1), cfill1 = min(2 * j + 3, nchunks - 1);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      // next step's operands: step s + 1 of this pair, or step 0 of the next pair (buffers rotated: A' = C, B' = A);
+      // past the end: a harmless reload of the last step.  (The lane's unit selector is laundered per step so that the
+      // nine selected tap offsets are formed where they are used instead of living in registers across the loop.)
+      const bool last = (s == 8);
+      const bool over = last && (j + 1 >= npairs);
+      const int jn = last ? (over ? j : j + 1) : j;
+      const int sn = last ? (over ? 8 : 0) : s + 1;
+      const int nA = (last && !over) ? bufC : bufA, nB = (last && !over) ? bufA : bufB;
+      int sel_s = sel;
+      asm volatile("" : "+v"(sel_s));
+      const int xaddr_n = xlane + (sel_s ? x_unit_off(nA, nB, 2 * sn + 1) : x_unit_off(nA, nB, 2 * sn));
+      const int uAn = tile_index(jn, 2 * sn), uBn = tile_index(jn, 2 * sn + 1);
+      // patch traffic of this step (table above): steps 0-2 fill chunk 2 j + 2 into buffer C, steps 5-7 chunk 2 j + 3
+      // into buffer A (free after the step-4 barrier)
+      const bool fill0 = s <= 2, fill1 = s >= 5 && s <= 7;
+      const int fk = fill0 ? s : s - 5;              // slot pair stored in this step
+      const bool st_useB = (fk == 1);
+      int lk = -1, lcc = 0;                          // slot pair fetched in this step and its chunk
+      if (s == 0) { lk = 2; lcc = cfill0; }
+      else if (s == 3) { lk = 0; lcc = cfill1; }
+      else if (s == 4) { lk = 1; lcc = cfill1; }
+      else if (s == 5) { lk = 2; lcc = cfill1; }
+      else if (s == 7) { lk = 0; lcc = min(2 * j + 4, nchunks - 1); }
+      else if (s == 8) { lk = 1; lcc = min(2 * j + 4, nchunks - 1); }
+      const bool ld_useB = (lk == 1);
+      // The MFMAs are volatile asm statements: memory operations keep their place between them (this is the issue
+      // order), the address / split arithmetic floats into the shadows.
+#pragma unroll
+      for (int pt = 0; pt < 16; ++pt) {
+        const int cur = (s * 16 + pt) % 3, nxt = (cur + 2) % 3;
+        const int xa = pt < 14 ? xaddr : xaddr_n, pn = pt < 14 ? pt + 2 : pt - 14;
+        const int xo = ((pn >> 1) * kPW + (pn & 1) * 16) * 32;
+        // small terms first: w_l x_h, w_h x_l, w_h x_h; the two cout tiles alternate so that an MFMA never waits for the
+        // accumulator of the one right in front of it
+        if (pt == 0) mfma16<true>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
+        else mfma16<false>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
+        if (!(ABL & 1)) xf[nxt][0] = *reinterpret_cast<const f16x8*>(smem + xa + xo);
+        mfma16<false>(acc[pt][1], wf[s & 1][1][1], xf[cur][0], false);
+        mfma16<false>(acc[pt][0], wf[s & 1][0][0], xf[cur][1], false);
+        if (!(ABL & 2) && pt >= 1 && pt <= 4) load_w1(wf[(s + 1) & 1], uAn, uBn, pt - 1, sel_s);
+        if (!(ABL & 4) && (pt == 6 || pt == 8) && (fill0 || fill1)) {
+          i32x4& r = st_useB ? stgB[pt == 8] : stgA[pt == 8];
+          asm volatile("" : "+v"(r));                // pins the split arithmetic here (it would float to the step's top)
+          store_slot(fill0 ? bufC : bufA, slot_of(t_l, 2 * fk + (pt == 8)), r, fill0 ? cfill0 : cfill1);
+        }
+        if (!(ABL & 4) && (pt == 10 || pt == 12) && lk >= 0)
+          (ld_useB ? stgB[pt == 12] : stgA[pt == 12]) = load_slot(slot_of(t_l, 2 * lk + (pt == 12)), lcc);
+        mfma16<false>(acc[pt][1], wf[s & 1][1][0], xf[cur][1], false);
+        if (!(ABL & 1)) xf[nxt][1] = *reinterpret_cast<const f16x8*>(smem + xa + xo + P3_PLANE);
+        mfma16<false>(acc[pt][0], wf[s & 1][0][0], xf[cur][0], false);
+        mfma16<false>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
+      }
+      xaddr = xaddr_n;
+      if (!(ABL & 8) && (s == 4 || s == 8)) __syncthreads();
+    }
+    const int t = bufA; bufA = bufC; bufC = bufB; bufB = t;      // (A, B, C) <- (C, A, B)
+    // nine steps per pair: the weights fetched during step 8 sit in buffer 1, the next pair starts on buffer 0
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) wf[0][ct][pl] = wf[1][ct][pl];
+  }
+  // the accumulators were written by matrix instructions the compiler does not see: let them retire before they are read
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if (tl) p.stamps[66 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
+  if (tl && tl_blk < 32) p.stamps[tl_blk] = __builtin_amdgcn_s_memtime() - cyc0;   // core cycles spent in the main loop
+
+  // ---- epilogue: straight from the accumulator layout (lane: pixel l15 of the tile, couts 4 grp .. 4 grp + 3)
+  scale_of(row_max16(p.xmax, b), sx, inv_x);         // (re-derived here: nothing of it lives across the main loop)
+  scale_of(row_max16(p.wmax, 0), sw, inv_w);
+  const float* __restrict__ res = p.res;
+  const float* __restrict__ cbp = p.cbias;
+  float* __restrict__ yout = p.y;
+  const int nb = n0 + wave * 32 + grp * 4;
+  f32x4 bias4[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    bias4[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4[ct] = *reinterpret_cast<const f32x4*>(p.bias + nb + ct * 16);
+    if (p.cbias_mode == 1) {
+      const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + (size_t)b * N + nb + ct * 16);
+      bias4[ct][0] += c[0]; bias4[ct][1] += c[1]; bias4[ct][2] += c[2]; bias4[ct][3] += c[3];
+    }
+  }
+  unsigned omax = 0;
+  // one straight-line body per (residual, per-pixel FiLM bias) combination: the loads of all tiles can be in flight together
+  auto finish = [&](auto has_res, auto has_cb2) {
+#pragma unroll
+    for (int pt = 0; pt < 16; ++pt) {
+      const size_t pixbase = ((((size_t)b * p.H + h0 + (pt >> 1)) * kW) + (pt & 1) * 16 + l15) * N + nb;
+      f32x4 add[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) add[ct] = bias4[ct];
+      if constexpr (decltype(has_cb2)::value) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(cbp + pixbase + ct * 16);
+          add[ct][0] += c[0]; add[ct][1] += c[1]; add[ct][2] += c[2]; add[ct][3] += c[3];
+        }
+      }
+      if constexpr (decltype(has_res)::value) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(res + pixbase + ct * 16);
+          add[ct][0] += c[0]; add[ct][1] += c[1]; add[ct][2] += c[2]; add[ct][3] += c[3];
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (acc[pt][ct][e] * inv_x) * inv_w + add[ct][e];
+          omax = max(omax, __float_as_uint(o[e]) & 0x7fffffffu);
+        }
+        *reinterpret_cast<f32x4*>(yout + pixbase + ct * 16) = o;
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  if (res) { if (p.cbias_mode == 2) finish(T{}, T{}); else finish(T{}, F{}); }
+  else { if (p.cbias_mode == 2) finish(F{}, T{}); else finish(F{}, F{}); }
+  if (p.ymax) {   // this block is partial maximum number (row tile, cout block) of image b; unused entries zeroed
+    const int part = (h0 / TR3) * gridDim.y + blockIdx.y, nparts = tiles_per_img * gridDim.y;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+    __syncthreads();
+    unsigned* ured = reinterpret_cast<unsigned*>(smem);
+    if (lane == 0) ured[wave] = omax;
+    __syncthreads();
+    if (tid == 0) p.ymax[b * 16 + part] = max(max(ured[0], ured[1]), max(ured[2], ured[3]));
+    if (part == 0 && tid >= nparts && tid < 16) p.ymax[b * 16 + tid] = 0u;
+  }
+  if (tl) p.stamps[67 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
+}
+
+}  // namespace
+
+bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N) { return H % TR3 == 0 && C % 32 == 0 && N % BN == 0; }
+
+int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream) {
+  const dim3 grid(a.B * (a.H / TR3), a.N / BN);
+#define MULAN_V3_LAUNCH(ABL)                                                                                          \
+  {                                                                                                                   \
+    static bool configured = false;                                                                                   \
+    if (!configured) {                                                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<ABL>),                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);                        \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      configured = true;                                                                                              \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(conv3x3_f16x3_v3_kernel<ABL>, grid, dim3(256), SMEM3_B, stream, a);                            \
+  }
+  switch (g_mulan_tune[4]) {   // dev-only ablations (tools/conv_ab.py --ablate)
+    case 1: MULAN_V3_LAUNCH(1) break;
+    case 2: MULAN_V3_LAUNCH(2) break;
+    case 4: MULAN_V3_LAUNCH(4) break;
+    case 8: MULAN_V3_LAUNCH(8) break;
+    case 15: MULAN_V3_LAUNCH(15) break;
+    default: MULAN_V3_LAUNCH(0) break;
+  }
+#undef MULAN_V3_LAUNCH
+  return (int)hipGetLastError();
+}

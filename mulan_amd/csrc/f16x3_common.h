@@ -1,0 +1,66 @@
+// Shared pieces of the f16x3 kernels (conv3x3_f16x3.hip, conv3x3_f16x3_v3.hip): operand scales, the fp32 -> 2 x fp16
+// split, the maxima format and the argument block of the forward / input-gradient convolution.
+#pragma once
+#include "common.h"
+
+namespace f16x3 {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kW = 32, kPW = 34, CK = 16, TROWS = 4;
+constexpr int PIXB = 80;                        // bytes per patch pixel: 2 planes x 32 B + 16 pad ((PIXB/16) odd)
+constexpr int NB = 80;                          // bytes per cout row of a weight tile
+constexpr int PATCH_B = (TROWS + 2) * kPW * PIXB;   // 16320
+constexpr int BN = 128;
+constexpr int WT_B = BN * NB;                   // 10240
+constexpr int SMEM_B = PATCH_B + 3 * WT_B;      // 47040 (dynamic shared memory): 1 patch + 3-deep weight ring
+
+// ---- power-of-two scales from an absolute maximum given as fp32 bits
+// s = 2^(140 - e) with e the (clamped) biased exponent of the maximum: max * s in [2^13, 2^14).  inv = 1 / s.
+__device__ __forceinline__ void scale_of(unsigned maxbits, float& s, float& inv) {
+  int e = (int)((maxbits >> 23) & 255u);
+  e = e < 14 ? 14 : (e > 254 ? 254 : e);
+  s = __uint_as_float((unsigned)(267 - e) << 23);
+  inv = __uint_as_float((unsigned)(e - 13) << 23);
+}
+
+// Maxima arrays hold kMaxParts partial maxima per row (fp32 bit patterns; producers write their partials without
+// atomics or a zero-fill pass, unused entries are 0); consumers take the maximum of the 16 entries of a row.
+constexpr int kMaxParts = 16;
+__device__ __forceinline__ unsigned row_max16(const unsigned* __restrict__ m, int row) {
+  const unsigned* r = m + (size_t)row * kMaxParts;
+  unsigned v = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxParts; ++i) v = max(v, r[i]);
+  return v;
+}
+
+__device__ __forceinline__ void split2(float vs, _Float16& h, _Float16& l) {
+  h = (_Float16)vs;
+  l = (_Float16)(vs - (float)h);
+}
+
+struct ConvArgsH {
+  const float* x;            // [B,H,32,C] fp32
+  const unsigned* xmax;      // [B] fp32 bits of max|x[b]|
+  const unsigned char* wp;   // packed weights [9][C/16][N][2][16] fp16 (scaled)
+  const unsigned* wmax;      // [1] fp32 bits of max|w|
+  const float* bias; const float* cbias; const float* res;
+  float* y;
+  int B, H, C, N, cbias_mode;
+  unsigned long long* stamps;   // dev-only (mulan_set_debug_buffer)
+  unsigned char* xs;            // optional by-product: the split planes of x, [B][C/16][H*W][plane][16] fp16
+  unsigned* ymax;               // optional by-product: [B][16] partial maxima of |y| (mulan_absmax_rows format)
+};
+
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBufWord3 = 0x00020000;           // raw buffer resource (no swizzle); out-of-range lanes are dropped / read 0
+
+
+}  // namespace f16x3
+
+// conv3x3_f16x3_v3.hip: 16x16x32 MFMA, two co-resident blocks per CU; returns a hipError_t as int
+int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream);
+bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N);

@@ -5,9 +5,13 @@ quoted on synthetic batches, so this module provides
   * 'synthetic'  : uniform random uint8 images, seeded per rank (bench / smoke / plumbing);
   * 'cifar10'    : the python-pickle CIFAR-10 archive (cifar-10-batches-py) read from
                    $MULAN_DATA_DIR, test split unshuffled for create_one_time_eval_dataset;
-  * 'imagenet32' : the downsampled-ImageNet 32x32 python pickles (train_data_batch_1..10, val_data: dict with
-                   'data' [N, 3072] uint8 in channel-major order and 'labels') under
-                   $MULAN_DATA_DIR/Imagenet32_train and Imagenet32_val (or both in $MULAN_DATA_DIR/imagenet32);
+  * 'imagenet32' : the downsampled-ImageNet 32x32 python pickles of Chrabaszcz et al. (train_data_batch_1..10,
+                   val_data: dict with 'data' [N, 3072] uint8 in channel-major order) under
+                   $MULAN_DATA_DIR/Imagenet32_train and Imagenet32_val (or both in $MULAN_DATA_DIR/imagenet32).
+                   NOTE: the reference reads TFDS `downsampled_imagenet/32x32` = the van den Oord et al. PNG archives,
+                   a DIFFERENT downsampling of ImageNet; likelihoods on the two variants are not comparable.  For
+                   numbers comparable with the reference / the paper, dump the Oord train_32x32 / valid_32x32 images
+                   to an .npz and use 'npz:<file>'.  Labels are zero like the reference's (label_key=None);
   * 'npz:<path>' : any .npz with uint8 `images` [N,32,32,3] (e.g. a downsampled-ImageNet-32 dump).
 Batch dict keys follow _preprocess_cifar10 (ldm/dataset.py:310-322): images u8, labels, conditioning.
 """
@@ -31,8 +35,10 @@ def _cifar_split(root, train):
 
 
 def _imagenet32_split(root, train):
-    """downsampled ImageNet 32x32 as distributed by image-net.org (the source of TFDS downsampled_imagenet/32x32 that
-    the reference reads, ldm/dataset.py:187-199): pickled dicts, images flattened [N, 3 * 32 * 32] channel-major"""
+    """downsampled ImageNet 32x32 as distributed by image-net.org (Chrabaszcz et al. box-resize pickles: dicts with the
+    images flattened [N, 3 * 32 * 32] channel-major).  This is NOT the variant TFDS downsampled_imagenet/32x32 serves
+    to the reference (van den Oord et al., ldm/dataset.py:187-199): see the module docstring.  Labels are returned as
+    zeros, as the reference does for this dataset (label_key=None)."""
     cands = [os.path.join(root, "Imagenet32_train" if train else "Imagenet32_val"), os.path.join(root, "imagenet32")]
     d = next((c for c in cands if os.path.isdir(c)), None)
     if d is None:
@@ -50,7 +56,7 @@ def _imagenet32_split(root, train):
         with open(path, "rb") as f:
             e = pickle.load(f, encoding="latin1")
         xs.append(np.asarray(e["data"], dtype=np.uint8).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1))
-        ys.append(np.asarray(e["labels"], dtype=np.int32) - 1)      # labels are 1-based in the archive
+        ys.append(np.zeros(len(xs[-1]), dtype=np.int32))          # the reference drops the labels (label_key=None)
     return np.concatenate(xs), np.concatenate(ys)
 
 
@@ -75,46 +81,65 @@ def load_arrays(name, train):
 
 
 class BatchStream:
-    """Infinite (train/eval) or one-pass iterator of per-rank batches on `device`."""
+    """Infinite (train/eval) or one-pass iterator of per-rank batches on `device`.
+
+    Infinite streams: every rank walks the SAME permutation of the data set (drawn from a rank-independent generator
+    seeded with (seed, train, epoch)) and takes the strided shard perm[pos * world + rank], so that one epoch over all
+    ranks is one pass over the data set (the reference gives each host a disjoint split, ldm/dataset.py:66,264); the
+    per-rank generator only draws synthetic images and augmentations.
+    One pass (create_one_time_eval_dataset): `batch_size` is the GLOBAL batch of the reference; whole global batches
+    are dealt to the ranks round-robin (batch k goes to rank k % world), the remainder is dropped like the reference's
+    drop_remainder batching, so the evaluated image set and every per-batch statistic are the same for any world size.
+    """
 
     def __init__(self, name, batch_size, *, train, device, seed=0, rank=0, world=1, substeps=None, one_pass=False):
-        if batch_size % world != 0:
+        if not one_pass and batch_size % world != 0:
             raise ValueError("Batch size must be divisible by the number of devices")   # ldm/dataset.py:256-259
-        self.local = batch_size // world
+        self.local = batch_size if one_pass else batch_size // world
         self.device = device
         self.substeps = substeps
         self.one_pass = one_pass
         self.rank, self.world = rank, world
+        self.seed, self.train = int(seed), bool(train)
         self.x, self.y = load_arrays(name, train)
         # cifar10_aug (ldm/dataset.py:125-131, 358-376): the train stream gets a random left/right flip and a random
         # rotation by 90 / 180 / 270 degrees, each with probability 1/2; `conditioning` flags augmented images
         self.augment = train and name == "cifar10_aug"
         self.gen = np.random.default_rng([int(seed), int(rank), int(train)])
         self.pos = 0
-        if self.x is not None and not one_pass and train:
-            self.perm = self.gen.permutation(len(self.x))
-        else:
-            self.perm = None if self.x is None else np.arange(len(self.x))
+        self.epoch = 0
+        self.shuffle = self.x is not None and not one_pass and train
+        self.perm = None if self.x is None else self._permutation()
+
+    def _permutation(self):
+        if not self.shuffle:
+            return np.arange(len(self.x))
+        return np.random.default_rng([self.seed, int(self.train), self.epoch]).permutation(len(self.x))
 
     def __len__(self):
         if self.x is None or not self.one_pass:
             raise TypeError("infinite stream")
-        return len(self.x) // (self.local * self.world)
+        nb = len(self.x) // self.local                   # global batches
+        return (nb - self.rank + self.world - 1) // self.world
 
     def _take(self, n):
         if self.x is None:
             img = self.gen.integers(0, 256, size=(n, 32, 32, 3), dtype=np.uint8)
             lab = np.zeros(n, dtype=np.int32)
             return img, lab
+        if self.one_pass:                                # whole global batch number pos * world + rank
+            k = self.pos * self.world + self.rank
+            if (k + 1) * n > len(self.x):
+                return self.x[:0], self.y[:0]
+            self.pos += 1
+            return self.x[k * n:(k + 1) * n], self.y[k * n:(k + 1) * n]
         idx = []
         while len(idx) < n:
-            # rank r reads a strided shard of the (shuffled) index stream
+            # rank r reads a strided shard of the (shuffled) index stream shared by all ranks
             if self.pos * self.world + self.rank >= len(self.perm):
-                if self.one_pass:
-                    break
                 self.pos = 0
-                if self.perm is not None and not self.one_pass:
-                    self.perm = self.gen.permutation(len(self.x))
+                self.epoch += 1
+                self.perm = self._permutation()
             idx.append(self.perm[self.pos * self.world + self.rank])
             self.pos += 1
         idx = np.asarray(idx, dtype=np.int64)
@@ -164,7 +189,10 @@ def create_dataset(config, device, seed, rank=0, world=1):
     return train, evl
 
 
-def create_one_time_eval_dataset(config, batch_size, device, rank=0, world=1):
-    """Unshuffled single pass over the test split (ldm/dataset.py:379-410), sharded by rank."""
-    return BatchStream(config.data.dataset, batch_size * world, train=False, device=device, rank=rank, world=world,
+def create_one_time_eval_dataset(config, batch_size=None, device="cpu", rank=0, world=1):
+    """Unshuffled single pass over the test split in batches of `batch_size` (the reference's global batch,
+    ldm/dataset.py:379-410; default config.training.batch_size_eval); whole batches are dealt round-robin to ranks."""
+    if batch_size is None:
+        batch_size = config.training.batch_size_eval
+    return BatchStream(config.data.dataset, batch_size, train=False, device=device, rank=rank, world=world,
                        one_pass=True)

@@ -92,12 +92,14 @@ def _reduce_mean(total, count, device):
     return total / max(count, 1), count
 
 
-def eval_bpd_dense_sampling(experiment, config, n_timesteps=128, max_images=0):
-    loader = dataset.create_one_time_eval_dataset(config, 1, experiment.device, experiment.rank, experiment.world)
+def _dense_partial(experiment, config, n_timesteps, rank, world, max_images=0):
+    """(sum of per-image BPDs, image count) of the images rank `rank` of `world` evaluates: image i goes to rank
+    i % world; every image is a batch of n_timesteps copies under the SAME key PRNGKey(0) (notebook_utils.py:176-191)"""
+    loader = dataset.create_one_time_eval_dataset(config, 1, experiment.device, rank, world)
     rng = PRNGKey(0)
     total, count = 0.0, 0
     for eval_step, batch in enumerate(loader):
-        if max_images and eval_step * experiment.world >= max_images:
+        if max_images and eval_step * world + rank >= max_images:
             break
         images = batch['images'].reshape(1, 32, 32, 3).expand(n_timesteps, 32, 32, 3).contiguous()
         tiled = {'images': images, 'labels': batch['labels'].expand(n_timesteps),
@@ -106,29 +108,41 @@ def eval_bpd_dense_sampling(experiment, config, n_timesteps=128, max_images=0):
             bpd, _ = experiment.loss_fn(experiment.orig_params, tiled, eval_step, rng=rng, is_train=False)
         total += float(bpd)
         count += 1
-        if count % 100 == 0 and experiment.rank == 0:
+        if count % 100 == 0 and rank == 0:
             print(f'eval_step {count} cum_avg_bpd {total / count} ')
+    return total, count
+
+
+def eval_bpd_dense_sampling(experiment, config, n_timesteps=128, max_images=0):
+    total, count = _dense_partial(experiment, config, n_timesteps, experiment.rank, experiment.world, max_images)
     mean, n = _reduce_mean(total, count, experiment.device)
     if experiment.rank == 0:
         print('Num eval steps:', n)
     return mean
 
 
-def eval_bpd_sparse_sampling(experiment, config, max_images=0):
+def _sparse_partial(experiment, config, rank, world, max_images=0):
+    """(sum of per-batch BPDs, batch count): batches of config.training.batch_size_eval DISTINCT images, the reference's
+    global batch on every rank that evaluates one (the antithetic time grid spans the whole batch,
+    notebook_utils.py:157-173), whole batches dealt round-robin to the ranks"""
     batch_size = config.training.batch_size_eval
-    loader = dataset.create_one_time_eval_dataset(config, batch_size, experiment.device, experiment.rank,
-                                                  experiment.world)
+    loader = dataset.create_one_time_eval_dataset(config, batch_size, experiment.device, rank, world)
     rng = PRNGKey(0)
     total, count = 0.0, 0
     for eval_step, batch in enumerate(loader):
-        if max_images and eval_step * batch_size * experiment.world >= max_images:
+        if max_images and (eval_step * world + rank) * batch_size >= max_images:
             break
         with torch.no_grad():
             bpd, _ = experiment.loss_fn(experiment.orig_params, batch, eval_step, rng=rng, is_train=False)
         total += float(bpd)
         count += 1
-        if count % 100 == 0 and experiment.rank == 0:
+        if count % 100 == 0 and rank == 0:
             print(f'eval_step {count} cum_avg_bpd {total / count} ')
+    return total, count
+
+
+def eval_bpd_sparse_sampling(experiment, config, max_images=0):
+    total, count = _sparse_partial(experiment, config, experiment.rank, experiment.world, max_images)
     mean, n = _reduce_mean(total, count, experiment.device)
     if experiment.rank == 0:
         print('Num eval steps:', n)
@@ -293,8 +307,9 @@ def _logsumexp0(a):
 def _eval_bpd_ode(experiment, config, rng, deterministic_noise, hutchinson_type, dequantization='tn', num_is=1,
                   rtol=1e-5, atol=1e-5, max_images=0):
     """notebook_utils._eval_bpd_ode (:480-531): per batch, num_is likelihood draws, importance-weighted bound,
-    running mean over batches.  Under torchrun the test set is sharded over ranks by index and every rank integrates
-    its own batch (the step-size controller sees the rank's batch, not the global one)."""
+    running mean over batches.  Under torchrun whole global batches (config.training.batch_size_eval images, as in the
+    reference) are dealt round-robin to the ranks: every batch is integrated by one rank exactly as a single device
+    would (same step-size controller input), so the result does not depend on the world size."""
     batch_size = config.training.batch_size_eval
     loader = dataset.create_one_time_eval_dataset(config, batch_size, experiment.device, experiment.rank,
                                                   experiment.world)
@@ -303,7 +318,7 @@ def _eval_bpd_ode(experiment, config, rng, deterministic_noise, hutchinson_type,
     bpd_offset = _get_bpd_offset(dequantization, num_is)
     total, count = 0.0, 0
     for eval_step, batch in enumerate(loader):
-        if max_images and eval_step * batch_size * experiment.world >= max_images:
+        if max_images and (eval_step * experiment.world + experiment.rank) * batch_size >= max_images:
             break
         log_ps, log_qs, aux_loss = [], [], None
         for _ in range(num_is):

@@ -81,6 +81,8 @@ class Experiment(abc.ABC):
         total = tr.num_steps_train
 
         def schedule(step):
+            if warm <= 0:            # optax.linear_schedule with transition_steps <= 0 returns the end value
+                return lr if not decay else lr * max(0.0, 1.0 - step / max(1, total))
             if step < warm or not decay:
                 return lr * min(max(step, 0), warm) / warm
             return lr * max(0.0, 1.0 - (step - warm) / max(1, total - warm))

@@ -2,9 +2,10 @@
 
 Replaces jax.pmap + lax.pmean of the reference (ldm/experiment.py:89-95,341,347,365): parameters are
 replicated, the batch is sharded by rank, and the only data-path collective is the all-reduce of the
-flat gradient buffer.  The buffer is cut into buckets in the order gradients become ready during
-backward; each bucket is all-reduced on a side HIP stream as soon as its last gradient has landed, so
-the exchange overlaps the rest of the U-Net backward.  The 1/world_size factor is folded into the
+flat gradient buffer.  TrainState lays the buffer out in the order gradients become ready during backward
+(train_state.grad_ready_rank), so cutting it into contiguous buckets by offset gives buckets that complete one
+after the other; each bucket is all-reduced on a side HIP stream as soon as its last gradient has landed, so the
+exchange overlaps the rest of the backward pass (`ready_order` records the order the buckets actually fired in).  The 1/world_size factor is folded into the
 optimizer kernel (grad_scale).  Works unchanged with backend "gloo" on CPU tensors (tests).
 """
 import os
@@ -79,6 +80,7 @@ class GradReducer:
         if self.buckets:
             self.buckets[0][0] = 0
         self.pending = [0] * len(self.buckets)
+        self.ready_order = []       # bucket indices in the order they were launched in the last backward
         self.works = []
         self.launched = [False] * len(self.buckets)
         if self.enabled:
@@ -89,12 +91,14 @@ class GradReducer:
         """Call before each backward."""
         self.pending = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
+        self.ready_order = []
         self.works = []
 
     def _launch(self, bi):
         lo, hi, _ = self.buckets[bi]
         view = self.flat[lo:hi]
         self.launched[bi] = True
+        self.ready_order.append(bi)
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):

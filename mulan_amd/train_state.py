@@ -17,6 +17,39 @@ def _is_decayed(path):
     return path[-1] != 'bias' and tuple(path[-2:]) not in (('layer_norm', 'scale'), ('final_layer_norm', 'scale'))
 
 
+_NET_ORDER = {'score_model': 0, 'gamma': 1, 'encoder_model': 2}      # backward visits them in this order
+
+
+def grad_ready_rank(path):
+    """Sort key: position of a parameter leaf in the order gradients are produced by one backward pass
+    (ldm/model_vdm.py:335-386 and ldm/model_mulan_epsilon.py:101-154,531-538 read backwards)."""
+    net = _NET_ORDER.get(path[0], 3)
+    mod = path[1] if len(path) > 1 else ''
+    sub = path[2] if len(path) > 2 else ''
+    if net == 1:                                   # gamma MLP: the three output layers, then dense_2, dense_1
+        pos = {'dense_out_c': 0, 'dense_out_b': 0, 'dense_out_a': 0, 'dense_2': 1, 'dense_1': 2}.get(mod, 3)
+        return (net, pos, 0, mod)
+    if sub == 'cond_proj' or mod in ('dense0', 'dense1'):
+        return (net, 9, {'dense1': 1, 'dense0': 2}.get(mod, 0), '')          # after every block of the U-Net
+    if mod == 'dense_layer_final':
+        return (net, 0, 0, mod)
+    if mod == 'conv_out':
+        return (net, 1, 0, mod)
+    if mod == 'GroupNorm_0':
+        return (net, 2, 0, mod)
+    kind, _, name = mod.partition('.')
+    idx = int(name.rsplit('_', 1)[1]) if '_' in name and name.rsplit('_', 1)[1].isdigit() else 0
+    if kind == 'up':
+        return (net, 3, -idx, name)
+    if kind == 'mid':
+        return (net, 4, -idx, name)
+    if kind == 'down':
+        return (net, 5, -idx, name)
+    if mod == 'conv_in':
+        return (net, 6, 0, mod)
+    return (net, 8, 0, mod)
+
+
 class TrainState:
     def __init__(self, apply_fn, template, device, optimizer_args=None):
         self.apply_fn = apply_fn
@@ -25,9 +58,15 @@ class TrainState:
             assert path[0] in {'encoder_model', 'score_model', 'gamma'}, path
         decayed = [(p, v) for p, v in leaves if _is_decayed(p)]
         plain = [(p, v) for p, v in leaves if not _is_decayed(p)]
-        # the FiLM projection kernels (cond_proj) of one U-Net share their input: they are laid out back to back so
-        # that one strided view [G, K, N] over the flat buffers serves a single batched GEMM (ops.cond_proj)
-        decayed.sort(key=lambda pv: (0, pv[0][0]) if pv[0][-2:] == ('cond_proj', 'kernel') else (1, ''))
+        # Both classes are laid out in the order their gradients become ready during backward (reverse execution order:
+        # score U-Net from conv_out back to conv_in, its conditioning MLP, the gamma MLP, the encoder), so that
+        # parallel.GradReducer's contiguous buckets complete -- and start their all-reduce -- one after the other while
+        # backward is still running.  The FiLM projection kernels (cond_proj) of one U-Net share their input: they get one
+        # common rank (their batched weight gradient is formed once all blocks are done, next to the conditioning MLP)
+        # and therefore sit back to back, so that one strided view [G, K, N] over the flat buffers serves a single
+        # batched GEMM (ops.cond_proj).
+        decayed.sort(key=lambda pv: grad_ready_rank(pv[0]))
+        plain.sort(key=lambda pv: grad_ready_rank(pv[0]))
         self.layout = []   # (path, offset, shape)
         off = 0
         self.n_decay = 0

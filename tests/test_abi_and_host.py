@@ -139,6 +139,40 @@ def test_npz_one_pass_eval_is_sharded_in_order(tmp_path):
         it = data.create_one_time_eval_dataset(cfg, 1, "cpu", rank=rank, world=2)
         seen.append([int(b["images"][0, 0, 0, 0]) for b in it])
     assert seen == [[0, 2, 4, 6, 8], [1, 3, 5, 7, 9]]
+    # global batches of 4: whole batches go to the ranks round-robin, the remainder (8, 9) is dropped like the
+    # reference's drop_remainder batching, so world size does not change which images are evaluated
+    for world in (1, 2, 3):
+        got = []
+        for rank in range(world):
+            it = data.create_one_time_eval_dataset(cfg, 4, "cpu", rank=rank, world=world)
+            assert len(it) == len(list(data.create_one_time_eval_dataset(cfg, 4, "cpu", rank=rank, world=world)))
+            for b in it:
+                assert b["images"].shape == (4, 32, 32, 3)
+                got.append([int(v) for v in b["images"][:, 0, 0, 0]])
+        assert sorted(got) == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
+def test_train_stream_ranks_partition_every_epoch(tmp_path):
+    """all ranks walk ONE permutation per epoch (rank-independent generator): the union over ranks of one epoch is the
+    data set, without cross-rank duplicates; the next epoch is shuffled differently"""
+    from mulan_amd import data
+    N, world, bs = 1000, 4, 40
+    imgs = np.zeros((N, 32, 32, 3), dtype=np.uint8)
+    imgs[:, 0, 0, 0] = np.arange(N) % 256
+    imgs[:, 0, 0, 1] = np.arange(N) // 256
+    np.savez(tmp_path / "d.npz", images=imgs)
+    streams = [data.BatchStream(f"npz:{tmp_path / 'd.npz'}", bs, train=True, device="cpu", seed=3, rank=r, world=world)
+               for r in range(world)]
+    ident = lambda b: (b["images"][:, 0, 0, 0].long() + 256 * b["images"][:, 0, 0, 1].long()).tolist()
+    epochs = []
+    for _ in range(2):
+        seen = []
+        for _ in range(N // bs):
+            for st in streams:
+                seen += ident(next(st))
+        assert sorted(seen) == list(range(N))
+        epochs.append(seen)
+    assert epochs[0] != epochs[1]
 
 
 # ------------------------------------------------------------------------------ train state / checkpoints
@@ -207,6 +241,88 @@ def test_checkpoint_roundtrip_pt_and_flax_msgpack(tmp_path):
     assert torch.equal(st3.flat, st.flat) and torch.equal(st3.ema, st.ema) and st3.step == 7
 
 
+def test_verify_checkpoint_on_synthetic_flax_with_aliased_names(tmp_path):
+    """tests/verify_checkpoint.py (the one-command oracle pin for whoever holds a released checkpoint) on a synthetic
+    Flax msgpack written the way the reference might: gamma network under its attribute names l1 .. l3_c
+    (ldm/model_mulan_epsilon.py:493-512), optax.chain(masked(adamw), masked(adamw)) optimizer state in CLU / Flax
+    state-dict form with masked-out leaves as empty nodes (ldm/experiment.py:151-173), one array in Flax's chunked
+    form.  The loader must resolve all of it; the verifier must report a matching tree and the oracle's BPD."""
+    import copy
+    from mulan_amd import checkpoint as ck
+    from mulan_amd.config import load_config_file
+    from mulan_amd.train_state import TrainState
+    from oracle import torch_ref as tr
+    from tests import verify_checkpoint as vc
+    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    config.model.sm_n_embd = 32
+    config.model.sm_n_layer = 1
+    config.model.forward_n_layer = 1
+    ocfg = vc.oracle_cfg(config)
+    ref = tr.init_params(ocfg, seed=4, dtype=torch.float64)
+    as_np = lambda tree, scale=1.0: tr.tree_map(lambda t: (t.detach().numpy() * scale).astype(np.float32), tree)
+    alias = {v: k for k, v in ck.GAMMA_NET_ALIASES.items()}
+
+    def aliased(tree):
+        out = dict(tree)
+        out["gamma"] = {alias[k]: v for k, v in tree["gamma"].items()}
+        return out
+
+    def masked(tree, keep_score):                      # optax.masked: the other sub-trees become empty MaskedNodes
+        empty = lambda t: {k: empty(v) for k, v in t.items()} if isinstance(t, dict) else {}
+        return {k: (v if (k == "score_model") == keep_score else empty(v)) for k, v in tree.items()}
+
+    params, ema = aliased(as_np(ref)), aliased(as_np(ref, 0.5))
+    mu, nu = aliased(as_np(ref, 0.1)), aliased(as_np(ref, 0.01))
+    adam = lambda keep: {"inner_state": {"0": {"count": np.int32(9), "mu": masked(mu, keep), "nu": masked(nu, keep)},
+                                         "1": {}, "2": {}}}
+    sd = {"step": np.int32(9), "params": params, "ema_params": ema, "opt_state": {"0": adam(True), "1": adam(False)}}
+    # one leaf in Flax's chunked-array form (arrays above 2^30 bytes in real checkpoints)
+    k = ema["score_model"]["dense0"]["kernel"]
+    sd["ema_params"] = copy.deepcopy(ema)
+    sd["ema_params"]["score_model"]["dense0"]["kernel"] = {
+        "__msgpack_chunked_array__": True, "shape": {"0": k.shape[0], "1": k.shape[1]},
+        "chunks": {"0": k.reshape(-1)[:100].copy(), "1": k.reshape(-1)[100:].copy()}}
+    path = str(tmp_path / "ckpt-9.flax")
+    ck.save_flax(path, sd)
+
+    back = ck.restore_dict(path)
+    assert set(back["ema_params"]["gamma"]) == set(ck.GAMMA_NET_ALIASES.values())
+    assert np.array_equal(back["ema_params"]["score_model"]["dense0"]["kernel"], k)
+    assert set(back["opt_state"]["mu"]) == {"score_model", "encoder_model", "gamma"}
+    assert np.array_equal(back["opt_state"]["nu"]["gamma"]["dense_2"]["kernel"], nu["gamma"]["l2"]["kernel"])
+    assert np.array_equal(back["opt_state"]["mu"]["score_model"]["conv_in"]["bias"], mu["score_model"]["conv_in"]["bias"])
+
+    vdm, tmpl = vc.expected_tree(config)
+    st = TrainState.create(apply_fn=None, variables={"params": vdm.init(__import__("mulan_amd.rng", fromlist=["x"]).PRNGKey(0))},
+                           device="cpu")
+    st.load_state_dict(back)                            # strict: every leaf of params / ema / mu / nu is present
+    assert st.step == 9
+    assert torch.equal(st.ema_params["gamma"]["dense_out_b"]["kernel"], torch.tensor(ema["gamma"]["l3_b"]["kernel"]))
+
+    img = np.random.default_rng(1).integers(0, 256, (1, 32, 32, 3), dtype=np.uint8)
+    lines = []
+    res = vc.verify(path, config, img, n_timesteps=2, use_gpu=False, seed=3, log=lines.append)
+    assert res["tree_ok"] and len(res["oracle"]) == 1 and np.isfinite(res["oracle"][0]) and res["hip"] == []
+    rng = np.random.default_rng(3)
+    t0, raw = float(rng.random()), rng.gamma(1.0 / 15, size=(10, 2, 50))
+    e0, e = rng.standard_normal((2, 3072)), rng.standard_normal((2, 3072))
+    half = tr.tree_map(lambda t: (t.detach() * 0.5).float().double(), ref)        # what the checkpoint's ema_params hold
+    want = tr.mulan_forward(half, ocfg, torch.tensor(np.repeat(img, 2, axis=0)), t0, torch.tensor(raw),
+                            torch.tensor(e0).view(2, 32, 32, 3), torch.tensor(e).view(2, 32, 32, 3))
+    assert abs(res["oracle"][0] - float(want["bpd"])) < 1e-9 * abs(float(want["bpd"]))
+
+    broken = copy.deepcopy(sd)
+    del broken["ema_params"]["gamma"]["l3_c"]
+    broken["ema_params"]["score_model"]["conv_in"]["bias"] = np.zeros(7, np.float32)
+    ck.save_flax(str(tmp_path / "ckpt-10.flax"), broken)
+    res2 = vc.verify(str(tmp_path / "ckpt-10.flax"), config, img, n_timesteps=2, use_gpu=False, log=lines.append)
+    assert not res2["tree_ok"] and ("gamma", "dense_out_c", "kernel") in res2["missing"]
+    assert any(p == ("score_model", "conv_in", "bias") for p, _, _ in res2["mismatched"])
+    assert vc.main(["--ckpt", path, "--config", os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"),
+                    "--set", "model.sm_n_embd=32", "--set", "model.sm_n_layer=1", "--set", "model.forward_n_layer=1",
+                    "--data", "synthetic", "--n-images", "0", "--no-gpu"]) == 0
+
+
 def test_partial_restore_overlays_only_present_keys():
     from mulan_amd.experiment import restore_partial
     from mulan_amd.train_state import TrainState
@@ -259,7 +375,7 @@ def test_ode_evaluator_host_logic():
 
 
 def test_imagenet32_pickle_reader(tmp_path, monkeypatch):
-    """downsampled-ImageNet 32x32 archives: channel-major rows -> [N, 32, 32, 3], 1-based labels, unshuffled
+    """downsampled-ImageNet 32x32 archives: channel-major rows -> [N, 32, 32, 3], labels zeroed, unshuffled
     validation order for create_one_time_eval_dataset"""
     import pickle
     import numpy as np
@@ -275,10 +391,10 @@ def test_imagenet32_pickle_reader(tmp_path, monkeypatch):
         pickle.dump({"data": tr1, "labels": [7] * 5}, f)
     monkeypatch.setenv("MULAN_DATA_DIR", str(tmp_path))
     x, y = data.load_arrays("imagenet32", train=False)
-    assert x.shape == (6, 32, 32, 3) and list(y) == [0, 1, 2, 3, 4, 999]
+    assert x.shape == (6, 32, 32, 3) and list(y) == [0] * 6          # labels dropped like the reference (label_key=None)
     assert np.array_equal(x[2, 5, 7], val[2].reshape(3, 32, 32)[:, 5, 7])
     xt, yt = data.load_arrays("imagenet32", train=True)          # only the first training shard is present
-    assert xt.shape == (5, 32, 32, 3) and set(yt) == {6}
+    assert xt.shape == (5, 32, 32, 3) and set(yt) == {0}
     stream = data.BatchStream("imagenet32", 4, train=False, device="cpu", one_pass=True)
     first = next(iter(stream))
     assert np.array_equal(first["images"].numpy(), x[:4])
