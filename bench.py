@@ -4,11 +4,14 @@
   python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 One "step" = one full train step of the hot path (forward ELBO + backward + RCCL gradient all-reduce + AdamW/EMA)
-on one synthetic CIFAR-shaped uint8 batch that is already resident in HBM.  Workload at every N: BASELINE.json
+on one synthetic CIFAR-shaped uint8 batch that is already resident in HBM.  Default workload at every N: BASELINE.json
 configs[1] -- MuLAN-epsilon, ldm/configs/cifar10-conditioned.py (E=128, 32+2+33 ResBlocks), batch 128 per GPU
 (weak scaling: global batch 128*N), fp32 (the reference forces fp32 matmuls, ldm/main.py:39).
+`--global-batch G` fixes the GLOBAL batch instead (strong scaling, G/N images per GPU): BASELINE configs[2] is
+`--vdm-type mulan_velocity --global-batch 512`, configs[3] `--config ldm/configs/imagenet32.py --vdm-type mulan_velocity
+--vfe --global-batch 1024`.
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel: the 3x3-conv implicit GEMM) and
-`cpu_baseline` (oracle port on the host cores, bounded sample) objects.
+`cpu_baseline` (oracle port on the host cores, bounded samples) objects.
 """
 import argparse
 import json
@@ -32,20 +35,25 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--per-gpu-batch", type=int, default=128)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fixed global batch split over the ranks (BASELINE configs[2]: 512)")
+    ap.add_argument("--vfe", action="store_true", help="model.velocity_from_epsilon=True (BASELINE configs[3])")
     ap.add_argument("--vdm-type", default="mulan_epsilon")
     ap.add_argument("--config", default=os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per dominant-kernel launch from a PMC pass")
-    ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--cpu-timeout", type=int, default=420)
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the reference measurement with exact-fp32 MFMA convs")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
 def cpu_baseline(cfg_path, vdm_type, batch, steps):
-    """The oracle's torch port of the same train step (fwd + bwd + AdamW) in fp32 on all host cores."""
+    """The oracle's torch port of the train step (fwd + bwd + AdamW) in fp32 on all host cores: the two samples
+    BASELINE.md section 3 names -- the metric's configuration (MuLAN, `steps` steps of batch `batch`; default 3 x 8)
+    and BASELINE configs[0] (plain model_vdm.VDM, 10 steps of batch 2).  NOT the JAX reference (not installable here)."""
     import numpy as np
     import torch
     from mulan_amd.config import load_config_file
@@ -60,36 +68,74 @@ def cpu_baseline(cfg_path, vdm_type, batch, steps):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("MULAN_CPU_THREADS", "64"))))
     torch.set_num_threads(cores)
-    params = tr.init_params(ocfg, seed=0, dtype=torch.float32)
-    leaves = [l.requires_grad_(True) for _, l in tr.tree_leaves(params)]
-    opt = torch.optim.AdamW(leaves, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
     rng = np.random.default_rng(0)
     keep = float(np.float32(1.0 - m.sm_pdrop))
-
-    def masks(names):
-        return {n: torch.from_numpy(rng.random((batch, 32, 32, m.sm_n_embd)) < keep) for n in names}
     enc_names = [f"down.block_{i}" for i in range(m.forward_n_layer)] + ["mid.block_1", "mid.block_2"]
     sc_names = ([f"down.block_{i}" for i in range(m.sm_n_layer)] + ["mid.block_1", "mid.block_2"]
                 + [f"up.block_{i}" for i in range(m.sm_n_layer + 1)])
 
-    def step():
-        x = torch.from_numpy(rng.integers(0, 256, (batch, 32, 32, 3)).astype(np.uint8))
+    def timed(step_fn, n, bsz):
+        step_fn()                                # untimed warm-up (allocator, thread pool)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        dt = time.perf_counter() - t0
+        return bsz * n / dt, dt
+
+    def adamw(params):
+        leaves = [l.requires_grad_(True) for _, l in tr.tree_leaves(params)]
+        return torch.optim.AdamW(leaves, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+
+    # ---- sample A: the metric's configuration
+    params = tr.init_params(ocfg, seed=0, dtype=torch.float32)
+    opt = adamw(params)
+
+    def masks(names, bsz):
+        return {n: torch.from_numpy(rng.random((bsz, 32, 32, m.sm_n_embd)) < keep) for n in names}
+
+    def draw(bsz):
+        x = torch.from_numpy(rng.integers(0, 256, (bsz, 32, 32, 3)).astype(np.uint8))
+        e0 = torch.from_numpy(rng.standard_normal((bsz, 32, 32, 3)).astype(np.float32))
+        e = torch.from_numpy(rng.standard_normal((bsz, 32, 32, 3)).astype(np.float32))
+        return x, e0, e
+
+    def step_a():
+        x, e0, e = draw(batch)
         raw = torch.from_numpy(rng.gamma(1.0 / 15, size=(10, batch, 50)).astype(np.float32))
-        e0 = torch.from_numpy(rng.standard_normal((batch, 32, 32, 3)).astype(np.float32))
-        e = torch.from_numpy(rng.standard_normal((batch, 32, 32, 3)).astype(np.float32))
-        out = tr.mulan_forward(params, ocfg, x, float(rng.random()), raw, e0, e, enc_masks=masks(enc_names),
-                               score_masks=masks(sc_names), keep=keep, dtype=torch.float32)
+        out = tr.mulan_forward(params, ocfg, x, float(rng.random()), raw, e0, e, enc_masks=masks(enc_names, batch),
+                               score_masks=masks(sc_names, batch), keep=keep, dtype=torch.float32)
         opt.zero_grad(set_to_none=True)
         out["bpd"].backward()
         opt.step()
-    step()                                   # untimed warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+    ips_a, dt_a = timed(step_a, steps, batch)
+    del params, opt
+
+    # ---- sample B: BASELINE configs[0], plain VDM (model_vdm.py) with the learnable monotone schedule, batch 2 x 10 steps
+    full = tr.init_params(dict(ocfg, vdm_type="mulan_velocity"), seed=1, dtype=torch.float32)
+    pv = {"score_model": full["score_model"]}
+    pv["score_model"]["dense0"]["kernel"] = pv["score_model"]["dense0"]["kernel"][:m.sm_n_embd + 1].clone()
+    gg = torch.Generator().manual_seed(8)
+    pv["gamma"] = {"l1": {"kernel": torch.tensor([[18.3]]), "bias": torch.tensor([-13.3])},
+                   "l2": {"kernel": torch.randn(1, 1024, generator=gg), "bias": torch.randn(1024, generator=gg)},
+                   "l3": {"kernel": torch.randn(1024, 1, generator=gg)}}
+    del full
+    optb = adamw(pv)
+    bsz_b, steps_b = 2, 10
+
+    def step_b():
+        x, e0, e = draw(bsz_b)
+        out = tr.plain_vdm_forward(pv, dict(ocfg, n_timesteps=0), x, float(rng.random()), e0, e, dtype=torch.float32)
+        optb.zero_grad(set_to_none=True)
+        out["bpd"].backward()
+        optb.step()
+    ips_b, dt_b = timed(step_b, steps_b, bsz_b)
+    return {"value": ips_a, "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{steps} train steps (fwd+bwd+AdamW) of batch {batch}, full {vdm_type} CIFAR config, fp32, "
-                      f"oracle/torch_ref.py on {cores} threads"}
+                      f"oracle/torch_ref.py on {cores} threads, {dt_a:.1f} s of CPU work; NOT the JAX reference "
+                      "(JAX / Flax are not installable on this image)",
+            "config0_plain_vdm": {"value": ips_b, "unit": "images/s",
+                                  "sample": f"{steps_b} train steps of batch {bsz_b}, plain model_vdm.VDM (gamma_type="
+                                            f"learnable_nnet, no dropout), same U-Net, fp32, {dt_b:.1f} s of CPU work"}}
 
 
 def main():
@@ -110,12 +156,17 @@ def main():
     config = load_config_file(a.config)
     config.vdm_type = a.vdm_type
     config.data.dataset = "synthetic"
-    config.training.batch_size_train = a.per_gpu_batch * world
-    config.training.batch_size_eval = a.per_gpu_batch * world
+    if a.vfe:
+        config.model.velocity_from_epsilon = True
+    strong = a.global_batch > 0
+    if strong and a.global_batch % world != 0:
+        raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} ranks")
+    B = a.global_batch // world if strong else a.per_gpu_batch
+    config.training.batch_size_train = B * world
+    config.training.batch_size_eval = B * world
     config.training.substeps = 1
     exp = Experiment_VDM(config)
     dev = exp.device
-    B = a.per_gpu_batch
 
     g = torch.Generator().manual_seed(rank)
     nb = a.steps + a.warmup
@@ -241,7 +292,7 @@ def main():
     out = {
         "metric": "train images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "conv_mode": ops.CONV_MODE + {
             "bf16x6": ": fp32 operands split into 3 bf16 pieces, 6 bf16 MFMA passes, fp32 accumulate",
             "f16x3": ": fp32 operands scaled by a power of two and split into 2 fp16 pieces, 3 fp16 MFMA passes, fp32 "
@@ -250,7 +301,10 @@ def main():
             "f32": ": exact fp32 MFMA"}.get(ops.CONV_MODE, ""),
         "config": {"workload": f"MuLAN ({a.vdm_type}) config ldm/configs/{os.path.basename(a.config)} "
                                f"(E={config.model.sm_n_embd}, {config.model.sm_n_layer}+2+{config.model.sm_n_layer + 1} "
-                               f"ResnetBlocks), full train step (fwd+bwd+all-reduce+AdamW/EMA), batch {B}/GPU",
+                               f"ResnetBlocks{', velocity_from_epsilon' if a.vfe else ''}), full train step "
+                               f"(fwd+bwd+all-reduce+AdamW/EMA), " +
+                               (f"global batch {B * world} fixed (strong scaling), {B}/GPU" if strong else
+                                f"batch {B}/GPU (weak scaling)"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
         "model_tflops_per_gpu": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3, 2),
         "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 /

@@ -165,6 +165,19 @@ int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const 
                         unsigned long long seed, unsigned long long offset, unsigned* ymax, mulan_stream_t stream);
 /* ymax (optional, [B][16]): partial maxima of |y| in the format of mulan_absmax_rows, a by-product that saves the
  * following convolution its own pass over y. */
+/* _dyn: seed_dev (optional, device memory) makes the dropout seed `seed ^ seed_dev[0]`, read when the kernel runs: a
+ * stream-ordered parameter, so a captured HIP graph (the lax.scan of ldm/experiment.py:89-91: many sub-steps per host
+ * dispatch) replays with a fresh seed per step. */
+int mulan_groupnorm_fwd_dyn(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                            float* y, float* mean, float* rstd, int B, int hw, int G, float eps, int act, float keep,
+                            unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
+                            unsigned* ymax, mulan_stream_t stream);
+int mulan_groupnorm_bwd_dyn(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                            const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
+                            float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
+                            unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
+                            int accumulate, unsigned* dx1max, unsigned* dx2max, const float* add1, const float* add2,
+                            float* dxsum_part, mulan_stream_t stream);
 /* dgamma_part / dbeta_part are [B, C1+C2] per-sample partials (reduce with mulan_colsum). */
 int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
                         const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
@@ -320,6 +333,11 @@ int mulan_global_norm_clip(const float* g, size_t n, float clip, float pre_scale
 int mulan_adamw_ema_step_scaled(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay,
                                 float lr, float b1, float b2, float eps, float weight_decay, int step, float ema_rate,
                                 float grad_scale, const float* grad_scale_dev, mulan_stream_t stream);
+/* the same step with lr and the Adam bias corrections on the device: dyn[0] = lr(step) (ldm/experiment.py:343),
+ * dyn[1] = 1 - b1^t, dyn[2] = 1 - b2^t; stream-ordered parameters for HIP-graph replay of the train step. */
+int mulan_adamw_ema_step_dyn(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay,
+                             float b1, float b2, float eps, float weight_decay, float ema_rate, float grad_scale,
+                             const float* grad_scale_dev, const float* dyn, mulan_stream_t stream);
 /* N(0,1) draws: Philox4x32-10 + Box-Muller (stands in for jax.random.normal, model_mulan_velocity.py:223,235) */
 int mulan_randn(float* out, size_t n, unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
 

@@ -1,2 +1,3 @@
-"""ldm.ldm_unet surface: the per-pixel-FiLM U-Net is score_unet(...) with config.unet_type == 'ldm'."""
-from mulan_amd.model import score_unet as UNet, resnet_block as ResnetBlock  # noqa: F401
+"""ldm.ldm_unet surface (ldm/ldm_unet.py of the reference): UNet(config).apply(params, z, g_t [B,32,32,3],
+conditioning, deterministic=True) = the per-pixel-FiLM denoiser; ResnetBlock in its functional form."""
+from mulan_amd.model import UNet, resnet_block as ResnetBlock  # noqa: F401

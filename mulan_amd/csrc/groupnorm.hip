@@ -21,6 +21,7 @@ struct GnArgs {
   int B, G; float eps; int act;               // act: 0 none, 1 silu
   float keep; unsigned long long seed, offset;  // dropout: keep == 1 -> off
   unsigned* ymax;                             // optional [B][16]: partial maxima of |y| (mulan_absmax_rows format)
+  const unsigned long long* seed_dev;         // optional: dropout seed = seed ^ seed_dev[0] (stream-ordered: graph replay)
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -90,6 +91,7 @@ __device__ __forceinline__ void group_reduce2(float& a, float& b, int quad, int 
 }
 
 __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
+  if (p.seed_dev) p.seed ^= p.seed_dev[0];
   __shared__ float red[64];
   const int tid = threadIdx.x, quad = tid & 7, prow = tid >> 3;
   const int b = blockIdx.x, Ct = p.C1 + p.C2;
@@ -178,9 +180,11 @@ struct GnBwdArgs {
   unsigned* dx1max; unsigned* dx2max;          // optional [B][16]: partial maxima of |dx1|, |dx2| (single-pass kernel)
   const float* add1; const float* add2;        // optional: dx1 += add1, dx2 += add2 (gradient of a skip path of x)
   float* dxsum_part;                           // optional [B, C1+C2]: per-sample channel sums of the written dx
+  const unsigned long long* seed_dev;          // optional: dropout seed = seed ^ seed_dev[0] (as in the forward pass)
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
+  if (p.seed_dev) p.seed ^= p.seed_dev[0];
   __shared__ float red[64];
   __shared__ float cred[2 * 4 * 32];
   const int tid = threadIdx.x, quad = tid & 7, prow = tid >> 3;
@@ -273,6 +277,7 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
 // Single-pass backward: 512 threads own (sample, 32-channel slab); each thread keeps its 16 pixels' xhat and
 // activation-gradient float4s in registers (128 VGPRs), so x and dy are read exactly once: 2 reads + 1 write.
 __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
+  if (p.seed_dev) p.seed ^= p.seed_dev[0];
   constexpr int NPB = HW / 64;   // pixels per thread
   __shared__ float red[2 * 8 * 8];
   __shared__ float cred[2 * 8 * 32];
@@ -435,17 +440,49 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
 
 }  // namespace
 
-MULAN_API int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma,
-                                  const float* beta, float* y, float* mean, float* rstd, int B, int hw, int G,
-                                  float eps, int act, float keep, unsigned long long seed,
-                                  unsigned long long offset, unsigned* ymax, hipStream_t stream) {
+// seed_dev (optional, device memory): the dropout seed is `seed ^ seed_dev[0]`, read by the kernel when it runs -- a
+// stream-ordered parameter, so that a captured HIP graph replays with a fresh seed per step (seed = 0 there).
+MULAN_API int mulan_groupnorm_fwd_dyn(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                      const float* beta, float* y, float* mean, float* rstd, int B, int hw, int G,
+                                      float eps, int act, float keep, unsigned long long seed,
+                                      unsigned long long offset, const unsigned long long* seed_dev, unsigned* ymax,
+                                      hipStream_t stream) {
   const int Ct = C1 + C2;
   if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   if (ymax && Ct / 32 > 16) return (int)hipErrorInvalidValue;
-  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax};
+  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev};
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_groupnorm_fwd(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                  const float* beta, float* y, float* mean, float* rstd, int B, int hw, int G,
+                                  float eps, int act, float keep, unsigned long long seed,
+                                  unsigned long long offset, unsigned* ymax, hipStream_t stream) {
+  return mulan_groupnorm_fwd_dyn(x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, hw, G, eps, act, keep, seed, offset,
+                                 nullptr, ymax, stream);
+}
+
+MULAN_API int mulan_groupnorm_bwd_dyn(const float* dy, const float* x1, const float* x2, int C1, int C2,
+                                      const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                      float* dx1, float* dx2, float* dgamma_part, float* dbeta_part, int B, int hw,
+                                      int G, int act, float keep, unsigned long long seed, unsigned long long offset,
+                                      const unsigned long long* seed_dev, int accumulate, unsigned* dx1max,
+                                      unsigned* dx2max, const float* add1, const float* add2, float* dxsum_part,
+                                      hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
+  if ((dx1max && C1 / 32 > 16) || (dx2max && C2 / 32 > 16)) return (int)hipErrorInvalidValue;
+  GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
+              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max, add1, add2, dxsum_part, seed_dev};
+  if (g_mulan_tune[2] == 1 && !dx1max && !dx2max && !add1 && !add2 && !dxsum_part)   // dev A/B: two-pass 256-thread variant
+    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
 
@@ -455,16 +492,7 @@ MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float*
                                   int G, int act, float keep, unsigned long long seed, unsigned long long offset,
                                   int accumulate, unsigned* dx1max, unsigned* dx2max, const float* add1,
                                   const float* add2, float* dxsum_part, hipStream_t stream) {
-  const int Ct = C1 + C2;
-  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0) return (int)hipErrorInvalidValue;
-  const int cpg = Ct / G;
-  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
-  if ((dx1max && C1 / 32 > 16) || (dx2max && C2 / 32 > 16)) return (int)hipErrorInvalidValue;
-  GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
-              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max, add1, add2, dxsum_part};
-  if (g_mulan_tune[2] == 1 && !dx1max && !dx2max && !add1 && !add2 && !dxsum_part)   // dev A/B: two-pass 256-thread variant
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
-  MULAN_CHECK_LAUNCH();
+  return mulan_groupnorm_bwd_dyn(dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part, B, hw,
+                                 G, act, keep, seed, offset, nullptr, accumulate, dx1max, dx2max, add1, add2,
+                                 dxsum_part, stream);
 }

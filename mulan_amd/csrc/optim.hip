@@ -13,12 +13,14 @@ struct AdamArgs {
   size_t n, n_decay;
   float lr, b1, b2, eps, wd, bc1, bc2, ema_rate, gscale;
   const float* gscale_dev;   // optional extra factor computed on the device (global-norm clipping)
+  const float* dyn;          // optional [3] on the device: lr, 1 - b1^t, 1 - b2^t (stream-ordered: graph replay)
 };
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const size_t n4 = a.n >> 2;
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, ome = 1.f - a.ema_rate;
   if (a.gscale_dev) a.gscale *= a.gscale_dev[0];
+  if (a.dyn) { a.lr = a.dyn[0]; a.bc1 = a.dyn[1]; a.bc2 = a.dyn[2]; }
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
     const size_t i = q << 2;
     f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
@@ -110,18 +112,31 @@ __global__ void randn_kernel(float* __restrict__ out, size_t n, unsigned long lo
 
 static int adamw_launch(float* p, const float* g, float* m, float* v, float* ema, size_t n, size_t n_decay, float lr,
                         float b1, float b2, float eps, float weight_decay, int step, float ema_rate, float grad_scale,
-                        const float* grad_scale_dev, hipStream_t stream) {
-  if (step < 1) return (int)hipErrorInvalidValue;
+                        const float* grad_scale_dev, hipStream_t stream, const float* dyn = nullptr) {
+  if (step < 1 && !dyn) return (int)hipErrorInvalidValue;
   const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!(al(p) && al(g) && al(m) && al(v) && al(ema))) return (int)hipErrorInvalidValue;
+  const int st = step < 1 ? 1 : step;
   AdamArgs a{p, g, m, v, ema, n, n_decay, lr, b1, b2, eps, weight_decay,
-             (float)(1.0 - pow((double)b1, step)), (float)(1.0 - pow((double)b2, step)), ema_rate, grad_scale,
-             grad_scale_dev};
+             (float)(1.0 - pow((double)b1, st)), (float)(1.0 - pow((double)b2, st)), ema_rate, grad_scale,
+             grad_scale_dev, dyn};
   size_t blocks = ((n >> 2) + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
   hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
+}
+
+// The step with its per-step scalars on the device: dyn[0] = learning rate, dyn[1] = 1 - b1^t, dyn[2] = 1 - b2^t (t = the
+// Adam count), read by the kernel when it runs, so that a captured HIP graph replays with this step's values;
+// grad_scale_dev as in mulan_adamw_ema_step_scaled (may be NULL).
+MULAN_API int mulan_adamw_ema_step_dyn(float* p, const float* g, float* m, float* v, float* ema, size_t n,
+                                       size_t n_decay, float b1, float b2, float eps, float weight_decay,
+                                       float ema_rate, float grad_scale, const float* grad_scale_dev,
+                                       const float* dyn, hipStream_t stream) {
+  if (!dyn) return (int)hipErrorInvalidValue;
+  return adamw_launch(p, g, m, v, ema, n, n_decay, 0.f, b1, b2, eps, weight_decay, 0, ema_rate, grad_scale,
+                      grad_scale_dev, stream, dyn);
 }
 
 MULAN_API int mulan_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, size_t n,

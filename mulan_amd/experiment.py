@@ -7,6 +7,7 @@ jax.pmap/lax.scan/lax.pmean become: one process per GPU (torchrun), a host loop 
 bucketed RCCL all-reduce of the flat gradient buffer overlapped with backward (mulan_amd.parallel).
 """
 import abc
+import contextlib
 import functools
 import logging
 import math
@@ -19,6 +20,7 @@ import torch
 from . import checkpoint as ckpt_lib
 from . import data as dataset
 from . import parallel
+from . import profiling
 from .model import VDMConfig, make_vdm, tree_leaves
 from .rng import PRNGKey
 from .train_state import TrainState, tree_leaves_in_layout
@@ -70,6 +72,7 @@ class Experiment(abc.ABC):
         self.rng, eval_rng, sample_rng = self.rng.split(3)
         self._eval_rng, self._sample_rng = eval_rng, sample_rng
         self._sample_dummy = None
+        self._profile = None                 # profiling.Profile while config.training.profile is set (train_and_evaluate)
 
     # ---- schedules / optimiser ------------------------------------------------------------------
     def get_lr_schedule(self):
@@ -105,20 +108,26 @@ class Experiment(abc.ABC):
         """Experiment.train_step (ldm/experiment.py:335-356): fold rank + step into the rng, value_and_grad,
         gradient mean over ranks, lr schedule, AdamW+EMA, scalar mean over ranks."""
         rng = base_rng.fold_in(self.rank).fold_in(state.step)
+        phase = self._profile.phase if self._profile is not None else (lambda name: contextlib.nullcontext())
         state.zero_grad()
         self.reducer.prepare()
         packer = state.param_packer()        # f16x3 mode: weight maxima + packed operands of all layers, two launches
         if packer is not None:
             packer.refresh()
-        bpd, metrics = self.loss_fn(state.params, batch, step=state.step, rng=rng, is_train=True)
-        bpd.backward()
-        state.collect_grads()
-        self.reducer.finish()
+        with phase("forward"):
+            bpd, metrics = self.loss_fn(state.params, batch, step=state.step, rng=rng, is_train=True)
+        with phase("backward"):
+            bpd.backward()
+            state.collect_grads()
+        with phase("all-reduce"):
+            self.reducer.finish()
         learning_rate = self.lr_schedule(state.step)
         if packer is not None:
             packer.invalidate()              # the optimizer rewrites the parameters
-        state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate, grad_scale=1.0 / self.world,
-                              clip_norm=self.config.optimizer.get('gradient_clip_norm', None))
+        with phase("optimizer"):
+            state.apply_gradients(lr=learning_rate, ema_rate=self.config.optimizer.ema_rate,
+                                  grad_scale=1.0 / self.world,
+                                  clip_norm=self.config.optimizer.get('gradient_clip_norm', None))
         scalars = parallel.allreduce_mean_scalars(metrics['scalars'], self.device)
         metrics['scalars'] = {'train_' + k: v for k, v in scalars.items()}
         return state, metrics
@@ -162,10 +171,15 @@ class Experiment(abc.ABC):
         if initial_step == 0:
             writer.write_hparams(self.config.to_dict())
         t_last, s_last = time.time(), step
+        if config.get('profile', False):
+            self._profile = profiling.Profile(num_profile_steps=5, first_profile=initial_step + 10 * substeps)
         while step < config.num_steps_train:
             is_last_step = step + substeps >= config.num_steps_train
             batch = next(self.train_iter)
-            state, _train_metrics = self.p_train_step(state, batch)
+            with profiling.trace_range(f"train step {step}"):        # jax.profiler.StepTraceAnnotation('train', step_num)
+                state, _train_metrics = self.p_train_step(state, batch)
+            if self._profile is not None:                            # hooks: periodic_actions.Profile (experiment.py:230-232)
+                self._profile(step + substeps)
             new_step = int(state.step)
             assert new_step == step + substeps
             step = new_step

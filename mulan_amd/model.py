@@ -15,6 +15,7 @@ deterministic)` returns a VDMOutput.  Mirrors:
 All tensor math runs in libmulan_hip.so (mulan_amd.ops); there is no CPU path.
 """
 import dataclasses
+import functools
 import math
 import numpy as np
 from typing import Any, Optional
@@ -662,6 +663,108 @@ PlainVDM.reverse_ode = _plain_reverse_ode
 PlainVDM.sample = _plain_sample
 PlainVDM.generate_x = _plain_generate_x
 PlainVDM.sample_coefficients = lambda self, params, embedding: None
+
+
+# ----------------------------------------------------------------------------- reference-shaped module surface
+class _Module:
+    """Flax-style handle of one sub-network: Module(config).apply(params, *args) with the reference's call signature, or
+    Module(config).bind(params)(*args).  `params` is that sub-network's tree (e.g. state.params['score_model']);
+    `rngs={'dropout': Key}` is needed with deterministic=False, like Flax's apply(..., rngs=...)."""
+
+    def __init__(self, config: VDMConfig):
+        self.config = config
+
+    def bind(self, params, rngs=None):
+        return functools.partial(self.apply, params, rngs=rngs)
+
+    def _drop(self, deterministic, rngs):
+        if deterministic:
+            return _Drop(None, 0.0)
+        key = (rngs or {}).get("dropout")
+        if key is None:
+            raise ValueError("deterministic=False needs rngs={'dropout': Key}")
+        return _Drop(key, self.config.sm_pdrop)
+
+
+def _pixels(z, ch):
+    """[B,32,32,ch] (reference layout) or [B,1024,ch] -> [B,1024,ch] fp32"""
+    return z.reshape(z.shape[0], HW, ch).to(torch.float32)
+
+
+class ScoreUNet(_Module):
+    """model_vdm.ScoreUNet (ldm/model_vdm.py:309-388): __call__(z, g_t, conditioning, deterministic=True, time=False)
+    -> eps_hat with the shape of z.  z [B,32,32,3]; g_t [B] (or a scalar); conditioning [B,K]."""
+    unet_type = 'vdm'
+
+    def apply(self, params, z, g_t, conditioning, deterministic=True, time=False, rngs=None):
+        cfg = self.config if self.config.unet_type == self.unet_type else dataclasses.replace(self.config, unet_type=self.unet_type)
+        B = z.shape[0]
+        g = torch.as_tensor(g_t, dtype=torch.float32, device=z.device)
+        if self.unet_type == 'ldm':
+            g = g.expand(z.shape).reshape(B, HW, 3).contiguous() if g.dim() < 4 and g.numel() != z.numel() \
+                else g.reshape(B, HW, 3)
+        else:
+            g = g.expand(B).contiguous() if g.dim() == 0 else g.reshape(B)    # model_vdm.py:329-332: g_t * ones(B)
+        cond = torch.as_tensor(conditioning, dtype=torch.float32, device=z.device).reshape(B, -1)
+        out = score_unet(params, cfg, _pixels(z, 3), g, cond, self._drop(deterministic, rngs), time=time)
+        return out.reshape(z.shape)
+
+    __call__ = apply
+
+
+class UNet(ScoreUNet):
+    """ldm_unet.UNet (ldm/ldm_unet.py:64-142): the same topology with per-pixel FiLM conditioning; g_t [B,32,32,3]."""
+    unet_type = 'ldm'
+
+
+class UnetEncoder(_Module):
+    """model_mulan_epsilon.UnetEncoder (ldm/model_mulan_epsilon.py:101-154): __call__(z, deterministic=True) ->
+    logits [B, latent_size]; z = EncDec.encode(images) [B,32,32,3]."""
+
+    def apply(self, params, z, deterministic=True, rngs=None):
+        return unet_encoder(params, self.config, _pixels(z, 3), self._drop(deterministic, rngs))
+
+    __call__ = apply
+
+
+class NoiseSchedule_polynomial_fixedend(_Module):
+    """model_mulan_epsilon.NoiseSchedule_polynomial_fixedend (ldm/model_mulan_epsilon.py:481-613):
+    __call__(embedding [B,latent], t [B] or scalar) -> gamma [B,3072]; grad_t(embedding, t) = d gamma / dt (:540-555)."""
+
+    def _eval(self, params, embedding, t):
+        emb = torch.as_tensor(embedding, dtype=torch.float32)
+        B = emb.shape[0]
+        t = torch.as_tensor(t, dtype=torch.float32, device=emb.device)
+        t = t.expand(B).contiguous() if t.dim() == 0 else t.reshape(B)
+        a, b, c = poly_coefficients(params, emb)
+        return ops.poly_gamma(a, b, c, t, self.config.gamma_min, self.config.gamma_max)
+
+    def apply(self, params, embedding, t, rngs=None):
+        return self._eval(params, embedding, t)[2]
+
+    def grad_t(self, params, embedding, t):
+        return self._eval(params, embedding, t)[3]
+
+    __call__ = apply
+
+
+class EncDec:
+    """model_vdm.EncDec (ldm/model_vdm.py:265-303): no parameters.  encode(x uint8) -> f in (-1, 1);
+    logprob(x, z, g_0) -> [B] sum over sub-pixels of the 256-bin decoder log-probabilities (the fused q-sample kernel
+    evaluated at eps_0 = 0 around z: -loss_recon)."""
+
+    def __init__(self, config: VDMConfig):
+        self.config = config
+
+    def encode(self, x):
+        return encode_images(x.reshape(x.shape[0], D).to(torch.uint8)).reshape(*x.shape)
+
+    def decode_argmax(self, z, g_0):
+        """argmax over the 256 bins of decode(z, g_0) (:282-293); g_0 per sample [B] or per element"""
+        B = z.shape[0]
+        g = torch.as_tensor(g_0, dtype=torch.float32, device=z.device)
+        g = g.expand(B).contiguous() if g.dim() == 0 else g.reshape(B, -1).squeeze(-1) if g.numel() == B else g.reshape(B, D)
+        return ops.decode_argmax(z.reshape(B, D).to(torch.float32).contiguous(), g.contiguous()).reshape(z.shape)
 
 
 def make_vdm(vdm_type: str, config: VDMConfig):

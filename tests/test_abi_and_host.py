@@ -323,6 +323,49 @@ def test_verify_checkpoint_on_synthetic_flax_with_aliased_names(tmp_path):
                     "--data", "synthetic", "--n-images", "0", "--no-gpu"]) == 0
 
 
+def test_reference_python_surface_is_importable():
+    """every name SURVEY section 8(b) lists under the kept Python API resolves, with the reference's call signatures"""
+    import inspect
+    import ldm.experiment, ldm.experiment_vdm, ldm.train_state, ldm.model_vdm, ldm.model_mulan_velocity  # noqa: E401
+    import ldm.model_mulan_epsilon, ldm.ldm_unet, ldm.notebook_utils, ldm.dataset, ldm.main, ldm.eval_bpd  # noqa: E401
+    assert inspect.isclass(ldm.experiment.Experiment) and inspect.isclass(ldm.experiment_vdm.Experiment_VDM)
+    assert inspect.isclass(ldm.train_state.TrainState)
+    for name in ("train_step", "eval_step", "loss_fn", "sample_fn", "get_model_and_params", "train_and_evaluate", "evaluate"):
+        assert hasattr(ldm.experiment_vdm.Experiment_VDM, name), name
+    assert {"VDMConfig", "VDMOutput", "VDM", "ScoreUNet", "EncDec"} <= set(dir(ldm.model_vdm))
+    assert list(inspect.signature(ldm.model_vdm.ScoreUNet.apply).parameters)[:6] == \
+        ["self", "params", "z", "g_t", "conditioning", "deterministic"]          # ldm/model_vdm.py:314
+    assert inspect.signature(ldm.model_vdm.ScoreUNet.apply).parameters["time"].default is False
+    assert list(inspect.signature(ldm.ldm_unet.UNet.apply).parameters)[:6] == \
+        ["self", "params", "z", "g_t", "conditioning", "deterministic"]          # ldm/ldm_unet.py:69
+    assert list(inspect.signature(ldm.model_mulan_epsilon.UnetEncoder.apply).parameters)[:4] == \
+        ["self", "params", "z", "deterministic"]                                 # ldm/model_mulan_epsilon.py:105
+    assert list(inspect.signature(ldm.model_mulan_epsilon.NoiseSchedule_polynomial_fixedend.apply).parameters)[:4] == \
+        ["self", "params", "embedding", "t"]                                     # ldm/model_mulan_epsilon.py:602
+    assert ldm.model_mulan_epsilon.GAMMA_NETWORKS["poly_fixedend"] is ldm.model_mulan_epsilon.NoiseSchedule_polynomial_fixedend
+    assert callable(ldm.model_mulan_velocity.VDM) and callable(ldm.model_mulan_epsilon.VDM)
+    for name in ("Experiment_Colab", "eval_bpd_dense_sampling", "eval_bpd_sparse_sampling", "eval_bpd_ode"):
+        assert hasattr(ldm.notebook_utils, name), name
+    assert callable(ldm.dataset.create_dataset) and callable(ldm.dataset.create_one_time_eval_dataset)
+
+
+def test_profiling_hooks_are_cheap_noops_without_a_profiler():
+    """config.training.profile / StepTraceAnnotation counterparts (ldm/experiment.py:230-232,243): ranges nest, the
+    Profile action opens a window of num_profile_steps calls after first_profile and emits phase ranges only inside it"""
+    from mulan_amd import profiling
+    with profiling.trace_range("train step 0"):
+        with profiling.trace_range("forward"):
+            pass
+    p = profiling.Profile(num_profile_steps=2, first_profile=3)
+    seen = []
+    for step in range(1, 8):
+        p(step)
+        seen.append(p.active)
+    assert seen == [False, False, True, True, False, False, False]
+    import contextlib
+    assert isinstance(p.phase("forward"), contextlib.nullcontext)
+
+
 def test_partial_restore_overlays_only_present_keys():
     from mulan_amd.experiment import restore_partial
     from mulan_amd.train_state import TrainState

@@ -472,3 +472,77 @@ def test_attention_on_split_kernels(ops, monkeypatch, C):
     with torch.no_grad():
         o2 = ops.attention(dev(q), dev(k), dev(v))
     assert np.array_equal(o2.cpu().double().numpy(), outs[True][0])
+
+
+def _heavy(rng, shape, outlier_axis0=True):
+    """Student-t (nu = 2) values with one element per image (leading index) 1e4 x the bulk's scale"""
+    x = rng.standard_t(2.0, size=shape)
+    if outlier_axis0:
+        flat = x.reshape(shape[0], -1)
+        for b in range(shape[0]):
+            flat[b, rng.integers(flat.shape[1])] = 1e4 * (1 if rng.random() < 0.5 else -1)
+    return x
+
+
+@pytest.mark.parametrize("C,N", [(128, 128), (256, 128)])
+def test_f16x3_heavy_tailed_operands(ops, monkeypatch, C, N):
+    """Where the split scheme could break: the per-image / per-tensor power-of-two scale puts the absolute error floor
+    at ~2^-38 of the operand's maximum, so what matters is how far the bulk sits below the maximum.  Activations with
+    Student-t (nu = 2) tails plus a 1e4 x outlier per image, weights with one output channel 1e3 x the others:
+    forward, input gradient and weight gradient, error per output element relative to sum |a||b| against float64, and
+    not worse than 1.5 x the exact-fp32 MFMA kernel's on the same data."""
+    rng = np.random.default_rng(C + N)
+    B = 2
+    x = _heavy(rng, (B, 32, 32, C))
+    w = rng.standard_normal((3, 3, C, N)) / math.sqrt(9 * C)
+    w[..., 5] *= 1e3
+    dy = _heavy(rng, (B, 32, 32, N))
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    x, w, dy = r32(x), r32(w), r32(dy)
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    yt = tr.conv3x3(xt, {"kernel": wt})
+    yt.backward(torch.tensor(dy))
+    refs = dict(fwd=yt.detach().numpy(), dgrad=xt.grad.numpy(), wgrad=wt.grad.numpy())
+    with torch.no_grad():
+        ax, aw, ady = torch.tensor(np.abs(x), requires_grad=True), torch.tensor(np.abs(w), requires_grad=True), np.abs(dy)
+    ya = tr.conv3x3(ax, {"kernel": aw})
+    ya.backward(torch.tensor(ady))
+    mags = dict(fwd=ya.detach().numpy(), dgrad=ax.grad.numpy(), wgrad=aw.grad.numpy())
+
+    def run():
+        xd, wd, dyd = dev(x).view(B, 1024, C), dev(w), dev(dy).view(B, 1024, N)
+        return dict(fwd=ops.conv3x3_raw(xd, wd).cpu().double().numpy().reshape(B, 32, 32, N),
+                    dgrad=ops.conv3x3_dgrad_raw(dyd, wd).cpu().double().numpy().reshape(B, 32, 32, C),
+                    wgrad=ops.conv3x3_wgrad_raw(xd, dyd).cpu().double().numpy())
+    got = run()
+    monkeypatch.setattr(ops, "CONV_MODE", "f32")
+    got32 = run()
+    for k in ("fwd", "dgrad", "wgrad"):
+        e16 = float((np.abs(got[k] - refs[k]) / mags[k]).max())
+        e32 = float((np.abs(got32[k] - refs[k]) / mags[k]).max())
+        # (with these tails the exact-fp32 MFMA kernel itself reaches ~4e-6 of sum |a||b|: long fp32 accumulation)
+        assert e32 < 1e-5 and e16 < 1e-5 and e16 < 1.5 * e32 + 2e-7, (k, e16, e32)
+
+
+def test_f16x3_plane_fed_wgrad_heavy_tails(ops):
+    """the production weight-gradient path (planes written by the forward / input-gradient kernels, per-image scales,
+    accumulator rescaling between images) on the same heavy-tailed data, images of very different magnitude"""
+    rng = np.random.default_rng(77)
+    B, C, N = 3, 128, 128
+    x = _heavy(rng, (B, 32, 32, C)) * np.array([1.0, 1e-3, 50.0])[:, None, None, None]
+    dy = _heavy(rng, (B, 32, 32, N)) * np.array([1e2, 1.0, 1e-2])[:, None, None, None]
+    w = rng.standard_normal((3, 3, C, N)) / math.sqrt(9 * C)
+    r32 = lambda a: a.astype(np.float32).astype(np.float64)
+    x, dy, w = r32(x), r32(dy), r32(w)
+    wt = torch.tensor(w, requires_grad=True)
+    tr.conv3x3(torch.tensor(x), {"kernel": wt}).backward(torch.tensor(dy))
+    aw = torch.tensor(np.abs(w), requires_grad=True)
+    tr.conv3x3(torch.tensor(np.abs(x)), {"kernel": aw}).backward(torch.tensor(np.abs(dy)))
+    xd, dyd, wd = dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N), dev(w)
+    xmax, dymax = ops.absmax_rows(xd), ops.absmax_rows(dyd)
+    _, xs = ops.conv3x3_raw(xd, wd, xmax=xmax, planes=True)
+    _, dys = ops.conv3x3_dgrad_raw(dyd, wd, dymax=dymax, planes=True)
+    dw = ops.conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, B, C, N).cpu().double().numpy()
+    err = float((np.abs(dw - wt.grad.numpy()) / aw.grad.numpy()).max())
+    assert err < 1e-5, err

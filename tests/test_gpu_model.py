@@ -42,13 +42,12 @@ def to_device_tree(flax_tree, like):
     return M.from_flax_layout(flax_tree, like)
 
 
-def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=False, n_layer=1, fwd_layers=1):
+def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=False, n_layer=1, fwd_layers=1, B=4):
     """tol scales the fp32-vs-float64 bars (E = 256 doubles / quadruples every contraction length)"""
     from mulan_amd import model as M
     from mulan_amd.rng import PRNGKey
     cfg, ocfg = make_cfg(vdm_type, unet_type, vfe, E=E, with_attention=with_attention, n_layer=n_layer,
                          fwd_layers=fwd_layers)
-    B = 4
     rng = np.random.default_rng(17)
     ref_params = tr.init_params(ocfg, seed=3, dtype=torch.float64)
     for _, leaf in tr.tree_leaves(ref_params):
@@ -583,3 +582,59 @@ def test_training_learns_a_small_structured_set():
     assert all(np.isfinite(hist)) and last < 0.6 * first, (first, last)
     ev = float(exp.eval_step(exp._eval_rng, exp.state.ema_params, sub, 0)['scalars']['eval_bpd'])
     assert np.isfinite(ev) and ev < 0.8 * first, (first, last, ev)
+
+
+@pytest.mark.parametrize("unet_type", ["vdm", "ldm"])
+def test_module_surface_matches_oracle(unet_type):
+    """The reference-shaped module handles of SURVEY 8(b) -- ScoreUNet / UNet (ldm/model_vdm.py:314, ldm/ldm_unet.py:69),
+    UnetEncoder (ldm/model_mulan_epsilon.py:105), NoiseSchedule_polynomial_fixedend (:602, grad_t :540), EncDec.encode --
+    called with the reference's argument lists on NHWC tensors, against the float64 oracle."""
+    import ldm.ldm_unet
+    import ldm.model_mulan_epsilon as me
+    import ldm.model_vdm as mv
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg, ocfg = make_cfg("mulan_velocity", unet_type)
+    B, E = 3, 128
+    ref = tr.init_params(ocfg, seed=21, dtype=torch.float64)
+    vdm = M.make_vdm("mulan_velocity", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
+    M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), ref), params)
+    rng = np.random.default_rng(2)
+    z = torch.tensor(rng.standard_normal((B, 32, 32, 3)))
+    emb = torch.tensor((rng.random((B, 50)) < 0.3).astype(np.float64))
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+    with torch.no_grad():
+        if unet_type == "vdm":
+            g = torch.tensor(rng.uniform(-10, 3, B))
+            net = mv.ScoreUNet(cfg).apply(params["score_model"], z.float().cuda(), g.float().cuda(), emb.float().cuda(),
+                                          deterministic=True)
+            want = tr.score_unet(z, g, emb, ref["score_model"], E, 1)
+        else:
+            g = torch.tensor(rng.uniform(-10, 3, (B, 32, 32, 3)))
+            net = ldm.ldm_unet.UNet(cfg).apply(params["score_model"], z.float().cuda(), g.float().cuda(),
+                                               emb.float().cuda(), deterministic=True)
+            want = tr.score_unet(z, g, emb, ref["score_model"], E, 1, per_pixel=True)
+        assert net.shape == z.shape and rel(net, want) < 2e-4
+        x = torch.tensor(rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8))
+        f = mv.EncDec(cfg).encode(x.cuda())
+        assert torch.equal(f.cpu().double(), tr.encode(x.double()))
+        logits = me.UnetEncoder(cfg)(params["encoder_model"], f, deterministic=True)
+        assert rel(logits, tr.unet_encoder(tr.encode(x.double()), ref["encoder_model"], E, 1)) < 2e-4
+        sched = me.NoiseSchedule_polynomial_fixedend(cfg)
+        t = torch.tensor(rng.random(B))
+        a, b, c = tr.poly_coefficients(emb, ref["gamma"])
+        assert rel(sched(params["gamma"], emb.float().cuda(), t.float().cuda()), tr.poly_gamma(a, b, c, t)) < 1e-5
+        assert rel(sched.grad_t(params["gamma"], emb.float().cuda(), t.float().cuda()),
+                   tr.poly_gamma_grad_t(a, b, c, t)) < 1e-5
+        assert rel(sched(params["gamma"], emb.float().cuda(), 0.0), torch.full((B, 3072), -13.3, dtype=torch.float64)) < 1e-6
+    with pytest.raises(ValueError):
+        mv.ScoreUNet(cfg).apply(params["score_model"], z.float().cuda(), 0.0, emb.float().cuda(), deterministic=False)
+
+
+def test_full_depth_train_mode_gradient_parity():
+    """the shipped depth (32 + 2 + 33 ResnetBlocks, 4-layer encoder) in TRAINING mode (dropout on) at B = 2: loss terms
+    and every parameter gradient against float64 autograd.  ~140 chained split-operand convolutions forward and
+    backward: fp32-level noise grows with depth, so the per-leaf bar is 5x the single-layer one (1e-2 of the leaf's
+    gradient scale); the BPD bar stays 1e-3 relative."""
+    run_case("mulan_velocity", "vdm", False, train=True, n_layer=32, fwd_layers=4, B=2, tol=5.0)
