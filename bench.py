@@ -194,6 +194,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     last_bpd = float(m["scalars"]["train_bpd"])
+    graph_used = bool(exp.hip_graph and exp._graphed is not None)
 
     # ---- dominant-kernel timing: HIP events (on the launch stream) around every convolution launch of one more step
     roof = None
@@ -258,6 +259,7 @@ def main():
     if world == 1 and ops.CONV_MODE != "f32" and not a.no_f32_mode:
         saved = ops.CONV_MODE
         ops.CONV_MODE = "f32"
+        exp.hip_graph = False               # (the captured graph holds the split-operand kernels)
         state, _ = exp.train_step(exp._train_rng, state, batches[0])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -311,6 +313,7 @@ def main():
                                      {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(
                                          ops.CONV_MODE, PEAK_F32_MFMA_TFLOPS), 4),
         "last_train_bpd": round(last_bpd, 4),
+        "hip_graph": graph_used,
         "roofline": roof, "f32_mfma_mode": f32_mode, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

@@ -34,6 +34,136 @@ def restore_partial(state, state_restore_dict):
     return state
 
 
+def ops_kernel_timer_off():
+    from . import ops
+    return ops.KERNEL_TIMER is None
+
+
+class GraphedStep:
+    """One train step captured as a HIP graph and replayed: the build's counterpart of the reference's
+    jax.pmap(lax.scan(train_step)) (ldm/experiment.py:89-91), which dispatches 1000 sub-steps per host call.
+
+    The step issues ~1950 kernel launches; from Python that is ~45 ms of host time, more than the GPU needs at small
+    per-GPU batches.  Captured once (forward, backward, gradient collection and -- on one rank -- AdamW/EMA), the step
+    is replayed with a single launch.  Everything that changes from step to step reaches the kernels through device
+    memory written before the replay ("stream-ordered parameters"):
+      * the uint8 batch and the noise tensors (eps_0, eps, Gamma draws) live in static buffers filled eagerly;
+      * t0 of the antithetic time grid is a 0-dim device tensor;
+      * the two dropout seeds are int64 device slots read by the GroupNorm kernels (mulan_groupnorm_*_dyn);
+      * learning rate and Adam bias corrections are a float device array read by mulan_adamw_ema_step_dyn.
+    The keys are derived on the host exactly as the eager step derives them (Experiment_VDM.step_keys), so a replayed
+    step is bit-identical to the eager one.  With more than one rank the graph ends after the gradients; the bucketed
+    all-reduce and the optimizer launch follow eagerly (the collective stays outside the capture).
+    """
+
+    def __init__(self, exp, state, batch):
+        from . import ops
+        from .rng import Key
+        self.exp = exp
+        dev = exp.device
+        self.shape = tuple(batch['images'].shape)
+        B = self.shape[0]
+        cfg = exp.model.config
+        self.inputs = {k: torch.empty_like(v) for k, v in batch.items()}
+        self.need_gamma = getattr(cfg, 'reparam_type', 'true') == 'true' and hasattr(cfg, 'latent_k')
+        self.gumbel = getattr(cfg, 'topk_noise_type', 'gamma') == 'gumbel'
+        self.noise = {'t0': torch.zeros((), device=dev, dtype=torch.float32),
+                      'eps_0': torch.empty((B, 3072), device=dev, dtype=torch.float32),
+                      'eps': torch.empty((B, 3072), device=dev, dtype=torch.float32)}
+        if not cfg.antithetic_time_sampling:
+            self.noise['t'] = torch.empty((B,), device=dev, dtype=torch.float32)
+        if self.need_gamma:
+            if self.gumbel:
+                self.noise['gumbel'] = torch.empty((B, cfg.latent_size), device=dev, dtype=torch.float32)
+            else:
+                self.noise['gamma_raw'] = torch.empty((10, B, cfg.latent_size), device=dev, dtype=torch.float32)
+        self.seeds = torch.zeros(2, device=dev, dtype=torch.int64)
+        self.dyn = torch.zeros(4, device=dev, dtype=torch.float32)
+        self.h_seeds = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.h_dyn = torch.zeros(5, dtype=torch.float32).pin_memory()       # lr, bc1, bc2, 0, t0
+        self.whole = exp.world == 1                  # optimizer inside the graph
+        self.mode = ops.CONV_MODE
+        self.copied = torch.cuda.Event()             # the pinned staging buffers have been read by the device
+        self.graph = torch.cuda.CUDAGraph()
+        self.metrics = None
+        rngs = {'dropout_pair': (Key(0, dev=self.seeds[0:1]), Key(0, dev=self.seeds[1:2]))}
+        exp.reducer.paused = True
+        try:
+            self._fill(exp._train_rng, state, batch)         # valid contents while capturing (nothing executes)
+            state.zero_grad()
+            state.drop_graph_refs()                          # no autograd node of the eager stream may survive
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph):
+                state.zero_grad()
+                packer = state.param_packer()
+                if packer is not None:
+                    packer.refresh()
+                bpd, metrics = exp.loss_fn(state.params, self.inputs, step=0, rng=None, is_train=True, rngs=rngs,
+                                           noise=self.noise)
+                bpd.backward()
+                state.collect_grads()
+                if packer is not None:
+                    packer.invalidate()
+                if self.whole:
+                    state.apply_gradients(lr=0.0, ema_rate=exp.config.optimizer.ema_rate, grad_scale=1.0,
+                                          clip_norm=exp.config.optimizer.get('gradient_clip_norm', None), dyn=self.dyn,
+                                          count_step=False)
+                self.metrics = metrics
+        finally:
+            exp.reducer.paused = False
+
+    def matches(self, batch):
+        from . import ops
+        return tuple(batch['images'].shape) == self.shape and ops.CONV_MODE == self.mode
+
+    def _fill(self, base_rng, state, batch):
+        """everything that differs from step to step, written where the captured kernels read it"""
+        from . import ops
+        exp = self.exp
+        rng = base_rng.fold_in(exp.rank).fold_in(state.step)
+        keys = exp.step_keys(rng, True)
+        for k, v in batch.items():
+            self.inputs[k].copy_(v, non_blocking=True)
+        B = self.shape[0]
+        dev = exp.device
+        if 't' in self.noise:
+            self.noise['t'].copy_(ops.noise((B,), keys['t'].v, 0, dev, "uniform"))
+        if 'gamma_raw' in self.noise:
+            cfg = exp.model.config
+            self.noise['gamma_raw'].copy_(keys['gamma'].gamma(1.0 / cfg.latent_k, (10, B, cfg.latent_size), dev))
+        if 'gumbel' in self.noise:
+            self.noise['gumbel'].copy_(ops.noise(tuple(self.noise['gumbel'].shape), keys['gamma'].v, 0, dev, "gumbel"))
+        ops.randn(None, keys['eps_0'].v, 0, dev, out=self.noise['eps_0'])
+        ops.randn(None, keys['eps'].v, 0, dev, out=self.noise['eps'])
+        to_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+        self.h_seeds[0], self.h_seeds[1] = to_i64(keys['enc'].v), to_i64(keys['score'].v)
+        lr = exp.lr_schedule(state.step)
+        vals = state.dynamic_scalars(lr, state.step + 1)
+        for i, v in enumerate(vals):
+            self.h_dyn[i] = v
+        self.h_dyn[4] = float(np.float32(keys['t'].uniform()))
+        self.seeds.copy_(self.h_seeds, non_blocking=True)
+        self.dyn.copy_(self.h_dyn[:4], non_blocking=True)
+        self.noise['t0'].copy_(self.h_dyn[4], non_blocking=True)
+        self.copied.record()
+
+    def step(self, base_rng, state, batch):
+        exp = self.exp
+        self.copied.synchronize()      # the pinned staging buffers are rewritten below: the last copies must be done
+        self._fill(base_rng, state, batch)
+        self.graph.replay()
+        if self.whole:
+            state.step += 1
+        else:
+            exp.reducer.allreduce_now()
+            state.apply_gradients(lr=exp.lr_schedule(state.step), ema_rate=exp.config.optimizer.ema_rate,
+                                  grad_scale=1.0 / exp.world,
+                                  clip_norm=exp.config.optimizer.get('gradient_clip_norm', None))
+        scalars = parallel.allreduce_mean_scalars({k: v.clone() for k, v in self.metrics['scalars'].items()}, exp.device)
+        metrics = {'scalars': {'train_' + k: v for k, v in scalars.items()}, 'images': {'inputs': batch['images']}}
+        return state, metrics
+
+
 class Experiment(abc.ABC):
     """Boilerplate for training and evaluating VDM models (ldm/experiment.py:42-104)."""
 
@@ -73,6 +203,12 @@ class Experiment(abc.ABC):
         self._eval_rng, self._sample_rng = eval_rng, sample_rng
         self._sample_dummy = None
         self._profile = None                 # profiling.Profile while config.training.profile is set (train_and_evaluate)
+        # the lax.scan of the reference (ldm/experiment.py:89-91: `substeps` train steps per host dispatch) becomes a
+        # HIP-graph replay per step (GraphedStep); MULAN_HIP_GRAPH=0 or config.training.hip_graph=False runs eagerly
+        self.hip_graph = (os.environ.get("MULAN_HIP_GRAPH", "1") != "0" and bool(config.training.get("hip_graph", True))
+                          and torch.device(self.device).type == "cuda")
+        self._graphed = None
+        self._eager_steps = 0
 
     # ---- schedules / optimiser ------------------------------------------------------------------
     def get_lr_schedule(self):
@@ -107,6 +243,21 @@ class Experiment(abc.ABC):
     def train_step(self, base_rng, state, batch):
         """Experiment.train_step (ldm/experiment.py:335-356): fold rank + step into the rng, value_and_grad,
         gradient mean over ranks, lr schedule, AdamW+EMA, scalar mean over ranks."""
+        if self.hip_graph and self._profile is None and ops_kernel_timer_off() and hasattr(self.model, "parameterization"):
+            g = self._graphed
+            if g is None or not g.matches(batch):
+                if self._eager_steps >= 1:           # one eager step first: every kernel configured, allocator warm
+                    try:
+                        self._graphed = g = GraphedStep(self, state, batch)
+                    except Exception as e:           # noqa: BLE001  capture is an optimisation: fall back loudly, once
+                        log.warning("HIP-graph capture of the train step failed (%s: %s); running eagerly", type(e).__name__, e)
+                        self.hip_graph = False
+                        g = None
+                else:
+                    g = None
+            if g is not None:
+                return g.step(base_rng, state, batch)
+        self._eager_steps += 1
         rng = base_rng.fold_in(self.rank).fold_in(state.step)
         phase = self._profile.phase if self._profile is not None else (lambda name: contextlib.nullcontext())
         state.zero_grad()
@@ -247,15 +398,30 @@ class Experiment_VDM(Experiment):
         rng1, _rng2 = rng.split()
         return model, model.init(rng1)
 
-    def loss_fn(self, params, inputs, step, rng, is_train):
-        """Experiment_VDM.loss_fn (ldm/experiment_vdm.py:47-78)."""
+    @staticmethod
+    def step_keys(rng, is_train=True):
+        """The keys one loss_fn call consumes, derived exactly as loss_fn / VDM._noise / VDM.apply derive them:
+        {'t', 'gamma', 'eps_0', 'eps'} from the 'sample' stream, {'enc', 'score'} from the 'dropout' stream."""
         rng, sample_rng = rng.split()
-        rngs = {'sample': sample_rng}
+        k_t, k_g, k_0, k_e = sample_rng.split(4)
+        keys = {'t': k_t, 'gamma': k_g, 'eps_0': k_0, 'eps': k_e}
         if is_train:
             rng, dropout_rng = rng.split()
-            rngs['dropout'] = dropout_rng
+            keys['enc'], keys['score'] = dropout_rng.split(2)
+        return keys
+
+    def loss_fn(self, params, inputs, step, rng, is_train, rngs=None, noise=None):
+        """Experiment_VDM.loss_fn (ldm/experiment_vdm.py:47-78).  rngs / noise (not in the reference): the already
+        derived keys / noise tensors of this step, used by the graph-captured train step (GraphedStep)."""
+        if rngs is None:
+            rng, sample_rng = rng.split()
+            rngs = {'sample': sample_rng}
+            if is_train:
+                rng, dropout_rng = rng.split()
+                rngs['dropout'] = dropout_rng
         outputs = self.state.apply_fn(params, inputs['images'], inputs.get('labels'), inputs.get('conditioning'),
-                                      step=step, rngs=rngs, deterministic=not is_train)
+                                      step=step, rngs=rngs, deterministic=not is_train, **({} if noise is None else
+                                                                                           {'noise': noise}))
         rescale_to_bpd = 1. / (float(np.prod(inputs['images'].shape[1:])) * math.log(2.))
         bpd_latent = outputs.loss_klz.mean() * rescale_to_bpd
         bpd_recon = outputs.loss_recon.mean() * rescale_to_bpd

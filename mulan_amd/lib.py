@@ -90,6 +90,7 @@ SIGNATURES = {
     "mulan_dequantize": [P, P, P, P, Z, I, F, P],
     "mulan_adamw_ema_step": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P],
     "mulan_adamw_ema_step_scaled": [P, P, P, P, P, Z, Z, F, F, F, F, F, I, F, F, P, P],
+    "mulan_adamw_ema_step_dyn": [P, P, P, P, P, Z, Z, F, F, F, F, F, F, P, P, P],
     "mulan_global_norm_clip_workspace": [],
     "mulan_global_norm_clip": [P, Z, F, F, P, P, P],
     "mulan_randn": [P, Z, U, U, P],

@@ -150,7 +150,8 @@ class _Drop:
     def __init__(self, key: Optional[Key], rate: float):
         self.on = key is not None and rate > 0.0
         self.keep = 1.0 - rate if self.on else 1.0
-        self.seed = key.v if key is not None else 0
+        # a Key bound to a device slot (rng.Key.dev, graph capture) hands the kernels the slot instead of the value
+        self.seed = 0 if key is None else (key.dev if getattr(key, "dev", None) is not None else key.v)
         self.site = 0
 
     def next(self):
@@ -303,8 +304,9 @@ class _VDMBase:
         # t = mod(t0 + arange(0, 1, 1/B), 1)  (ldm/model_mulan_velocity.py:196-198), built in fp32 like jnp
         # (evaluated on the device: the same IEEE fp32 multiply / add / floor as on the host, and no blocking
         # host-to-device copy, which would make the host wait for the whole previous step)
-        t = torch.remainder(torch.arange(B, dtype=torch.float32, device=device) * float(np.float32(1.0 / B))
-                            + float(np.float32(t0)), 1.0)
+        # (t0 may be a 0-dim fp32 device tensor: a stream-ordered parameter under HIP-graph replay)
+        t0v = t0.to(device=device, dtype=torch.float32) if torch.is_tensor(t0) else float(np.float32(t0))
+        t = torch.remainder(torch.arange(B, dtype=torch.float32, device=device) * float(np.float32(1.0 / B)) + t0v, 1.0)
         if T > 0:
             t = torch.ceil(t * T) / T
         return t
@@ -357,10 +359,12 @@ class MulanVDM(_VDMBase):
         noise = self._noise(rngs, noise, B, dev, cfg.reparam_type == 'true')
         t = self._times(noise, B, dev)
         f = encode_images(x)
+        # rngs['dropout_pair']: the two sub-keys already split (and bound to device slots) by a graphed train step
+        pair = None if deterministic else (rngs or {}).get("dropout_pair")
         drop_key = None if deterministic else (rngs or {}).get("dropout")
-        if not deterministic and drop_key is None:
+        if not deterministic and drop_key is None and pair is None:
             raise ValueError("training mode needs rngs['dropout']")
-        k_enc, k_score = drop_key.split(2) if drop_key is not None else (None, None)
+        k_enc, k_score = pair if pair is not None else (drop_key.split(2) if drop_key is not None else (None, None))
         if cfg.reparam_type == 'true':
             logits = unet_encoder(params["encoder_model"], cfg, f, _Drop(k_enc, cfg.sm_pdrop))
             if cfg.topk_noise_type == 'gumbel':

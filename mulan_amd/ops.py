@@ -334,8 +334,9 @@ def colsum_raw(x2d, nseg, seg, C, out=None):
     return out
 
 
-def randn(shape, seed, offset, device):
-    out = torch.empty(shape, device=device, dtype=torch.float32)
+def randn(shape, seed, offset, device, out=None):
+    if out is None:
+        out = torch.empty(shape, device=device, dtype=torch.float32)
     call("mulan_randn", ptr(out), out.numel(), int(seed) & (2**64 - 1), int(offset), stream())
     return out
 
@@ -574,6 +575,11 @@ class CondProjGroup:
         self._key = None
         self._outs = None
 
+    def clear(self):
+        """drops the cached outputs (and with them the autograd graph they hold, including the AccumulateGrad node of
+        the super-parameter, which remembers the stream it was created on)"""
+        self._cond = self._key = self._outs = None
+
     def outputs(self, cond):
         import weakref
         key = (cond._version, torch.is_grad_enabled())
@@ -688,6 +694,14 @@ def softplus_shift(x, shift):
 
 
 # ----------------------------------------------------------------------------- group norm
+def _seed_args(seed):
+    """(seed by value, device pointer or None): a seed given as a 1-element int64 device tensor is read by the kernel
+    when it runs (stream-ordered parameter: HIP-graph replay draws a fresh dropout mask per step)"""
+    if torch.is_tensor(seed):
+        return 0, seed
+    return int(seed), None
+
+
 def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     x1, x2 = _c(x1), _c(x2)
     B, C1 = x1.shape[0], x1.shape[-1]
@@ -698,12 +712,13 @@ def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     # by-product for a following f16x3 convolution: the per-image maxima of y
     ymax = (torch.empty((B, MAX_PARTS), device=x1.device, dtype=torch.int32)
             if CONV_MODE == "f16x3" and (C1 + C2) // 32 <= MAX_PARTS else None)
-    call("mulan_groupnorm_fwd", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B,
-         HW, groups, float(eps), int(act), float(keep), int(seed), int(offset), ptr(ymax), stream())
+    sv, sd = _seed_args(seed)
+    call("mulan_groupnorm_fwd_dyn", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), B,
+         HW, groups, float(eps), int(act), float(keep), sv, int(offset), ptr(sd), ptr(ymax), stream())
     if ymax is not None:
         y._absmax = (ymax, y._version)
     ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
-    ctx.meta = (groups, int(act), float(keep), int(seed), int(offset))
+    ctx.meta = (groups, int(act), float(keep), seed, int(offset))
     ctx.gv = (_gv(gamma), _gv(beta))
     return y, x1, x2
 
@@ -726,8 +741,9 @@ def _gn_backward(ctx, dy, add1=None, add2=None):
     m2 = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
           if f16 and x2 is not None and C2 // 32 <= MAX_PARTS else None)
     csum = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
-    call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-         ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, seed, offset, 0, ptr(m1), ptr(m2),
+    sv, sd = _seed_args(seed)
+    call("mulan_groupnorm_bwd_dyn", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+         ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), 0, ptr(m1), ptr(m2),
          ptr(_c(add1)), ptr(_c(add2)), ptr(csum), stream())
     if m1 is not None:
         dx1._absmax = (m1, dx1._version)
@@ -784,7 +800,7 @@ class GroupNormSkipFn(torch.autograd.Function):
 
 
 def group_norm(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=1.0, seed=0, offset=0):
-    return GroupNormFn.apply(x1, x2, gamma, beta, groups, eps, int(act), keep, seed, offset)
+    return GroupNormFn.apply(x1, x2, gamma, beta, groups, eps, int(act), keep, seed, offset)   # seed: int or device tensor
 
 
 def group_norm_skip(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=1.0, seed=0, offset=0):
@@ -1181,9 +1197,20 @@ def topk_embedding(logits, gnoise, k, tau=10.0):
 
 
 # ----------------------------------------------------------------------------- optimiser
-def adamw_ema_step(p, g, m, v, ema, n_decay, lr, b1, b2, eps, wd, step, ema_rate, grad_scale=1.0, clip_norm=None):
+def adamw_ema_step(p, g, m, v, ema, n_decay, lr, b1, b2, eps, wd, step, ema_rate, grad_scale=1.0, clip_norm=None, dyn=None):
     """one AdamW + EMA step on the flat buffers; clip_norm: optax.clip_by_global_norm in front (the factor is
-    computed and applied on the device).  Returns the [2] device tensor (factor, gradient norm) when clipping."""
+    computed and applied on the device).  Returns the [2] device tensor (factor, gradient norm) when clipping.
+    dyn: optional fp32 device tensor [lr, 1 - b1^t, 1 - b2^t] read by the kernel when it runs (graph replay); lr / step
+    are ignored then."""
+    if dyn is not None:
+        out = None
+        if clip_norm is not None:
+            ws = torch.empty(lib.load().mulan_global_norm_clip_workspace() // 8, device=p.device, dtype=torch.float64)
+            out = torch.empty(2, device=p.device, dtype=torch.float32)
+            call("mulan_global_norm_clip", ptr(g), g.numel(), float(clip_norm), float(grad_scale), ptr(ws), ptr(out), stream())
+        call("mulan_adamw_ema_step_dyn", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(b1),
+             float(b2), float(eps), float(wd), float(ema_rate), float(grad_scale), ptr(out), ptr(dyn), stream())
+        return out
     if clip_norm is None:
         call("mulan_adamw_ema_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), p.numel(), int(n_decay), float(lr),
              float(b1), float(b2), float(eps), float(wd), int(step), float(ema_rate), float(grad_scale), stream())

@@ -79,6 +79,7 @@ class GradReducer:
             b[1] = self.buckets[i + 1][0] if i + 1 < len(self.buckets) else flat_grad.numel()
         if self.buckets:
             self.buckets[0][0] = 0
+        self.paused = False         # True while a train step is being captured into a HIP graph: hooks do not launch
         self.pending = [0] * len(self.buckets)
         self.ready_order = []       # bucket indices in the order they were launched in the last backward
         self.works = []
@@ -111,10 +112,20 @@ class GradReducer:
         if gv is not None and t.grad is not None and t.grad.data_ptr() != gv.data_ptr():
             gv.copy_(t.grad)
             t.grad = gv       # so TrainState.collect_grads() does not overwrite the reduced bucket later
+        if self.paused:
+            return
         bi = self.leaf_bucket[id(t)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and not self.launched[bi]:
             self._launch(bi)
+
+    def allreduce_now(self):
+        """All buckets at once, after a graph-replayed backward (no hooks ran): same result as prepare() ... finish(),
+        without the overlap."""
+        if not self.enabled:
+            return
+        self.prepare()
+        self.finish()
 
     def finish(self):
         """Launch whatever did not fire (unused leaves), then make the compute stream wait for all buckets."""

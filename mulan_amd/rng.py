@@ -19,10 +19,14 @@ def _splitmix64(x):
 
 
 class Key:
-    __slots__ = ("v",)
+    """`dev` (optional): a 1-element int64 device tensor holding this key's value.  Kernels that take their seed from a
+    key then read the slot when they run (stream-ordered parameter) instead of a value frozen into the launch -- what a
+    captured HIP graph of the train step needs (mulan_amd.experiment.GraphedStep rewrites the slots every step)."""
+    __slots__ = ("v", "dev")
 
-    def __init__(self, v):
+    def __init__(self, v, dev=None):
         self.v = int(v) & _M64
+        self.dev = dev
 
     def fold_in(self, data):
         return Key(_splitmix64(self.v ^ _splitmix64(int(data) & _M64)))

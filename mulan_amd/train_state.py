@@ -134,6 +134,13 @@ class TrainState:
                 flush()
         flush()
 
+    def drop_graph_refs(self):
+        """forget every cached autograd graph (the per-forward cache of the grouped FiLM projections): needed before a
+        train step is captured on another stream, so that no gradient-accumulation node of the old stream survives"""
+        for _, _, _, leaves in self._supers:
+            for leaf in leaves:
+                leaf._group[0].clear()
+
     def reducer_leaves(self):
         """(tensor, offset, numel) per gradient-carrying tensor for parallel.GradReducer: grouped leaves are
         represented by their super-parameter (that is where autograd delivers their gradient)"""
@@ -196,15 +203,25 @@ class TrainState:
                     leaf._gview.copy_(g)
                 leaf.grad = leaf._gview
 
-    def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0, clip_norm=None):
+    def apply_gradients(self, *, lr, ema_rate, grad_scale=1.0, clip_norm=None, dyn=None, count_step=True):
         """TrainState.apply_gradients (ldm/train_state.py:70-102) on the flat gradient buffer; clip_norm = the optional
-        optimizer.gradient_clip_norm (optax.clip_by_global_norm in front of AdamW, ldm/experiment.py:176-178)."""
-        self.step += 1
+        optimizer.gradient_clip_norm (optax.clip_by_global_norm in front of AdamW, ldm/experiment.py:176-178).
+        dyn: device tensor [lr, 1 - b1^t, 1 - b2^t] for the graph-captured step (see dynamic_scalars); count_step=False
+        leaves the host step counter to the caller (a captured launch is replayed, not re-run)."""
+        if count_step:
+            self.step += 1
         o = self.opt
         self.last_clip = ops.adamw_ema_step(self.flat, self.grad, self.mu, self.nu, self.ema, self.n_decay, lr, o["b1"],
-                                            o["b2"], o["eps"], o["weight_decay"], self.step, ema_rate, grad_scale,
-                                            clip_norm=clip_norm)
+                                            o["b2"], o["eps"], o["weight_decay"], max(1, self.step), ema_rate, grad_scale,
+                                            clip_norm=clip_norm, dyn=dyn)
         return self
+
+    def dynamic_scalars(self, lr, count):
+        """[lr, 1 - b1^count, 1 - b2^count, 0]: what mulan_adamw_ema_step derives on the host from (lr, step)"""
+        import numpy as np
+        o = self.opt      # (b1, b2 reach the kernel launcher as C floats: the same rounding here keeps replay bit-identical)
+        b1, b2 = float(np.float32(o["b1"])), float(np.float32(o["b2"]))
+        return [float(lr), 1.0 - b1 ** count, 1.0 - b2 ** count, 0.0]
 
     # -- checkpoint form: {step, params, ema_params, opt_state} (ldm/train_state.py:62-68)
     def state_dict(self):

@@ -638,3 +638,53 @@ def test_full_depth_train_mode_gradient_parity():
     backward: fp32-level noise grows with depth, so the per-leaf bar is 5x the single-layer one (1e-2 of the leaf's
     gradient scale); the BPD bar stays 1e-3 relative."""
     run_case("mulan_velocity", "vdm", False, train=True, n_layer=32, fwd_layers=4, B=2, tol=5.0)
+
+
+def test_graph_replayed_train_steps_equal_eager_steps():
+    """GraphedStep (HIP-graph replay of the train step, the build's lax.scan, ldm/experiment.py:89-91) against the
+    eager step: same batches, same keys -> the parameters, the EMA, the Adam moments and the logged scalars after 4 steps
+    are bit-identical (the replay launches the very same kernels; everything step-dependent -- batch, noise, t0,
+    dropout seeds, learning rate, bias corrections -- reaches them through device memory); the by-product hand-overs
+    between autograd nodes fire under capture as they do eagerly (maxima passes per step stay <= 22)."""
+    import os
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    from mulan_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(graph):
+        config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+        config.model.sm_n_layer = 2
+        config.model.forward_n_layer = 1
+        config.data.dataset = "synthetic"
+        config.training.batch_size_train = 4
+        config.training.batch_size_eval = 4
+        config.training.substeps = 1
+        config.training.hip_graph = graph
+        exp = Experiment_VDM(config)
+        g = torch.Generator().manual_seed(3)
+        scal = []
+        for i in range(4):
+            batch = {"images": torch.randint(0, 256, (4, 32, 32, 3), generator=g, dtype=torch.uint8).cuda(),
+                     "labels": torch.zeros(4, dtype=torch.int32).cuda(),
+                     "conditioning": torch.zeros(4, dtype=torch.uint8).cuda()}
+            _, m = exp.train_step(exp._train_rng, exp.state, batch)
+            scal.append({k: float(v) for k, v in m["scalars"].items()})
+        torch.cuda.synchronize()
+        st = exp.state
+        return (st.flat.clone(), st.ema.clone(), st.mu.clone(), st.nu.clone(), st.step, scal,
+                exp._graphed is not None)
+
+    calls = []
+    orig = lib.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    e = run(False)
+    g = run(True)
+    assert not e[6] and g[6] and e[4] == g[4] == 4
+    for a, b, name in zip(e[:4], g[:4], ("params", "ema", "mu", "nu")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert e[5] == g[5]
+    assert len({s["train_bpd"] for s in g[5]}) == 4               # four different steps, not one replayed result
