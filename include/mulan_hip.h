@@ -156,6 +156,26 @@ int mulan_gemm(const float* A, const float* B, float* C, const float* bias, cons
 /* bytes of split-K workspace mulan_gemm can use for this shape (0: none needed; workspace may be NULL) */
 size_t mulan_gemm_workspace(int M, int N, int K, int batch);
 
+/* ---- fused attention core (f16x3), S = 1024 positions, one head, C = 128 ------------------------------------
+ * AttnBlock core softmax((q / sqrt(C)) k^T) v and its gradients (model_vdm.py:679-683, 704-802) without the
+ * [1024 x 1024] score / probability matrices in HBM.  Operands are the packs of mulan_linear_pack_f16x3_batched:
+ * "T" pack of x [B,1024,C]: (K = C, N = 1024, transpose = 1); "N" pack: (K = 1024, N = C, transpose = 0); *max: the
+ * per-image maxima ([B][16], mulan_absmax_rows) the packs were scaled with.  alpha = 1 / sqrt(C).
+ * forward: o [B,1024,C] and lse [B,1024] = log sum_j exp(alpha q_i k_j).
+ * backward: delta = rowsum(do * o) (mulan_attention_delta), dmax = its maxima; dq, dk, dv [B,1024,C]. */
+int mulan_attention_fwd_f16x3(const void* qt, const void* kt, const void* vn, const unsigned* qmax, const unsigned* kmax,
+                              const unsigned* vmax, float* o, float* lse, int B, int S, int C, float alpha,
+                              mulan_stream_t stream);
+/* both packs of x [B,1024,C] in one pass (xt and / or xn may be NULL) */
+int mulan_attention_pack_f16x3(const float* x, const unsigned* xmax, void* xt, void* xn, int B, int S, int C,
+                               mulan_stream_t stream);
+int mulan_attention_delta(const float* dout, const float* o, float* delta, int B, int S, int C, mulan_stream_t stream);
+int mulan_attention_bwd_f16x3(const void* qt, const void* qn, const void* kt, const void* kn, const void* vt,
+                              const void* dot, const void* don, const unsigned* qmax, const unsigned* kmax,
+                              const unsigned* vmax, const unsigned* domax, const unsigned* dmax, const float* lse,
+                              const float* delta, float* dq, float* dk, float* dv, int B, int S, int C, float alpha,
+                              mulan_stream_t stream);
+
 /* ---- GroupNorm (+SiLU) (+dropout), input = virtual channel concat [x1|x2] --------------------
  * nn.GroupNorm() + nn.swish + nn.Dropout in ResnetBlock (model_vdm.py:622-623,632,643-644), final
  * norm (model_vdm.py:376-377), AttnBlock norm (model_vdm.py:672-674).  hw must be 1024.

@@ -58,6 +58,10 @@ SIGNATURES = {
     "mulan_linear_pack_f16x3_batched": [P, P, P, I, I, I, I, P],
     "mulan_linear_f16x3_batched": [P, P, I, P, P, P, P, P, I, I, I, P],
     "mulan_bmm_tn_f16x3_planes": [P, P, P, P, P, I, I, I, I, I, P],
+    "mulan_attention_fwd_f16x3": [P, P, P, P, P, P, P, P, I, I, I, F, P],
+    "mulan_attention_delta": [P, P, P, I, I, I, P],
+    "mulan_attention_pack_f16x3": [P, P, P, P, I, I, I, P],
+    "mulan_attention_bwd_f16x3": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, P],
     "mulan_fourier_fwd": [P, P, Z, P],
     "mulan_fourier_bwd": [P, P, P, Z, I, P],
     "mulan_temb_fwd": [P, P, I, I, I, I, P],

@@ -855,6 +855,68 @@ def bmm_tn_planes_raw(xs, xmax, dys, dymax, B, C, N):
     return out
 
 
+ATTN_FUSED = True      # fused (flash-style) attention kernels for C = 128: S and P never reach HBM
+
+
+def _attn_fused_ok(q):
+    B, S, C = q.shape
+    return CONV_MODE == "f16x3" and ATTN_F16X3 and ATTN_FUSED and S == HW and C == 128
+
+
+def _attn_packs(x, xmax, want_t=True, want_n=True):
+    """("T" pack, "N" pack) of x [B, 1024, 128] for the fused attention kernels, one pass over x"""
+    B, S, C = x.shape
+    xt = torch.empty(B * S * C * 4, device=x.device, dtype=torch.uint8) if want_t else None
+    xn = torch.empty(B * S * C * 4, device=x.device, dtype=torch.uint8) if want_n else None
+    call("mulan_attention_pack_f16x3", ptr(x), ptr(xmax), ptr(xt), ptr(xn), B, S, C, stream())
+    return xt, xn
+
+
+class FusedAttentionFn(torch.autograd.Function):
+    """softmax((q / sqrt(C)) k^T) v on the fused f16x3 kernels (attention_f16x3.hip): the forward kernel keeps the online
+    softmax state and writes o + the per-query log-sum-exp, the backward kernels recompute the probabilities from it.
+    Saved for backward: the split packs of q, k, v (which replace the fp32 tensors), o and lse -- no [B, 1024, 1024]
+    tensor."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        q, k, v = _c(q), _c(k), _c(v)
+        B, S, C = q.shape
+        alpha = 1.0 / math.sqrt(C)
+        need = any(ctx.needs_input_grad)          # (grad mode is off inside Function.forward: this is the signal)
+        qm, km, vm = cached_absmax(q), cached_absmax(k), cached_absmax(v)
+        qt, qn = _attn_packs(q, qm, True, need)
+        kt, kn = _attn_packs(k, km, True, need)
+        vt, vn = _attn_packs(v, vm, need, True)
+        o = torch.empty_like(q)
+        lse = torch.empty((B, S), device=q.device, dtype=torch.float32)
+        _timed("attn_f16x3_kernel<fwd>", 4.0 * B * S * S * C,
+               lambda: call("mulan_attention_fwd_f16x3", ptr(qt), ptr(kt), ptr(vn), ptr(qm), ptr(km), ptr(vm), ptr(o),
+                            ptr(lse), B, S, C, alpha, stream()))
+        if need:
+            ctx.save_for_backward(o, lse, qt, qn, kt, kn, vt, qm, km, vm)
+        return o
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, do):
+        o, lse, qt, qn, kt, kn, vt, qm, km, vm = ctx.saved_tensors
+        do = _c(do)
+        B, S, C = o.shape
+        alpha = 1.0 / math.sqrt(C)
+        dom = cached_absmax(do)
+        delta = torch.empty((B, S), device=o.device, dtype=torch.float32)
+        call("mulan_attention_delta", ptr(do), ptr(o), ptr(delta), B, S, C, stream())
+        dm = absmax_rows(delta)
+        dot, don = _attn_packs(do, dom)
+        dq, dk, dv = torch.empty_like(o), torch.empty_like(o), torch.empty_like(o)
+        _timed("attn_f16x3_kernel<bwd>", 14.0 * B * S * S * C,
+               lambda: call("mulan_attention_bwd_f16x3", ptr(qt), ptr(qn), ptr(kt), ptr(kn), ptr(vt), ptr(dot), ptr(don),
+                            ptr(qm), ptr(km), ptr(vm), ptr(dom), ptr(dm), ptr(lse), ptr(delta), ptr(dq), ptr(dk),
+                            ptr(dv), B, S, C, alpha, stream()))
+        return dq, dk, dv
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax((q / sqrt(C)) k^T) v for one head over 1024 positions (ldm/model_vdm.py:679-683,704-802).
     f16x3 mode: S = q k^T, O = P v, dP = dO v^T and dQ = dS k run on the split-operand kernel with one packed operand
@@ -919,6 +981,8 @@ class AttentionFn(torch.autograd.Function):
 
 
 def attention(q, k, v):
+    if _attn_fused_ok(q):
+        return FusedAttentionFn.apply(q, k, v)
     return AttentionFn.apply(q, k, v)
 
 

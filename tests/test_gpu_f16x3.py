@@ -546,3 +546,52 @@ def test_f16x3_plane_fed_wgrad_heavy_tails(ops):
     dw = ops.conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, B, C, N).cpu().double().numpy()
     err = float((np.abs(dw - wt.grad.numpy()) / aw.grad.numpy()).max())
     assert err < 1e-5, err
+
+
+def test_fused_attention_forced_rescales_and_ranges(ops, monkeypatch):
+    """The fused attention kernels (attention_f16x3.hip) where the online softmax could go wrong: keys that beat the
+    running maximum late in the sweep (one query/key pair with a score far above the rest in tile 21, another in the
+    last tile), a query whose scores are all very negative, images of very different magnitude; forward and all three
+    gradients against float64 autograd, per image, and against the unfused split-operand path."""
+    rng = np.random.default_rng(9)
+    B, S, C = 2, 1024, 128
+    q, k, v = (rng.standard_normal((B, S, C)) for _ in range(3))
+    k[0, 700] = 6.0 * q[0, 5]                  # query 5: the maximum jumps by ~60 at row tile 21
+    k[0, 1023] = 9.0 * q[0, 77]                # query 77: ... and in the very last tile
+    q[1, 300] *= 25.0                          # a query with a wide score range
+    k[1, 0] = -4.0 * q[1, 301]                 # one strongly negative score in the first tile
+    v[1] *= 512.0
+    do = rng.standard_normal((B, S, C))
+    do[0] *= 1e-3
+    qt, kt, vt = (torch.tensor(a, requires_grad=True) for a in (q, k, v))
+    o = torch.einsum("bqk,bkc->bqc", torch.softmax(torch.einsum("bqc,bkc->bqk", qt / math.sqrt(C), kt), -1), vt)
+    o.backward(torch.tensor(do))
+    refs = [o.detach().numpy(), qt.grad.numpy(), kt.grad.numpy(), vt.grad.numpy()]
+    rel = lambda a, r: float(np.abs(a - r).max() / np.abs(r).max())
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "ATTN_FUSED", fused)
+        g = [dev(a).requires_grad_() for a in (q, k, v)]
+        out = ops.attention(*g)
+        assert (type(out.grad_fn).__name__ == "FusedAttentionFnBackward") == fused
+        out.backward(dev(do))
+        outs[fused] = [out.detach().cpu().double().numpy()] + [a.grad.cpu().double().numpy() for a in g]
+    for b in range(B):
+        for name, got, old, r in zip(("o", "dq", "dk", "dv"), outs[True], outs[False], refs):
+            assert rel(got[b], r[b]) < 1e-5, (name, b, rel(got[b], r[b]))
+            assert rel(got[b], r[b]) < 2.0 * rel(old[b], r[b]) + 2e-6, (name, b, rel(got[b], r[b]), rel(old[b], r[b]))
+    # the rows that took the rescale branch, on their own (their dq is ~0: the softmax is saturated on one key)
+    for (b, i) in ((0, 5), (0, 77), (1, 300)):
+        assert rel(outs[True][0][b, i], refs[0][b, i]) < 1e-5
+
+
+def test_attention_dual_pack_equals_the_generic_packs(ops):
+    """mulan_attention_pack_f16x3 (both operand layouts in one pass) is bit-identical to the two calls of
+    mulan_linear_pack_f16x3_batched it replaces"""
+    torch.manual_seed(3)
+    x = torch.randn(3, 1024, 128, device="cuda") * torch.tensor([1.0, 300.0, 1e-3], device="cuda")[:, None, None]
+    m = ops.absmax_rows(x)
+    xt, xn = ops._attn_packs(x, m)
+    assert torch.equal(xt, ops._pack_batched(x, True, m)) and torch.equal(xn, ops._pack_batched(x, False, m))
+    only_t, none = ops._attn_packs(x, m, True, False)
+    assert none is None and torch.equal(only_t, xt)
