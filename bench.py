@@ -233,17 +233,26 @@ def main():
             # FLOP/s is the dense bf16/fp16 MFMA peak / passes; exact-fp32 MFMA mode: the fp32 MFMA peak.
             peak = PEAK_BF16_MFMA_TFLOPS / passes if bf else PEAK_F32_MFMA_TFLOPS
             # HBM bytes per launch: from the committed rocprofv3 PMC passes of this kernel (separate FETCH_SIZE /
-            # WRITE_SIZE runs, gfx950 corrections applied; tools/pmc_conv.py), not re-measured inside the bench
+            # WRITE_SIZE runs per launch shape, gfx950 corrections applied; tools/pmc_conv.py), not re-measured inside
+            # the bench: every launch of the step is priced with the bytes of its shape (by its FLOP count: 128->128
+            # vs the two 256 <-> 128 shapes) and `traffic` is the mean over the step's launches
             traffic, pmc = a.traffic, None
-            pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_conv3x3_f16x3.json")
-            if "f16x3" in name and os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_conv3x3_f16x3.json")
+            if "f16x3" in name and os.path.exists(pmc_file) and int(config.model.sm_n_embd) == 128:
                 with open(pmc_file) as f:
-                    pj = json.load(f)
-                pmc = {"source": "profiles/r01_pmc_conv3x3_f16x3.json (B=128, 128->128 launch)",
-                       "hbm_bytes_per_launch": pj["hbm_bytes_per_launch"], "hbm_GBps": round(pj["hbm_GBps"], 1),
-                       "mfma_util": round(pj["mfma_util"], 4), "clock_GHz": round(pj["clock_GHz_from_GRBM"], 3)}
-                if traffic is None:
-                    traffic = pj["hbm_bytes_per_launch"]
+                    pj = json.load(f)["shapes"]
+                scale = B / 128.0
+                small = pj["fwd_128_128_res"]["hbm_bytes_per_launch"]
+                big = 0.5 * (pj["fwd_256_128"]["hbm_bytes_per_launch"] + pj["dgrad_128_256"]["hbm_bytes_per_launch"])
+                fl_small = 2.0 * B * 1024 * 9 * 128 * 128
+                byts = [scale * (small if fl < 1.5 * fl_small else big) for (nm, _, _, fl) in recs if nm == name]
+                pmc = {"source": "profiles/r02_pmc_conv3x3_f16x3.json (B = 128; shapes 128->128 +residual, 256->128, "
+                                 "128->256 input gradient; scaled by batch / 128)",
+                       "hbm_bytes_per_launch_by_shape": {k: v["hbm_bytes_per_launch"] for k, v in pj.items()},
+                       "mfma_util_by_shape": {k: round(v["mfma_util"], 4) for k, v in pj.items()},
+                       "traffic_over_algorithmic_by_shape": {k: round(v["traffic_over_algorithmic"], 3) for k, v in pj.items()}}
+                if traffic is None and byts:
+                    traffic = sum(byts) / len(byts)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "pmc": pmc,
                     "peak_note": (f"dense 16-bit MFMA 2500 TFLOP/s / {passes} passes (split operands, fp32-equivalent "

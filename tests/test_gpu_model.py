@@ -688,3 +688,41 @@ def test_graph_replayed_train_steps_equal_eager_steps():
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
     assert e[5] == g[5]
     assert len({s["train_bpd"] for s in g[5]}) == 4               # four different steps, not one replayed result
+
+
+def test_by_product_hand_overs_fire_in_a_full_depth_step(monkeypatch):
+    """The f16x3 kernels hand their by-products on (output maxima from GroupNorm / convolution epilogues, split planes,
+    channel sums): a separate mulan_absmax_rows pass is only needed where no producer kernel exists.  A silent miss
+    (e.g. after a torch upgrade changed tensor versioning) would cost an extra pass per layer: count the launches of one
+    full-depth (32 + 2 + 33 blocks) train step."""
+    import os
+    from collections import Counter
+    from mulan_amd import ops as _ops
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+    config.data.dataset = "synthetic"
+    config.training.batch_size_train = 2
+    config.training.batch_size_eval = 2
+    config.training.substeps = 1
+    config.training.hip_graph = False
+    exp = Experiment_VDM(config)
+    batch = {"images": torch.randint(0, 256, (2, 32, 32, 3), dtype=torch.uint8).cuda(),
+             "labels": torch.zeros(2, dtype=torch.int32).cuda(), "conditioning": torch.zeros(2, dtype=torch.uint8).cuda()}
+    exp.train_step(exp._train_rng, exp.state, batch)            # warm-up
+    counts = Counter()
+    orig = _ops.call
+
+    def counting(name, *a):
+        counts[name] += 1
+        return orig(name, *a)
+    monkeypatch.setattr(_ops, "call", counting)
+    exp.train_step(exp._train_rng, exp.state, batch)
+    torch.cuda.synchronize()
+    print("launches per step:", sum(counts.values()), dict(counts.most_common(12)))
+    # 2 attention blocks x (q, k, v, dO, delta) + conv_in / conv_out / loss-side tensors: no per-ResnetBlock passes
+    assert counts["mulan_absmax_rows"] <= 24, counts["mulan_absmax_rows"]
+    assert counts["mulan_conv3x3_pack_f16x3"] == 0 and counts["mulan_linear_pack_f16x3"] == 0   # ParamPacker did them all
+    assert counts["mulan_param_pack_f16x3"] == 1 and counts["mulan_param_maxima"] == 1
+    assert counts["mulan_conv3x3_wgrad_f16x3_planes"] >= 2 * 67 + 2 * 6                     # plane-fed weight gradients
