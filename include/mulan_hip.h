@@ -205,6 +205,18 @@ int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C
                         unsigned long long seed, unsigned long long offset, int accumulate, unsigned* dx1max,
                         unsigned* dx2max, const float* add1, const float* add2, float* dxsum_part,
                         mulan_stream_t stream);
+/* _fused: the reduction of the per-sample partials over the samples happens inside the launch (the last block of each
+ * 32-channel slab sums them in a fixed order): dgamma / dbeta [C1+C2] receive the totals, dxsum (optional) the sum over
+ * samples of dxsum_part's x1 columns [C1] = the bias gradient of the convolution whose output gradient dx1 is, dxsum2
+ * (optional) a second copy of it (a shortcut layer's bias that sees the same gradient).  tickets: [16] unsigned, zero
+ * before the first launch on a stream (each launch leaves them zero). */
+int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                              const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
+                              float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
+                              unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
+                              unsigned* dx1max, unsigned* dx2max, const float* add1, const float* add2,
+                              float* dxsum_part, float* dgamma, float* dbeta, float* dxsum, float* dxsum2,
+                              unsigned* tickets, mulan_stream_t stream);
 /* add1 / add2 (optional): gradients arriving through a skip path of x1 / x2 (the ResnetBlock residual, nin_shortcut),
  * added while dx is written, so that no separate accumulation pass exists.  By-products of the written gradients (the
  * dy of the convolution in front): dx1max / dx2max (optional, [B][16], mulan_absmax_rows format) and dxsum_part

@@ -41,10 +41,19 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // acc += A B in place on accumulator registers ("a" class): the 128 accumulator registers stay out of the compiler's
 // allocation games (with the builtin it rotates them through the vector registers and spills at the 256-register cap).
-// PAD: two wait states in front for a VALU-written operand (the weight-fragment copy at the end of a chunk pair).
-template <bool PAD>
+// PAD 1: two wait states in front for a VALU-written operand (the weight-fragment copy at the end of a chunk pair).
+// PAD 2: the last MFMA of a chunk pair (the loop may end behind it).  The compiler does not know that these statements
+// are matrix instructions and handles none of their hazards: at the loop exit it reads accumulators back (register
+// shuffles, spills) right away, and a v_accvgpr_read that comes too early returns the value from BEFORE the last MFMA
+// -- seen as wrong outputs in the last pixel tile, in blocks that run without other stalls (raised priority, B >= 128).
+// The wait therefore sits inside the same statement, where nothing can be scheduled in front of it; it overlaps the
+// barrier that follows, and the other block of the CU issues meanwhile.
+template <int PAD>
 __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const f16x3::f16x8& b, bool) {
-  if (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  if (PAD == 1) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else if (PAD == 2)
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+a"(acc) : "v"(a), "v"(b));
   else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
@@ -237,11 +246,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         const int xo = ((pn >> 1) * kPW + (pn & 1) * 16) * 32;
         // small terms first: w_l x_h, w_h x_l, w_h x_h; the two cout tiles alternate so that an MFMA never waits for the
         // accumulator of the one right in front of it
-        if (pt == 0) mfma16<true>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
-        else mfma16<false>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
+        if (pt == 0) mfma16<1>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
+        else mfma16<0>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
         if (!(ABL & 1)) xf[nxt][0] = *reinterpret_cast<const f16x8*>(smem + xa + xo);
-        mfma16<false>(acc[pt][1], wf[s & 1][1][1], xf[cur][0], false);
-        mfma16<false>(acc[pt][0], wf[s & 1][0][0], xf[cur][1], false);
+        mfma16<0>(acc[pt][1], wf[s & 1][1][1], xf[cur][0], false);
+        mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][1], false);
         if (!(ABL & 2) && pt >= 1 && pt <= 4) load_w1(wf[(s + 1) & 1], uAn, uBn, pt - 1, sel_s);
         if (!(ABL & 4) && (pt == 6 || pt == 8) && (fill0 || fill1)) {
           i32x4& r = st_useB ? stgB[pt == 8] : stgA[pt == 8];
@@ -250,10 +259,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         }
         if (!(ABL & 4) && (pt == 10 || pt == 12) && lk >= 0)
           (ld_useB ? stgB[pt == 12] : stgA[pt == 12]) = load_slot(slot_of(t_l, 2 * lk + (pt == 12)), lcc);
-        mfma16<false>(acc[pt][1], wf[s & 1][1][0], xf[cur][1], false);
+        mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][1], false);
         if (!(ABL & 1)) xf[nxt][1] = *reinterpret_cast<const f16x8*>(smem + xa + xo + P3_PLANE);
-        mfma16<false>(acc[pt][0], wf[s & 1][0][0], xf[cur][0], false);
-        mfma16<false>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
+        mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][0], false);
+        if (s == 8 && pt == 15) mfma16<2>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
+        else mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
       }
       xaddr = xaddr_n;
       if (!(ABL & 8) && (s == 4 || s == 8)) __syncthreads();
@@ -265,8 +275,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) wf[0][ct][pl] = wf[1][ct][pl];
   }
-  // the accumulators were written by matrix instructions the compiler does not see: let them retire before they are read
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   if (tl) p.stamps[66 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
   if (tl && tl_blk < 32) p.stamps[tl_blk] = __builtin_amdgcn_s_memtime() - cyc0;   // core cycles spent in the main loop
 

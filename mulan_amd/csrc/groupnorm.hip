@@ -181,6 +181,12 @@ struct GnBwdArgs {
   const float* add1; const float* add2;        // optional: dx1 += add1, dx2 += add2 (gradient of a skip path of x)
   float* dxsum_part;                           // optional [B, C1+C2]: per-sample channel sums of the written dx
   const unsigned long long* seed_dev;          // optional: dropout seed = seed ^ seed_dev[0] (as in the forward pass)
+  // optional in-kernel final reduction over the samples (fused entry point): the block that finishes last among the B
+  // blocks of a 32-channel slab sums the per-sample partials in a fixed order and writes the totals
+  unsigned* tickets;                           // [Ct / 32] arrival counters, zero before the first launch (re-armed here)
+  float* dgamma; float* dbeta;                 // [Ct] totals
+  float* dxsum; float* dxsum2;                 // optional [C1] each: sum over samples of dxsum_part's x1 columns (the bias
+                                               // gradient of the convolution in front, and of a shortcut layer sharing it)
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -365,8 +371,13 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     float a = 0.f, bb = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) { a += cred[w * 32 + tid]; bb += cred[256 + w * 32 + tid]; }
-    p.dgamma_part[(size_t)b * Ct + c0 + tid] = a;
-    p.dbeta_part[(size_t)b * Ct + c0 + tid] = bb;
+    if (p.tickets) {   // handed to another block inside this launch: write-through stores (guide G16, R1)
+      __hip_atomic_store(p.dgamma_part + (size_t)b * Ct + c0 + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.dbeta_part + (size_t)b * Ct + c0 + tid, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      p.dgamma_part[(size_t)b * Ct + c0 + tid] = a;
+      p.dbeta_part[(size_t)b * Ct + c0 + tid] = bb;
+    }
   }
   const int g0 = (quad / qpg) * qpg;
   float t1 = 0.f, t2 = 0.f;
@@ -416,7 +427,8 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
       float a = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) a += cred[w * 32 + tid];
-      p.dxsum_part[(size_t)b * Ct + c0 + tid] = a;
+      if (p.tickets) __hip_atomic_store(p.dxsum_part + (size_t)b * Ct + c0 + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else p.dxsum_part[(size_t)b * Ct + c0 + tid] = a;
     }
   }
   unsigned* mout = c0 < p.C1 ? p.dx1max : p.dx2max;
@@ -435,6 +447,48 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
       mout[b * 16 + slab] = m;
     }
     if (slab == 0 && tid >= nslab && tid < 16) mout[b * 16 + tid] = 0u;
+  }
+  if (p.tickets) {
+    // Final reduction over the samples, inside the launch (replaces one mulan_colsum launch per GroupNorm and one per
+    // convolution bias).  Hand-off as in the guide's G16 / R1: the partials above are write-through stores; every wave
+    // drains its stores, the block's barrier, ONE lane takes a ticket (agent-scope atomic add); the block whose add
+    // returns B - 1 came last: its lanes load after the barrier that follows, with sc1 loads (no acquire needed for
+    // this row of the table: 4-byte sc1 stores, 4-byte sc1 loads, hipMalloc memory).  The sum runs in a fixed order
+    // (16 interleaved sample lanes, then the 16 partial sums in order): deterministic, whichever block comes last.
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)p.B - 1u) ? 1u : 0u;
+      if (s_last) __hip_atomic_store(p.tickets + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+    if (s_last) {
+      const int ch = tid & 31, sl = tid >> 5;                  // 16 sample lanes x 32 channels
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int sm = sl; sm < p.B; sm += 16) {
+        const size_t o = (size_t)sm * Ct + c0 + ch;
+        a0 += __hip_atomic_load(p.dgamma_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a1 += __hip_atomic_load(p.dbeta_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p.dxsum && c0 < p.C1) a2 += __hip_atomic_load(p.dxsum_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      float* outs[3] = {p.dgamma, p.dbeta, c0 < p.C1 ? p.dxsum : nullptr};
+      const float vals[3] = {a0, a1, a2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        __syncthreads();
+        cred[tid] = vals[k];
+        __syncthreads();
+        if (tid < 32 && outs[k]) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) t += cred[j * 32 + tid];
+          outs[k][c0 + tid] = t;
+          if (k == 2 && p.dxsum2) p.dxsum2[c0 + tid] = t;
+        }
+      }
+    }
   }
 }
 
@@ -478,11 +532,38 @@ MULAN_API int mulan_groupnorm_bwd_dyn(const float* dy, const float* x1, const fl
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   if ((dx1max && C1 / 32 > 16) || (dx2max && C2 / 32 > 16)) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
-              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max, add1, add2, dxsum_part, seed_dev};
+              B, G, act, keep, seed, offset, accumulate, dx1max, dx2max, add1, add2, dxsum_part, seed_dev, nullptr, nullptr,
+              nullptr, nullptr, nullptr};
   if (g_mulan_tune[2] == 1 && !dx1max && !dx2max && !add1 && !add2 && !dxsum_part)   // dev A/B: two-pass 256-thread variant
     hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   else
     hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+// mulan_groupnorm_bwd_dyn + the final reduction over the samples inside the launch: dgamma / dbeta [C1 + C2] receive the
+// totals (dgamma_part / dbeta_part [B, C1 + C2] stay the scratch for the per-sample partials), dxsum (optional, [C1]) the
+// sum over samples of dxsum_part's x1 columns -- the bias gradient of the convolution whose output gradient dx1 is --
+// and dxsum2 (optional) a second copy of it (the bias of a shortcut layer that sees the same gradient).
+// tickets: [16] unsigned, zero before the first launch on a stream (every launch leaves them zero again).
+MULAN_API int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const float* x2, int C1, int C2,
+                                        const float* gamma, const float* beta, const float* mean, const float* rstd,
+                                        float* dx1, float* dx2, float* dgamma_part, float* dbeta_part, int B, int hw,
+                                        int G, int act, float keep, unsigned long long seed, unsigned long long offset,
+                                        const unsigned long long* seed_dev, unsigned* dx1max, unsigned* dx2max,
+                                        const float* add1, const float* add2, float* dxsum_part, float* dgamma,
+                                        float* dbeta, float* dxsum, float* dxsum2, unsigned* tickets,
+                                        hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !tickets || !dgamma || !dbeta || !dgamma_part || !dbeta_part ||
+      (dxsum && !dxsum_part) || (dxsum2 && !dxsum) || Ct / 32 > 16)
+    return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
+  GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
+              B, G, act, keep, seed, offset, 0, dx1max, dx2max, add1, add2, dxsum_part, seed_dev, tickets, dgamma, dbeta,
+              dxsum, dxsum2};
+  hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
 

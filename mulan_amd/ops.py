@@ -320,17 +320,19 @@ def gemm_raw(A, Bm, M, N, K, *, bias=None, R=None, transA=False, transB=False, a
     return out
 
 
-def colsum_raw(x2d, nseg, seg, C, out=None):
-    """out[s][c] = sum of `seg` consecutive rows; long segments are reduced in two stages so the grid
-    always has enough blocks to stream from HBM (fixed order => deterministic)."""
+def colsum_raw(x2d, nseg, seg, C, out=None, ld=None):
+    """out[s][c] = sum of `seg` consecutive rows (row stride ld, default C); long segments are reduced in two stages so
+    the grid always has enough blocks to stream from HBM (fixed order => deterministic)."""
     chunk = 512
+    ld = C if ld is None else ld
+    src = ptr(x2d) if ld == C else x2d.data_ptr()       # rows of a wider matrix: the stride goes to the kernel
     if seg >= 4 * chunk and seg % chunk == 0:
         part = torch.empty((nseg * (seg // chunk), C), device=x2d.device, dtype=torch.float32)
-        call("mulan_colsum", ptr(x2d), ptr(part), nseg * (seg // chunk), chunk, C, C, 0, stream())
-        x2d, seg = part, seg // chunk
+        call("mulan_colsum", src, ptr(part), nseg * (seg // chunk), chunk, C, ld, 0, stream())
+        src, seg, ld = ptr(part), seg // chunk, C
     if out is None:
         out = torch.empty((nseg, C), device=x2d.device, dtype=torch.float32)
-    call("mulan_colsum", ptr(x2d), ptr(out), nseg, seg, C, C, 0, stream())
+    call("mulan_colsum", src, ptr(out), nseg, seg, C, ld, 0, stream())
     return out
 
 
@@ -365,6 +367,11 @@ class Conv3x3Fn(torch.autograd.Function):
         ctx.xmax = xmax
         ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
         ctx.gv = (_gv(w), _gv(bias))
+        if ctx.gv[1] is not None and ctx.needs_input_grad[2]:
+            # A GroupNorm that consumes y writes this bias' gradient (the channel sums of the dy it produces) from inside
+            # its backward kernel; `twin`: the bias of the shortcut layer whose output is `res` sees the same gradient.
+            twin = getattr(res, "_bias_twin", None) if res is not None else None
+            y._bias_sink = (ctx.gv[1], twin[0] if (twin is not None and twin[1] == res._version) else None, y._version)
         return y
 
     @staticmethod
@@ -396,9 +403,16 @@ class Conv3x3Fn(torch.autograd.Function):
             per_sample = cs[0] if (cs is not None and cs[1] == dy._version and cs[0].shape == (B, N)) \
                 else colsum_raw(dy, B, HW, N)              # [B,N]
         if has_bias and ctx.needs_input_grad[2]:
-            dbias = colsum_raw(per_sample, 1, B, N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
+            done = getattr(dy, "_biasdone", None)          # the GroupNorm backward already summed it into the sink
+            twin = None
+            if (done is not None and done[2] == dy._version and gvb is not None and
+                    done[0].data_ptr() == gvb.data_ptr()):
+                dbias, twin = _fresh(gvb), done[1]
+            else:
+                dbias = colsum_raw(per_sample, 1, B, N, out=_fresh(gvb).view(1, N) if gvb is not None else None,
+                                   ld=per_sample.stride(0)).view(N)
             try:       # the shortcut layer that shares this dy (nin_shortcut + bias) needs the very same column sum
-                dy._biasgrad = (dbias.view(N), dy._version)    # (a separate view object: autograd adopts `dbias` itself)
+                dy._biasgrad = (dbias.view(N), dy._version, twin)   # (a separate view: autograd adopts `dbias` itself)
             except (AttributeError, RuntimeError):
                 pass
         if cb_dim is not None and ctx.needs_input_grad[3]:
@@ -412,6 +426,13 @@ def conv3x3(x, w, bias=None, cbias=None, res=None):
 
 
 # ----------------------------------------------------------------------------- dense
+def _tag_bias_twin(y, gvb, wanted):
+    """A dense layer whose output becomes the residual input of a 3x3 convolution (nin_shortcut, ldm/model_vdm.py:652-656)
+    has the same bias gradient as that convolution: the convolution passes this sink on (Conv3x3Fn.forward)."""
+    if gvb is not None and wanted:
+        y._bias_twin = (gvb, y._version)
+
+
 def _dense_bias_grad(dy, M, N, gvb):
     """sum of dy over all rows; re-used from the convolution that consumed the same dy when there is one"""
     out = _fresh(gvb) if gvb is not None else None
@@ -419,7 +440,8 @@ def _dense_bias_grad(dy, M, N, gvb):
     if c is not None and c[1] == dy._version and c[0].numel() == N:
         if out is None:
             return c[0].view(N)
-        out.view(N).copy_(c[0].view(N))
+        if not (len(c) > 2 and c[2] is not None and c[2].data_ptr() == out.data_ptr()):   # else: written there already
+            out.view(N).copy_(c[0].view(N))
         return out.view(N)
     return colsum_raw(dy.reshape(M, N), 1, M, N, out=out.view(1, N) if out is not None else None).view(N)
 
@@ -494,7 +516,9 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.meta = (x.shape, bias is not None, res is not None)
         ctx.gv = (_gv(w), _gv(bias))
-        return y.view(*x.shape[:-1], N)
+        y = y.view(*x.shape[:-1], N)
+        _tag_bias_twin(y, ctx.gv[1], ctx.needs_input_grad[2])
+        return y
 
     @staticmethod
     @once_differentiable
@@ -627,7 +651,9 @@ class Linear2Fn(torch.autograd.Function):
         ctx.save_for_backward(a1, a2, w)
         ctx.shape = x1.shape[:-1]
         ctx.gv = (_gv(w), _gv(bias))
-        return y.view(*x1.shape[:-1], N)
+        y = y.view(*x1.shape[:-1], N)
+        _tag_bias_twin(y, ctx.gv[1], ctx.needs_input_grad[3])
+        return y
 
     @staticmethod
     @once_differentiable
@@ -702,6 +728,18 @@ def _seed_args(seed):
     return int(seed), None
 
 
+GN_FUSED_REDUCE = _os.environ.get("MULAN_GN_FUSED_REDUCE", "1") == "1"   # A/B switch: 0 = separate mulan_colsum launches
+_TICKETS = {}
+
+
+def _gn_tickets(device):
+    """arrival counters of the in-kernel reductions (zero between launches; one stream at a time per device)"""
+    t = _TICKETS.get(device)
+    if t is None:
+        t = _TICKETS[device] = torch.zeros(16, device=device, dtype=torch.int32)
+    return t
+
+
 def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     x1, x2 = _c(x1), _c(x2)
     B, C1 = x1.shape[0], x1.shape[-1]
@@ -720,6 +758,8 @@ def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd)
     ctx.meta = (groups, int(act), float(keep), seed, int(offset))
     ctx.gv = (_gv(gamma), _gv(beta))
+    bs = getattr(x1, "_bias_sink", None)       # left by the convolution that produced x1 (see Conv3x3Fn.forward)
+    ctx.bias_sink = bs[:2] if (bs is not None and bs[2] == x1._version and bs[0].numel() == C1) else None
     return y, x1, x2
 
 
@@ -742,22 +782,33 @@ def _gn_backward(ctx, dy, add1=None, add2=None):
           if f16 and x2 is not None and C2 // 32 <= MAX_PARTS else None)
     csum = torch.empty((B, Ct), device=dy.device, dtype=torch.float32)
     sv, sd = _seed_args(seed)
-    call("mulan_groupnorm_bwd_dyn", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
-         ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), 0, ptr(m1), ptr(m2),
-         ptr(_c(add1)), ptr(_c(add2)), ptr(csum), stream())
+    gvg, gvb = ctx.gv
+    dgamma = _fresh(gvg) if gvg is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
+    dbeta = _fresh(gvb) if gvb is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
+    cpg = Ct // groups
+    fused = (GN_FUSED_REDUCE and C1 % 32 == 0 and C2 % 32 == 0 and Ct // 32 <= 16 and cpg % 4 == 0 and 32 % cpg == 0)
+    if fused:       # the sums over the samples (dgamma, dbeta, the bias gradient of the convolution in front) in-kernel
+        sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
+        call("mulan_groupnorm_bwd_fused", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+             ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(m1), ptr(m2),
+             ptr(_c(add1)), ptr(_c(add2)), ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2),
+             ptr(_gn_tickets(dy.device)), stream())
+        if sink is not None:
+            dx1._biasdone = (sink, sink2, dx1._version)
+    else:
+        call("mulan_groupnorm_bwd_dyn", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+             ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), 0, ptr(m1), ptr(m2),
+             ptr(_c(add1)), ptr(_c(add2)), ptr(csum), stream())
+        if Ct % 4 == 0 and dgamma.data_ptr() % 16 == 0 and dbeta.data_ptr() % 16 == 0:
+            call("mulan_colsum_pair", ptr(parts), ptr(dgamma), ptr(dbeta), B, Ct, stream())     # both sums, one launch
+        else:
+            colsum_raw(dgp, 1, B, Ct, out=dgamma.view(1, Ct))
+            colsum_raw(dbp, 1, B, Ct, out=dbeta.view(1, Ct))
     if m1 is not None:
         dx1._absmax = (m1, dx1._version)
     if m2 is not None:
         dx2._absmax = (m2, dx2._version)
-    dx1._colsum = (csum if x2 is None else csum[:, :C1].contiguous(), dx1._version)
-    gvg, gvb = ctx.gv
-    dgamma = _fresh(gvg) if gvg is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
-    dbeta = _fresh(gvb) if gvb is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
-    if Ct % 4 == 0 and dgamma.data_ptr() % 16 == 0 and dbeta.data_ptr() % 16 == 0:
-        call("mulan_colsum_pair", ptr(parts), ptr(dgamma), ptr(dbeta), B, Ct, stream())     # both sums, one launch
-    else:
-        colsum_raw(dgp, 1, B, Ct, out=dgamma.view(1, Ct))
-        colsum_raw(dbp, 1, B, Ct, out=dbeta.view(1, Ct))
+    dx1._colsum = (csum[:, :C1], dx1._version)          # a strided view when there is an x2: consumers take its row stride
     return dx1, dx2, dgamma, dbeta
 
 

@@ -360,6 +360,57 @@ def test_group_norm_skip_adds_the_skip_gradient_in_kernel(ops):
             assert float((cs.double() - refcs).abs().max()) <= 2e-5 * float(dx1.abs().double().sum(1).max())
 
 
+@pytest.mark.parametrize("B,C2", [(1, 0), (5, 0), (37, 128), (128, 128)])
+def test_gn_backward_sums_over_samples_inside_the_launch(ops, monkeypatch, B, C2):
+    """mulan_groupnorm_bwd_fused: dgamma, dbeta and the bias gradients of the convolution in front (and of the shortcut
+    layer that shares its dy) are summed over the samples by the block that finishes last -- no column-sum launches.
+    Equal to the separate-launch path within fp32 summation error, bit-stable across repeats (fixed summation order
+    whichever block comes last), arrival counters back at zero."""
+    torch.manual_seed(B + C2)
+    C = 128
+
+    def leaf(*shape, scale=1.0):
+        t = (torch.randn(*shape, device="cuda") * scale).requires_grad_(True)
+        t._gview = torch.zeros(*shape, device="cuda")           # the flat-gradient-buffer sink TrainState registers
+        return t
+
+    w, bias = leaf(3, 3, C, C, scale=0.05), leaf(C)
+    wn, bn = leaf(C, C, scale=0.1), leaf(C)
+    gamma, beta = leaf(C + C2), leaf(C + C2)
+    x = torch.randn(B, 1024, C, device="cuda", requires_grad=True)
+    skip = torch.randn(B, 1024, C2, device="cuda", requires_grad=True) if C2 else None
+    gy = torch.randn(B, 1024, C + C2, device="cuda")
+    leaves = (w, bias, wn, bn, gamma, beta)
+    names = []
+    real_call = ops.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (names.append(name), real_call(name, *a))[1])
+
+    def run(fused):
+        monkeypatch.setattr(ops, "GN_FUSED_REDUCE", fused)
+        for t in leaves + (x,):
+            t.grad = None
+        for t in leaves:
+            t._gview.zero_()
+        names.clear()
+        h = ops.conv3x3(x, w, bias, None, ops.linear(x, wn, bn))
+        y = ops.group_norm(h, skip, gamma, beta, act=True, keep=0.9, seed=11, offset=0)
+        (y * gy).sum().backward()
+        return [t.grad.clone() for t in leaves] + [x.grad.clone()], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert "mulan_groupnorm_bwd_fused" in got_names and "mulan_colsum_pair" not in got_names
+    assert sum(n == "mulan_colsum" for n in got_names) == 0 < sum(n == "mulan_colsum" for n in ref_names)
+    for a, r, nm in zip(got, ref, ("w", "bias", "wn", "bn", "gamma", "beta", "x")):
+        assert float((a - r).abs().max()) <= 2e-6 * B ** 0.5 * float(r.abs().max()) + 1e-30, nm
+    assert torch.equal(got[1], got[3])                           # the shortcut bias received the very same sums
+    assert bias.grad.data_ptr() == bias._gview.data_ptr()        # written in place, adopted by autograd without a copy
+    for _ in range(3):
+        again, _ = run(True)
+        assert all(torch.equal(a, b) for a, b in zip(again, got))
+    assert int(ops._gn_tickets(x.device).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("B,K1,K2,N", [(2, 128, 128, 128), (3, 128, 0, 128), (1, 256, 256, 256)])
 def test_f16x3_dense_weight_gradient_from_planes(ops, B, K1, K2, N):
     """dw = [x1|x2]^T dy of a per-pixel dense layer from the planes handed on by its forward kernel and by the
@@ -482,6 +533,33 @@ def _heavy(rng, shape, outlier_axis0=True):
         for b in range(shape[0]):
             flat[b, rng.integers(flat.shape[1])] = 1e4 * (1 if rng.random() < 0.5 else -1)
     return x
+
+
+@pytest.mark.parametrize("B,C,N", [(128, 128, 128), (160, 128, 256), (256, 256, 128)])
+def test_conv_v3_with_two_blocks_per_cu_is_exact_and_repeatable(ops, B, C, N):
+    """The 2-blocks-per-CU convolution kernel at launch sizes where blocks really share a CU (more than 256 blocks, the
+    second round runs with raised priority): equal to the one-block-per-CU kernel (same arithmetic, another schedule)
+    to fp32 rounding of the epilogue, and bit-identical from launch to launch.  (Regression: accumulators of the last
+    pixel tile read back before the last matrix instruction had retired -- only in blocks that ran without stalls.)"""
+    torch.manual_seed(B + C + N)
+    lib = ops.lib.load()
+    x = torch.randn(B, 1024, C, device="cuda")
+    w = torch.randn(3, 3, C, N, device="cuda") * 0.05
+    bias, res = torch.randn(N, device="cuda"), torch.randn(B, 1024, N, device="cuda")
+    try:
+        lib.mulan_set_tuning(3, 2)
+        ref, ref_planes = ops.conv3x3_raw(x, w, bias, None, res, planes=True)
+    finally:
+        lib.mulan_set_tuning(3, 0)
+    first = None
+    for _ in range(6):
+        y, planes = ops.conv3x3_raw(x, w, bias, None, res, planes=True)
+        assert torch.equal(planes, ref_planes)
+        assert float((y - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+        first = y.clone() if first is None else first
+        assert torch.equal(y, first)
+        assert np.array_equal(y._absmax[0].cpu().numpy().view(np.float32).max(1),
+                              y.abs().reshape(B, -1).amax(1).cpu().numpy())
 
 
 @pytest.mark.parametrize("C,N", [(128, 128), (256, 128)])

@@ -1,40 +1,38 @@
-"""dev: where the device-to-device copies of one train step come from (aten::copy_ call sites)"""
+#!/usr/bin/env python3
+"""dev: where do the device-to-device copies and tiny torch kernels of one eager train step come from?
+(torch.profiler with stacks; prints the Python call sites of Memcpy DtoD and of aten::add_/copy_/cat kernels)"""
 import collections
 import os
 import sys
-import traceback
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from torch.profiler import ProfilerActivity, profile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
 from mulan_amd.config import load_config_file
 from mulan_amd.experiment import Experiment_VDM
-from torch.utils._python_dispatch import TorchDispatchMode
 
-config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
-config.data.dataset = 'synthetic'
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+config.data.dataset = "synthetic"
+config.training.batch_size_train = 4
+config.training.batch_size_eval = 4
 config.training.substeps = 1
+config.training.hip_graph = False
 exp = Experiment_VDM(config)
-batch = next(exp.train_iter)
-sub = {k: v[0] for k, v in batch.items()}
+batch = {"images": torch.randint(0, 256, (4, 32, 32, 3), dtype=torch.uint8).cuda(),
+         "labels": torch.zeros(4, dtype=torch.int32).cuda(), "conditioning": torch.zeros(4, dtype=torch.uint8).cuda()}
 for _ in range(2):
-    exp.state, _ = exp.train_step(exp._train_rng.fold_in(0), exp.state, sub)
-sites = collections.Counter()
-
-
-class Spy(TorchDispatchMode):
-    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
-        name = str(func)
-        if any(k in name for k in ("copy_", "clone", "contiguous", "cat", "add", "mul", "zero_", "fill_", "maximum")):
-            fr = [f for f in traceback.extract_stack()[:-1] if "mulan_amd" in f.filename][-3:]
-            shp = tuple(args[0].shape) if args and hasattr(args[0], "shape") else ()
-            sites[(name, shp, " < ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(fr)))] += 1
-        return func(*args, **(kwargs or {}))
-
-
-with Spy():
-    exp.state, _ = exp.train_step(exp._train_rng.fold_in(0), exp.state, sub)
+    exp.train_step(exp._train_rng, exp.state, batch)
 torch.cuda.synchronize()
-for (name, shp, where), n in sites.most_common(24):
-    print(n, name, shp, where)
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    exp.train_step(exp._train_rng, exp.state, batch)
+    torch.cuda.synchronize()
+sites = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::add_", "aten::add", "aten::cat", "aten::clone", "aten::contiguous", "aten::zero_",
+                   "aten::fill_", "aten::mul", "aten::sum", "aten::mean", "aten::div", "aten::to", "aten::_to_copy"):
+        st = [s for s in (ev.stack or []) if "mulan_amd" in s or "torch/autograd" in s]
+        sites[(ev.name, st[0] if st else "?")] += 1
+for (name, site), n in sites.most_common(40):
+    print(f"{n:5d}  {name:18s} {site}")
