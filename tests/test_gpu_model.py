@@ -431,7 +431,15 @@ def test_gradient_sink_equals_autograd_accumulation():
         g_ref, _ = grads(False)
     finally:
         _ops.GROUP_COND_PROJ = saved_group
-    assert torch.equal(g_sink, g_ref)
+    # bit-identical, except the bias gradients: with a sink they are summed over the samples inside the GroupNorm
+    # backward kernel, without one by a column-sum launch (another summation order, same fp32 sums)
+    for path, off, shape in st.layout:
+        n = int(np.prod(shape))
+        a, r = g_sink[off:off + n], g_ref[off:off + n]
+        if path[-1] == "bias":
+            assert float((a - r).abs().max()) <= 2e-6 * float(r.abs().max()) + 1e-30, path
+        else:
+            assert torch.equal(a, r), path
     assert aliased >= 0.9 * len(st._leaves), (aliased, len(st._leaves))   # autograd adopted the flat views
 
 
