@@ -762,6 +762,10 @@ def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode():
             config.training.substeps = 1
             config.training.hip_graph = False
             exp = Experiment_VDM(config)
+            with torch.no_grad():   # un-zero the zero-initialised layers: every block contributes, every gradient is live
+                exp.state.flat.add_(0.01 * torch.randn(exp.state.flat.shape, device="cuda",
+                                                       generator=torch.Generator("cuda").manual_seed(0)))
+                exp.state.ema.copy_(exp.state.flat)
             g = torch.Generator().manual_seed(17)
             bpd = []
             for _ in range(steps):
@@ -789,5 +793,5 @@ def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode():
     g16, g32 = one[3].double(), ref[3].double()
     err = float((g16 - g32).norm() / g32.norm())
     print("full-size gradient, f16x3 vs exact-fp32 MFMA kernels: relative L2 error %.3e; bpd %r vs %r" % (err, one[4], ref[4]))
-    assert err < 1e-3                                          # measured: see the printed value
+    assert err < 5e-4                                          # measured: 4e-5
     assert abs(one[4][0] - ref[4][0]) < 1e-4 * abs(ref[4][0])
