@@ -100,7 +100,8 @@ class GraphedStep:
                     packer.refresh()
                 bpd, metrics = exp.loss_fn(state.params, self.inputs, step=0, rng=None, is_train=True, rngs=rngs,
                                            noise=self.noise)
-                bpd.backward()
+                with ops.weight_gradient_stream():
+                    bpd.backward()
                 state.collect_grads()
                 if packer is not None:
                     packer.invalidate()
@@ -268,7 +269,9 @@ class Experiment(abc.ABC):
         with phase("forward"):
             bpd, metrics = self.loss_fn(state.params, batch, step=state.step, rng=rng, is_train=True)
         with phase("backward"):
-            bpd.backward()
+            from . import ops
+            with ops.weight_gradient_stream():       # weight gradients beside the input-gradient chain (ops._on_side)
+                bpd.backward()
             state.collect_grads()
         with phase("all-reduce"):
             self.reducer.finish()

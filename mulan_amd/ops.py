@@ -47,6 +47,71 @@ def _timed(name, flops, launch):
 
 MAX_PARTS = 16
 
+# ----------------------------------------------------------------------------- weight-gradient side stream
+# Nothing in the backward pass waits for a weight gradient (only the all-reduce of its bucket and the optimizer do), while
+# the input-gradient chain is strictly serial.  The weight-gradient kernels therefore go to a second HIP stream: they
+# run beside the GroupNorm / elementwise kernels of the layers in front (HBM-bound, few CUs' worth of work) and fill
+# the ramp-down of every kernel of the main chain, instead of taking their own slot in one queue.  Only gradients with
+# a sink in the flat gradient buffer take this path (nothing on the main stream reads them before side_join()).
+# Scope: `with weight_gradient_stream(): loss.backward()` (the train step does this); outside such a block everything
+# stays on the current stream.
+SIDE_STREAM = _os.environ.get("MULAN_SIDE_STREAM", "1") == "1"
+SIDE_DEPTH = 6                  # side launches whose operands are kept alive before the main stream waits for the oldest
+_SIDE = {"stream": None, "pending": None, "active": False}
+
+
+class weight_gradient_stream:
+    """context manager around a backward pass: weight gradients with a sink run on the side stream; on exit the current
+    stream waits for all of them"""
+
+    def __enter__(self):
+        _SIDE["active"] = SIDE_STREAM
+        return self
+
+    def __exit__(self, *exc):
+        _SIDE["active"] = False
+        side_join()
+        return False
+
+
+def side_stream():
+    """the weight-gradient stream (None until the first launch went there)"""
+    return _SIDE["stream"]
+
+
+def _on_side(launch, keep):
+    """launch() on the side stream, ordered after everything issued so far on the current stream.  `keep`: the tensors
+    the launch reads -- referenced until the current stream has waited for the launch, so that the caching allocator
+    (stream-ordered on the current stream) cannot hand their memory out underneath it."""
+    import collections
+    main = torch.cuda.current_stream()
+    if _SIDE["stream"] is None:
+        _SIDE["stream"], _SIDE["pending"] = torch.cuda.Stream(), collections.deque()
+    side, pending = _SIDE["stream"], _SIDE["pending"]
+    ev = torch.cuda.Event()
+    ev.record(main)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        launch()
+        done = torch.cuda.Event()
+        done.record(side)
+    pending.append((done, keep))
+    while len(pending) > SIDE_DEPTH:
+        main.wait_event(pending.popleft()[0])
+
+
+def side_join():
+    """the current stream waits for every weight gradient issued so far (before the optimizer / a gradient read)"""
+    pending = _SIDE["pending"]
+    if pending:
+        main = torch.cuda.current_stream()
+        while pending:
+            main.wait_event(pending.popleft()[0])
+
+
+def _side_ok(sink):
+    return _SIDE["active"] and sink is not None and sink.is_cuda
+
 
 def absmax_rows(x):
     """[B,16] int32: fp32 bit patterns of 16 partial maxima of |x[b]| (the per-image maximum is the max of a row);
@@ -389,13 +454,23 @@ class Conv3x3Fn(torch.autograd.Function):
                 dy._planes = (dys, dymax, dy._version)
             except (AttributeError, RuntimeError):
                 pass
-            dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
-                                          out=_fresh(gvw) if gvw is not None else None)
+            if _side_ok(gvw):
+                dw, xmax = _fresh(gvw), ctx.xmax
+                _on_side(lambda: conv3x3_wgrad_planes_raw(x, xmax, dys, dymax, B, w.shape[2], N, out=dw),
+                         (x, xmax, dys, dymax))
+            else:
+                dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
+                                              out=_fresh(gvw) if gvw is not None else None)
         else:
             dx = conv3x3_dgrad_raw(dy, w, dymax=dymax, wmax=ctx.wmax) if ctx.needs_input_grad[0] else None
             dw = None
             if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
-                dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None, xmax=ctx.xmax, dymax=dymax)
+                if _side_ok(gvw) and (dymax is None or ctx.xmax is not None):
+                    dw, xmax = _fresh(gvw), ctx.xmax
+                    _on_side(lambda: conv3x3_wgrad_raw(x, dy, out=dw, xmax=xmax, dymax=dymax), (x, dy, xmax, dymax))
+                else:
+                    dw = conv3x3_wgrad_raw(x, dy, out=_fresh(gvw) if gvw is not None else None, xmax=ctx.xmax,
+                                           dymax=dymax)
         dbias = dcb = None
         per_sample = None
         if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):
@@ -538,7 +613,11 @@ class LinearFn(torch.autograd.Function):
                 dx = gemm_raw(dy2, w, M, K, N, transB=True).view(xshape)
         gvw, gvb = ctx.gv
         if ctx.needs_input_grad[1]:
-            dw = gemm_raw(x2, dy2, K, N, M, transA=True, out=_fresh(gvw) if gvw is not None else None)
+            if _side_ok(gvw) and M >= 4096:          # (the small per-sample layers stay in line: nothing to overlap)
+                dw = _fresh(gvw)
+                _on_side(lambda: gemm_raw(x2, dy2, K, N, M, transA=True, out=dw), (x2, dy2))
+            else:
+                dw = gemm_raw(x2, dy2, K, N, M, transA=True, out=_fresh(gvw) if gvw is not None else None)
         if has_bias and ctx.needs_input_grad[2]:
             db = _dense_bias_grad(dy, M, N, gvb)
         dres = dy if (has_res and ctx.needs_input_grad[3]) else None
@@ -676,7 +755,17 @@ class Linear2Fn(torch.autograd.Function):
             dw = _fresh(gvw) if gvw is not None else torch.empty_like(w)
             pl = getattr(dy, "_planes", None)
             if ctx.xs is not None and pl is not None and pl[2] == dy._version and pl[0].numel() == M * N * 4:
-                linear_wgrad_planes_raw(ctx.xs, ctx.xsmax, pl[0], pl[1], M // HW, K1 + K2, N, out=dw)
+                if _side_ok(gvw):
+                    xs, xsmax = ctx.xs, ctx.xsmax
+                    _on_side(lambda: linear_wgrad_planes_raw(xs, xsmax, pl[0], pl[1], M // HW, K1 + K2, N, out=dw),
+                             (xs, xsmax, pl[0], pl[1]))
+                else:
+                    linear_wgrad_planes_raw(ctx.xs, ctx.xsmax, pl[0], pl[1], M // HW, K1 + K2, N, out=dw)
+            elif _side_ok(gvw):
+                def both():
+                    gemm_raw(a1, dy2, K1, N, M, transA=True, out=dw[:K1])
+                    gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])
+                _on_side(both, (a1, a2, dy2))
             else:
                 gemm_raw(a1, dy2, K1, N, M, transA=True, out=dw[:K1])
                 gemm_raw(a2, dy2, K2, N, M, transA=True, out=dw[K1:])

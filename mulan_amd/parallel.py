@@ -102,6 +102,10 @@ class GradReducer:
         self.ready_order.append(bi)
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
+            from . import ops
+            wg = ops.side_stream()          # weight gradients of this bucket may still be in flight on their own stream
+            if wg is not None:
+                self.side.wait_stream(wg)
             with torch.cuda.stream(self.side):
                 self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
