@@ -467,11 +467,22 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     if (s_last) {
       const int ch = tid & 31, sl = tid >> 5;                  // 16 sample lanes x 32 channels
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-      for (int sm = sl; sm < p.B; sm += 16) {
-        const size_t o = (size_t)sm * Ct + c0 + ch;
-        a0 += __hip_atomic_load(p.dgamma_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a1 += __hip_atomic_load(p.dbeta_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (p.dxsum && c0 < p.C1) a2 += __hip_atomic_load(p.dxsum_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool want_x = p.dxsum && c0 < p.C1;
+      // this block is alone on the critical path of the launch: all loads of a batch of 8 samples per lane (128 per
+      // block) are issued before the first one is consumed -- one memory round trip instead of one per sample
+      for (int s0 = sl; s0 < p.B; s0 += 128) {
+        float g[8], bt[8], xs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int sm = s0 + 16 * u;
+          const size_t o = (size_t)(sm < p.B ? sm : s0) * Ct + c0 + ch;
+          g[u] = __hip_atomic_load(p.dgamma_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bt[u] = __hip_atomic_load(p.dbeta_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          xs[u] = want_x ? __hip_atomic_load(p.dxsum_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + 16 * u < p.B) { a0 += g[u]; a1 += bt[u]; a2 += xs[u]; }
       }
       float* outs[3] = {p.dgamma, p.dbeta, c0 < p.C1 ? p.dxsum : nullptr};
       const float vals[3] = {a0, a1, a2};

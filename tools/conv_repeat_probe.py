@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Repeatability probe for the 2-blocks-per-CU convolution kernel: the same launch several times at a batch size where
+blocks share a CU (DBG_B, default 128), each result compared with the one-block-per-CU kernel; prints which blocks /
+waves / pixel rows / couts differ.  (This is how the early accumulator read-back of round 2 was located: only blocks of
+the second dispatch round, last pixel tile, first registers of the last accumulator.)
+Usage: [DBG_B=256] [DBG_ABL=0,..] python tools/dbg_race.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -77,6 +77,18 @@ def main():
             t = timeit(fb, a.reps)
             by = 3.0 * B * 1024 * (C1 + C2) * 4
             print(f"groupnorm_bwd C={C1}+{C2} keep=0.9: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s algorithmic (x, dy -> dx)")
+            # the variants the train step launches: 1-pass kernel with maxima, skip-gradient adds, channel sums
+            m1 = torch.empty(B, 16, device=dev, dtype=torch.int32)
+            m2 = torch.empty(B, 16, device=dev, dtype=torch.int32) if C2 else None
+            a1, a2 = torch.randn_like(x1), (torch.randn_like(x2) if C2 else None)
+            cs = torch.empty(B, C1 + C2, device=dev)
+            for keep, adds in ((1.0, False), (0.9, False), (1.0, True)):
+                fb2 = lambda: call("mulan_groupnorm_bwd", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(g), ptr(b_), ptr(mean),
+                                   ptr(rstd), ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, 1024, 32, 1, keep, 123, 0, 0,
+                                   ptr(m1), ptr(m2), ptr(a1) if adds else None, ptr(a2) if adds else None, ptr(cs), stream())
+                t = timeit(fb2, a.reps)
+                by = (4.0 if adds else 3.0) * B * 1024 * (C1 + C2) * 4
+                print(f"groupnorm_bwd 1-pass C={C1}+{C2} keep={keep} skip-adds={adds}: {t*1e6:8.1f} us  {by/t/1e9:8.1f} GB/s algorithmic")
     if "gemm" in only:
         M = B * 1024
         for (m, n, k, ta, tb, tag) in ((M, 128, 128, 0, 0, "nin/qkv fwd"), (M, 128, 128, 0, 1, "dx"),
