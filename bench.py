@@ -271,6 +271,24 @@ def main():
                     "share_of_step": round(tot_t / (elapsed / a.steps), 3),
                     "other_kernels": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] * 1e3, 2)}
                                       for k, v in per.items() if k != name}}
+    # ---- the dominant kernel without a neighbour: in the step as shipped the weight-gradient kernels run on a second
+    # stream beside it (ops.weight_gradient_stream) and share the chip with it, which stretches its launches; one more
+    # step with that stream off gives the kernel's own duration (profiles/*_serial_kernel_stats.csv is this mode)
+    if rank == 0 and world == 1 and roof is not None and ops.SIDE_STREAM:
+        ops.SIDE_STREAM = False
+        ops.KERNEL_TIMER = []
+        state, _ = exp.train_step(exp._train_rng, state, batches[-1])
+        torch.cuda.synchronize()
+        mine = [(s_, e_, fl) for (nm, s_, e_, fl) in ops.KERNEL_TIMER if nm == roof["kernel"]]
+        ops.KERNEL_TIMER = None
+        ops.SIDE_STREAM = True
+        if mine:
+            t_alone = sum(max(1e-7, s_.elapsed_time(e_) * 1e-3 - roof["event_pair_overhead_us"] * 1e-6) for s_, e_, _ in mine)
+            ach_alone = sum(fl for _, _, fl in mine) / t_alone / 1e12
+            roof["alone"] = {"avg_launch_us": round(t_alone / len(mine) * 1e6, 1), "achieved": round(ach_alone, 2),
+                             "frac": round(ach_alone / roof["peak"], 4),
+                             "note": "same step with the weight-gradient stream off (MULAN_SIDE_STREAM=0): no other "
+                                     "kernel on the chip while this one runs"}
     # ---- the same step with the exact-fp32 MFMA convolution kernels (MULAN_CONV_MODE=f32), for reference
     if world == 1 and ops.CONV_MODE != "f32" and not a.no_f32_mode:
         saved = ops.CONV_MODE
