@@ -795,3 +795,51 @@ def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode():
     print("full-size gradient, f16x3 vs exact-fp32 MFMA kernels: relative L2 error %.3e; bpd %r vs %r" % (err, one[4], ref[4]))
     assert err < 5e-4                                          # measured: 4e-5
     assert abs(one[4][0] - ref[4][0]) < 1e-4 * abs(ref[4][0])
+
+
+def test_weight_gradient_stream_changes_nothing_but_the_schedule(monkeypatch):
+    """ops.weight_gradient_stream (weight gradients on a second HIP stream beside the input-gradient chain): three
+    train steps with and without it end in bit-identical parameters, moments and gradients -- the events that order the
+    two streams and keep the operands alive are complete (SIDE_DEPTH = 1 makes the main stream wait early and often)."""
+    import os
+    from mulan_amd import ops
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(side, depth):
+        monkeypatch.setattr(ops, "SIDE_STREAM", side)
+        monkeypatch.setattr(ops, "SIDE_DEPTH", depth)
+        config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+        config.model.sm_n_layer = 3
+        config.model.forward_n_layer = 1
+        config.data.dataset = "synthetic"
+        config.training.batch_size_train = 16
+        config.training.batch_size_eval = 16
+        config.training.substeps = 1
+        config.training.hip_graph = False
+        exp = Experiment_VDM(config)
+        with torch.no_grad():
+            exp.state.flat.add_(0.01 * torch.randn(exp.state.flat.shape, device="cuda",
+                                                   generator=torch.Generator("cuda").manual_seed(0)))
+        g = torch.Generator().manual_seed(5)
+        launches = []
+        real = ops._on_side
+        monkeypatch.setattr(ops, "_on_side", lambda fn, keep: (launches.append(1), real(fn, keep))[1])
+        for _ in range(3):
+            batch = {"images": torch.randint(0, 256, (16, 32, 32, 3), generator=g, dtype=torch.uint8).cuda(),
+                     "labels": torch.zeros(16, dtype=torch.int32).cuda(),
+                     "conditioning": torch.zeros(16, dtype=torch.uint8).cuda()}
+            exp.train_step(exp._train_rng, exp.state, batch)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops, "_on_side", real)
+        st = exp.state
+        return (st.flat.clone(), st.mu.clone(), st.nu.clone(), st.grad.clone()), len(launches)
+
+    ref, n0 = run(False, 6)
+    assert n0 == 0
+    for depth in (6, 1):
+        got, n = run(True, depth)
+        assert n >= 3 * 2 * (3 + 2 + 4)                       # every ResnetBlock convolution of every step went there
+        for a, b, name in zip(got, ref, ("params", "mu", "nu", "grad")):
+            assert torch.equal(a, b), (depth, name, float((a - b).abs().max()))
