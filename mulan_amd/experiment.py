@@ -205,9 +205,17 @@ class Experiment(abc.ABC):
         self._sample_dummy = None
         self._profile = None                 # profiling.Profile while config.training.profile is set (train_and_evaluate)
         # the lax.scan of the reference (ldm/experiment.py:89-91: `substeps` train steps per host dispatch) becomes a
-        # HIP-graph replay per step (GraphedStep); MULAN_HIP_GRAPH=0 or config.training.hip_graph=False runs eagerly
-        self.hip_graph = (os.environ.get("MULAN_HIP_GRAPH", "1") != "0" and bool(config.training.get("hip_graph", True))
-                          and torch.device(self.device).type == "cuda")
+        # HIP-graph replay per step (GraphedStep).  Default: on for one rank; off with several ranks, where the eager
+        # step overlaps the bucketed gradient all-reduce with the backward pass (a replayed graph ends before the
+        # collectives, which would then run exposed behind it) and the host keeps up at the per-GPU batch sizes of the
+        # shipped configurations.  MULAN_HIP_GRAPH=1 / 0 or config.training.hip_graph=True / False override.
+        env = os.environ.get("MULAN_HIP_GRAPH", "")
+        want = config.training.get("hip_graph", None)
+        if env in ("0", "1"):
+            want = env == "1" and want is not False
+        elif want is None:
+            want = self.world == 1
+        self.hip_graph = bool(want) and torch.device(self.device).type == "cuda"
         self._graphed = None
         self._eager_steps = 0
 

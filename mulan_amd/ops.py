@@ -829,6 +829,13 @@ def _gn_tickets(device):
     return t
 
 
+def reset_tickets():
+    """zeroes the arrival counters (TrainState.zero_grad calls this once per step: a launch that died half-way in an
+    earlier step must not leave a count behind)"""
+    for t in _TICKETS.values():
+        t.zero_()
+
+
 def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     x1, x2 = _c(x1), _c(x2)
     B, C1 = x1.shape[0], x1.shape[-1]

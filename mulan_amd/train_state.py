@@ -186,6 +186,7 @@ class TrainState:
     def zero_grad(self):
         """Call before each backward: clears the flat buffer and detaches stale .grad handles."""
         self.grad.zero_()
+        ops.reset_tickets()
         for leaf in self._leaves:
             leaf.grad = None
         for w, _, _, _ in self._supers:

@@ -444,10 +444,13 @@ def test_gradient_sink_equals_autograd_accumulation():
 
 
 @pytest.mark.timeout(900)
-def test_bench_two_ranks_share_one_gpu():
+@pytest.mark.parametrize("graph", ["", "1"])
+def test_bench_two_ranks_share_one_gpu(graph):
     """bench.py's N > 1 control flow (sharded batches, bucketed side-stream all-reduce, barriers, max-over-ranks timing,
     rank-0 JSON) with two ranks on the one GPU of this box.  RCCL refuses two ranks per device, so the collective
-    backend is gloo over the device tensors here; the calls are the same torch.distributed ones."""
+    backend is gloo over the device tensors here; the calls are the same torch.distributed ones.  graph = "": the
+    multi-rank default (eager step, all-reduce overlapped with backward); "1": MULAN_HIP_GRAPH=1 (replayed backward,
+    collectives and optimizer behind it)."""
     import json
     import os
     import socket
@@ -459,6 +462,9 @@ def test_bench_two_ranks_share_one_gpu():
     port = s.getsockname()[1]
     s.close()
     env = {**os.environ, "MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"}
+    env.pop("MULAN_HIP_GRAPH", None)
+    if graph:
+        env["MULAN_HIP_GRAPH"] = graph
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                         "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8"],
@@ -468,6 +474,7 @@ def test_bench_two_ranks_share_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
     assert out["roofline"] is not None and out["cpu_baseline"] is None
+    assert out["hip_graph"] == bool(graph)
 
 
 @pytest.mark.timeout(900)
