@@ -756,7 +756,7 @@ def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode():
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    B = 128
+    B = int(os.environ.get("MULAN_TEST_FULL_B", "128"))
 
     def run(mode, steps):
         saved = ops.CONV_MODE
