@@ -744,9 +744,11 @@ def test_by_product_hand_overs_fire_in_a_full_depth_step(monkeypatch):
 
 
 @pytest.mark.timeout(900)
-def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode():
-    """BASELINE's configuration at its full size (cifar10-conditioned, 32 + 2 + 33 blocks, batch 128 -- the bench
-    workload, far beyond what the float64 oracle can run): properties that do not need the oracle.  (a) Two fresh runs of
+@pytest.mark.parametrize("config_file", ["cifar10-conditioned.py", "imagenet32.py"])
+def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode(config_file):
+    """BASELINE's configurations at their full size (cifar10-conditioned = the bench workload, and imagenet32 with
+    E = 256; 32 + 2 + 33 blocks, batch 128 -- far beyond what the float64 oracle can run): properties that do not
+    need the oracle.  (a) Two fresh runs of
     two train steps end in bit-identical parameters, moments and gradients -- every kernel at its full launch size is
     free of races (this catches e.g. a block that reads its accumulators too early only when it shares a CU).  (b) The
     gradient of the same step with every convolution on the exact-fp32 MFMA kernels (an independent code path: other
@@ -762,7 +764,7 @@ def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode():
         saved = ops.CONV_MODE
         ops.CONV_MODE = mode
         try:
-            config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+            config = load_config_file(os.path.join(root, "ldm", "configs", os.environ.get("MULAN_TEST_FULL_CONFIG", config_file)))
             config.data.dataset = "synthetic"
             config.training.batch_size_train = B
             config.training.batch_size_eval = B
