@@ -744,8 +744,9 @@ def test_by_product_hand_overs_fire_in_a_full_depth_step(monkeypatch):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("config_file", ["cifar10-conditioned.py", "imagenet32.py"])
-def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode(config_file):
+@pytest.mark.parametrize("config_file,batch", [("cifar10-conditioned.py", 128), ("cifar10-conditioned.py", 200),
+                                               ("imagenet32.py", 128)])
+def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode(config_file, batch):
     """BASELINE's configurations at their full size (cifar10-conditioned = the bench workload, and imagenet32 with
     E = 256; 32 + 2 + 33 blocks, batch 128 -- far beyond what the float64 oracle can run): properties that do not
     need the oracle.  (a) Two fresh runs of
@@ -758,7 +759,7 @@ def test_full_size_step_is_repeatable_and_agrees_with_the_fp32_mfma_mode(config_
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    B = int(os.environ.get("MULAN_TEST_FULL_B", "128"))
+    B = int(os.environ.get("MULAN_TEST_FULL_B", batch))    # (200: 800 tiles per launch, a partial last round of blocks)
 
     def run(mode, steps):
         saved = ops.CONV_MODE
