@@ -82,6 +82,11 @@ int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int
 int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
                             const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, void* xs,
                             unsigned* ymax, int B, int H, int W, int C, int N, mulan_stream_t stream);
+/* The forward convolution fed with the split planes of its input (written by mulan_groupnorm_fwd_planes; xmax = the
+ * [B][16] array that call filled).  H % 8 == 0, C % 32 == 0, N % 128 == 0.  ldm/model_vdm.py:633-656. */
+int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                      const float* bias, const float* cbias, int cbias_mode, const float* res, float* y,
+                                      unsigned* ymax, int B, int H, int W, int C, int N, mulan_stream_t stream);
 
 size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,
@@ -192,6 +197,15 @@ int mulan_groupnorm_fwd_dyn(const float* x1, const float* x2, int C1, int C2, co
                             float* y, float* mean, float* rstd, int B, int hw, int G, float eps, int act, float keep,
                             unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
                             unsigned* ymax, mulan_stream_t stream);
+/* The same with the output written as the split fp16 operand planes of the f16x3 convolution that consumes it instead
+ * of as fp32 ([B][C/16][hw][plane][16], mulan_conv3x3_planes_bytes): the convolution (mulan_conv3x3_fwd_f16x3_planes_in)
+ * then neither splits its input nor stores planes, and its weight-gradient kernel takes the same tensor.  The planes are
+ * scaled by an a-priori bound of |y| -- (sqrt(hw * C / G) max|gamma| + max|beta|) / keep -- which ymax [B][16] receives in
+ * the maxima format.  ldm/model_vdm.py:622-623,632,643-644 (norm + swish + dropout in front of conv1 / conv2). */
+int mulan_groupnorm_fwd_planes(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                               void* yplanes, float* mean, float* rstd, int B, int hw, int G, float eps, int act,
+                               float keep, unsigned long long seed, unsigned long long offset,
+                               const unsigned long long* seed_dev, unsigned* ymax, mulan_stream_t stream);
 int mulan_groupnorm_bwd_dyn(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
                             const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
                             float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,

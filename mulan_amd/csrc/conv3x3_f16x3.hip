@@ -1196,6 +1196,22 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
   MULAN_CHECK_LAUNCH();
 }
 
+// The forward convolution fed with the split planes of its input (mulan_groupnorm_fwd_planes writes them; xmax is the
+// [B][16] array that kernel filled with the bound the planes are scaled with).  Same epilogue and by-products as
+// mulan_conv3x3_fwd_f16x3, minus the plane output -- the input already is one, for the weight-gradient kernel too.
+// Needs the shapes of the two-blocks-per-CU kernel: H % 8 == 0, C % 32 == 0, N % 128 == 0.
+MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp,
+                                                const unsigned* wmax, const float* bias, const float* cbias,
+                                                int cbias_mode, const float* res, float* y, unsigned* ymax, int B, int H,
+                                                int W, int C, int N, hipStream_t stream) {
+  if (W != kW || B <= 0 || C <= 0 || N <= 0 || !xplanes || !xmax || !wmax || !mulan_conv3x3_f16x3_v3_eligible(H, C, N) ||
+      (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts))
+    return (int)hipErrorInvalidValue;
+  ConvArgsH a{nullptr, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
+              cbias ? cbias_mode : 0, g_mulan_debug_buffer, nullptr, ymax, static_cast<const unsigned char*>(xplanes)};
+  return mulan_launch_conv3x3_f16x3_v3(a, stream);
+}
+
 MULAN_API size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N) {
   if (W != kW || H % WG_ROWS != 0) return 0;
   return (size_t)wgrad_splits_h(B, H, C, N) * 9 * C * N * sizeof(float);

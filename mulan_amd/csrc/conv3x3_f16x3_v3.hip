@@ -59,7 +59,10 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const
 
 // ABL: dev-only ablation bits (timing only, results wrong): 1 no LDS fragment reads, 2 no weight loads, 4 no patch
 // fills, 8 no barriers in the main loop
-template <int ABL>
+// PIN: the input arrives as split planes (written by the GroupNorm in front, mulan_groupnorm_fwd_planes): the fill is a
+// 16-byte copy per slot -- no split arithmetic and, above all, no plane stores out of this kernel (they cost 5-13 % of
+// a launch: conv_ab ablation 16 / 32 of round 2).
+template <int ABL, bool PIN = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x), 0, (int)((size_t)p.B * p.H * kW * C * 4), kBufWord3);
+      PIN ? static_cast<void*>(const_cast<unsigned char*>(p.xplanes)) : static_cast<void*>(const_cast<float*>(p.x)), 0,
+      (int)((size_t)p.B * p.H * kW * C * 4), kBufWord3);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(p.wp), 0, 9 * C * N * 4, kBufWord3);
   const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -106,19 +110,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     const bool inb = slot < P3_ROWS * kPW * 4;
     const bool ok = inb & ((unsigned)hh < (unsigned)p.H) & ((unsigned)ww < (unsigned)kW);
     Slot r;
-    const unsigned g = (unsigned)((((b * p.H + hh) * kW + ww) * C + q * 4) * 4);
+    // PIN: unit q = (plane, 8-channel half) of the pixel's 64-byte plane record, copied as it is
+    const unsigned g = PIN ? (unsigned)(((b * nchunks * p.H + hh) * kW + ww) * 64 + q * 16)
+                           : (unsigned)((((b * p.H + hh) * kW + ww) * C + q * 4) * 4);
     r.goff = ok ? g : 0x80000000u;
-    r.ldst = inb ? pix * 32 + q * 8 : P3_DUMMY + (t & 63) * 8;
+    r.ldst = inb ? (PIN ? (q >> 1) * P3_PLANE + pix * 32 + (q & 1) * 16 : pix * 32 + q * 8) : P3_DUMMY + (t & 63) * 8;
     const bool interior = inb & ((unsigned)(prow - 1) < (unsigned)TR3) & ((unsigned)ww < (unsigned)kW);
     const unsigned e = (unsigned)(((hh * kW + ww) * 2) * 32 + q * 8);
     r.emit = interior ? e : 0xffffffffu;
     return r;
   };
   auto load_slot = [&](const Slot& sl, int cc) {
-    return __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, sl.goff, cc * CK * 4, 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, sl.goff, PIN ? cc * (p.H * kW * 64) : cc * CK * 4, 0);
   };
   // split one float4 and store it into patch buffer `pbuf` (byte offset in LDS) and into the plane tensor
   auto store_slot = [&](int pbuf, const Slot& sl, i32x4 raw, int cc) {
+    if (PIN) {
+      *reinterpret_cast<i32x4*>(smem + (sl.ldst >= P3_DUMMY ? sl.ldst & ~15 : pbuf + sl.ldst)) = raw;
+      return;
+    }
     const f32x4 v = __builtin_bit_cast(f32x4, raw);
     f16x4 hi, lo;
 #pragma unroll
@@ -354,6 +364,17 @@ bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N) { return H % TR3 == 0 
 
 int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream) {
   const dim3 grid(a.B * (a.H / TR3), a.N / BN);
+  if (a.xplanes) {   // plane-fed forward convolution
+    static bool configured_pin = false;
+    if (!configured_pin) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);
+      if (e != hipSuccess) return (int)e;
+      configured_pin = true;
+    }
+    hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, true>), grid, dim3(256), SMEM3_B, stream, a);
+    return (int)hipGetLastError();
+  }
 #define MULAN_V3_LAUNCH(ABL)                                                                                          \
   {                                                                                                                   \
     static bool configured = false;                                                                                   \

@@ -52,6 +52,7 @@ struct ConvArgsH {
   unsigned long long* stamps;   // dev-only (mulan_set_debug_buffer)
   unsigned char* xs;            // optional by-product: the split planes of x, [B][C/16][H*W][plane][16] fp16
   unsigned* ymax;               // optional by-product: [B][16] partial maxima of |y| (mulan_absmax_rows format)
+  const unsigned char* xplanes; // optional: the input as split planes (format of xs, scaled by xmax) instead of x
 };
 
 typedef int i32x2 __attribute__((ext_vector_type(2)));

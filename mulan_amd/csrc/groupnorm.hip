@@ -7,6 +7,7 @@
 // written as one tensor with C1+C2 channels, so the concat is never materialised on its own.
 // One 256-thread block owns (sample, 32-channel slab): 1024 px x 128 B, kept in registers.
 #include "common.h"
+#include "f16x3_common.h"
 
 namespace {
 
@@ -22,6 +23,8 @@ struct GnArgs {
   float keep; unsigned long long seed, offset;  // dropout: keep == 1 -> off
   unsigned* ymax;                             // optional [B][16]: partial maxima of |y| (mulan_absmax_rows format)
   const unsigned long long* seed_dev;         // optional: dropout seed = seed ^ seed_dev[0] (stream-ordered: graph replay)
+  unsigned char* yplanes;                     // optional: y as the split fp16 planes of the f16x3 kernels instead of fp32
+                                              // ([B][Ct/16][HW][plane][16], scaled by the bound below); y is not written
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -105,6 +108,23 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   float s1 = 0.f, s2 = 0.f;
 #pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(prow + 32 * i) * ld);
+  // Planes mode: the operand scale must be known before the first element is written, so it comes from a bound instead
+  // of the maximum: |xhat| < sqrt(n - 1) for the n = HW * cpg elements of a group, |silu(z)| <= |z|, dropout scales by
+  // 1 / keep, hence |y| <= (sqrt(n) max|gamma| + max|beta|) / keep for every image of the launch.  Every block takes
+  // the two maxima over all Ct channels itself (same value in all blocks; the loads hide behind the slab's).
+  float bound = 0.f;
+  if (p.yplanes) {
+    float gm = 0.f, bm = 0.f;
+    for (int cc = tid; cc < Ct; cc += 256) { gm = fmaxf(gm, fabsf(p.gamma[cc])); bm = fmaxf(bm, fabsf(p.beta[cc])); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { gm = fmaxf(gm, __shfl_xor(gm, o, 64)); bm = fmaxf(bm, __shfl_xor(bm, o, 64)); }
+    __shared__ float bred[8];
+    if ((tid & 63) == 0) { bred[tid >> 6] = gm; bred[4 + (tid >> 6)] = bm; }
+    __syncthreads();
+    gm = fmaxf(fmaxf(bred[0], bred[1]), fmaxf(bred[2], bred[3]));
+    bm = fmaxf(fmaxf(bred[4], bred[5]), fmaxf(bred[6], bred[7]));
+    bound = (sqrtf((float)(HW * cpg)) * gm + bm) / p.keep;
+  }
   // the dropout mask does not depend on the data: draw it (10 Philox rounds per float4, quarter-rate integer
   // multiplies) while the slab is still in flight, 4 bits per float4
   unsigned mb[NP / 8];
@@ -136,6 +156,10 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   float* dst = p.y + (size_t)b * HW * Ct + c;
   unsigned amax = 0;
   const float inv_keep = 1.f / p.keep;
+  float psc, pinv;
+  f16x3::scale_of(__float_as_uint(bound), psc, pinv);
+  // plane record of pixel px, channels c .. c + 3: [b][c / 16][px][plane][c % 16]
+  unsigned char* pdst = p.yplanes ? p.yplanes + ((size_t)(b * (Ct >> 4) + (c >> 4)) * HW) * 64 + (c & 15) * 2 : nullptr;
   const f32x2 sc_lo = lo2(ga) * rstd, sc_hi = hi2(ga) * rstd;
 #pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) {
@@ -153,10 +177,25 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = apply_bit(o[e], inv_keep, mb[i >> 3], (i & 7) * 4 + e);
     }
-    *reinterpret_cast<f32x4*>(dst + (size_t)px * Ct) = o;
+    if (pdst) {
+      // (the clamp only acts where cancellation in E[x^2] - E[x]^2 left a variance far below the true one: the fp32
+      // path would carry on with those values, fp16 planes must not overflow)
+      f16x3::f16x4 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        f16x3::split2(fminf(fmaxf(o[e], -bound), bound) * psc, h, l);
+        hi[e] = h; lo[e] = l;
+      }
+      *reinterpret_cast<f16x3::f16x4*>(pdst + (size_t)px * 64) = hi;
+      *reinterpret_cast<f16x3::f16x4*>(pdst + (size_t)px * 64 + 32) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(dst + (size_t)px * Ct) = o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+    }
   }
+  if (p.yplanes) amax = __float_as_uint(bound);     // what the planes were scaled with: the consumers' "maximum"
   if (p.ymax) {   // this block's slab is partial maximum number blockIdx.y of image b (unused entries zeroed)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
@@ -517,7 +556,26 @@ MULAN_API int mulan_groupnorm_fwd_dyn(const float* x1, const float* x2, int C1, 
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   if (ymax && Ct / 32 > 16) return (int)hipErrorInvalidValue;
-  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev};
+  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev, nullptr};
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+// The same with the output written as the split fp16 operand planes of the f16x3 convolution that consumes it
+// (mulan_conv3x3_fwd_f16x3_planes_in, and later its weight-gradient kernel) instead of as fp32: the convolution then
+// neither splits its input nor stores planes.  yplanes: mulan_conv3x3_planes_bytes(B, 32, 32, C1 + C2) bytes; ymax
+// [B][16] receives the a-priori bound the planes are scaled with, in the maxima format (see gn_fwd_kernel).
+MULAN_API int mulan_groupnorm_fwd_planes(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                         const float* beta, void* yplanes, float* mean, float* rstd, int B, int hw, int G,
+                                         float eps, int act, float keep, unsigned long long seed,
+                                         unsigned long long offset, const unsigned long long* seed_dev, unsigned* ymax,
+                                         hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !yplanes || !ymax || !(keep > 0.f)) return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || Ct / 32 > 16) return (int)hipErrorInvalidValue;
+  GnArgs a{x1, x2, C1, C2, gamma, beta, nullptr, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev,
+           static_cast<unsigned char*>(yplanes)};
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -161,13 +161,13 @@ class _Drop:
 
 def resnet_block(p, x1, x2, cond, drop):
     """ResnetBlock.__call__ (ldm/model_vdm.py:618-657 / ldm/ldm_unet.py:18-61) on [x1|x2]."""
-    # s1 / s2 alias x1 / x2 for the skip path: their gradients are added inside the GroupNorm backward kernel
-    h, s1, s2 = ops.group_norm_skip(x1, x2, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], act=True)
+    # Each (norm + swish [+ dropout]) -> conv pair is one op: the normalised tensor goes from the GroupNorm kernel to the
+    # convolution as split fp16 planes (ops.GnConv3x3Fn; two ops with an fp32 tensor in between where that does not
+    # apply).  s1 / s2 alias x1 / x2 for the skip path: their gradients are added inside the GroupNorm backward kernel.
     cb = ops.cond_proj(cond, p["cond_proj"]["kernel"])       # [B,E] or [B,1024,E]
-    h = ops.conv3x3(h, p["conv1"]["kernel"], p["conv1"]["bias"], cbias=cb)
+    h, s1, s2 = ops.gn_conv3x3(x1, x2, p["GroupNorm_0"]["scale"], p["GroupNorm_0"]["bias"], p["conv1"]["kernel"],
+                               p["conv1"]["bias"], cbias=cb, act=True, skip=True)
     keep, seed, off = drop.next()
-    h = ops.group_norm(h, None, p["GroupNorm_1"]["scale"], p["GroupNorm_1"]["bias"], act=True, keep=keep, seed=seed,
-                       offset=off)
     if "nin_shortcut" in p:
         if x2 is None:
             res = ops.linear(s1, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
@@ -175,7 +175,8 @@ def resnet_block(p, x1, x2, cond, drop):
             res = ops.linear2(s1, s2, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
     else:
         res = s1
-    return ops.conv3x3(h, p["conv2"]["kernel"], p["conv2"]["bias"], res=res)
+    return ops.gn_conv3x3(h, None, p["GroupNorm_1"]["scale"], p["GroupNorm_1"]["bias"], p["conv2"]["kernel"],
+                          p["conv2"]["bias"], res=res, act=True, keep=keep, seed=seed, offset=off)
 
 
 def attn_block(p, x):

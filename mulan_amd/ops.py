@@ -442,6 +442,14 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        return _conv3x3_backward(ctx, dy)
+
+
+def _conv3x3_backward(ctx, dy):
+    """backward of y = conv3x3(x, w) + bias + cbias + res -> (dx, dw, dbias, dcbias, dres); ctx: the Conv3x3Fn context
+    or the stand-in GnConv3x3Fn builds (saved_tensors = (x or its planes, w), planes, xmax, wmax, has, gv,
+    needs_input_grad[0..4])"""
+    if True:
         x, w = ctx.saved_tensors
         dy = _c(dy)
         has_bias, cb_dim, has_res = ctx.has
@@ -498,6 +506,13 @@ class Conv3x3Fn(torch.autograd.Function):
 
 def conv3x3(x, w, bias=None, cbias=None, res=None):
     return Conv3x3Fn.apply(x, w, bias, cbias, res)
+
+
+class _Ctx:
+    """a plain attribute bag standing in for an autograd context (see GnConv3x3Fn.backward)"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
 
 
 # ----------------------------------------------------------------------------- dense
@@ -954,6 +969,108 @@ def group_norm_skip(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=
     """-> (y, s1, s2): use s1 / s2 instead of x1 / x2 on the skip path of the block (see GroupNormSkipFn)"""
     out = GroupNormSkipFn.apply(x1, x2, gamma, beta, groups, eps, int(act), keep, seed, offset)
     return out if len(out) == 3 else (out[0], out[1], None)
+
+
+GN_CONV_PLANES = _os.environ.get("MULAN_GN_CONV_PLANES", "1") == "1"    # A/B switch: 0 = fp32 hand-over (two ops)
+
+
+def gn_conv_ok(C1, C2, N, groups):
+    """GroupNorm -> 3x3 convolution with the normalised tensor handed over as split fp16 planes (GnConv3x3Fn)"""
+    Ct = C1 + C2
+    cpg = Ct // groups
+    return (GN_CONV_PLANES and CONV_MODE == "f16x3" and Ct % 128 == 0 and N % 128 == 0 and Ct // 32 <= MAX_PARTS and
+            C1 % 32 == 0 and C2 % 32 == 0 and Ct % groups == 0 and cpg % 4 == 0 and 32 % cpg == 0)
+
+
+class GnConv3x3Fn(torch.autograd.Function):
+    """y = conv3x3(dropout(act(GroupNorm([x1|x2]))), w) + bias + cbias + res  (norm1 + swish -> conv1 and norm2 + swish +
+    dropout -> conv2 of the ResnetBlock, ldm/model_vdm.py:622-656) as ONE autograd node, so that the normalised tensor
+    never exists in fp32: the GroupNorm kernel writes it as the split fp16 operand planes of the f16x3 kernels (scaled by
+    an a-priori bound, mulan_groupnorm_fwd_planes), the convolution copies them into LDS (no split, no plane stores out
+    of the MFMA kernel: 5-13 % of a launch) and its weight-gradient kernel reads the same tensor.  With skip=True also
+    returns the aliases s1 (, s2) of x1 (, x2) for the block's skip path, whose gradients are added inside the
+    GroupNorm backward kernel (as GroupNormSkipFn)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, act, keep, seed, offset, skip):
+        x1, x2, w = _c(x1), _c(x2), _c(w)
+        B, C1 = x1.shape[0], x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Ct, N = C1 + C2, w.shape[-1]
+        dev = x1.device
+        ys = torch.empty(B * HW * Ct * 4, device=dev, dtype=torch.uint8)
+        bound = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32)
+        mean = torch.empty((B, groups), device=dev, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        sv, sd = _seed_args(seed)
+        call("mulan_groupnorm_fwd_planes", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(ys), ptr(mean), ptr(rstd),
+             B, HW, groups, float(eps), int(act), float(keep), sv, int(offset), ptr(sd), ptr(bound), stream())
+        wp, wmax = _pack_weights(w, Ct, N, 0)
+        y = torch.empty((B, HW, N), device=dev, dtype=torch.float32)
+        ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
+        mode = 0 if cbias is None else (1 if cbias.dim() == 2 else 2)
+        bias_c, cb_c, res_c = _c(bias), _c(cbias), _c(res)
+        _timed("conv3x3_f16x3_kernel", 2.0 * B * HW * 9 * Ct * N,
+               lambda: call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c),
+                            ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), B, H, W, Ct, N, stream()))
+        if ymax is not None:
+            y._absmax = (ymax, y._version)
+        ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd, ys, w, bound)
+        ctx.meta = (groups, int(act), float(keep), seed, int(offset))
+        ctx.wmax = wmax
+        ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
+        ctx.gv_gn = (_gv(gamma), _gv(beta))
+        ctx.gv_conv = (_gv(w), _gv(bias))
+        bs = getattr(x1, "_bias_sink", None)       # left by the convolution that produced x1
+        ctx.bias_sink = bs[:2] if (bs is not None and bs[2] == x1._version and bs[0].numel() == C1) else None
+        if ctx.gv_conv[1] is not None and ctx.needs_input_grad[5]:
+            twin = getattr(res, "_bias_twin", None) if res is not None else None
+            y._bias_sink = (ctx.gv_conv[1], twin[0] if (twin is not None and twin[1] == res._version) else None, y._version)
+        ctx.skip = bool(skip)
+        ctx.has2 = x2 is not None
+        if not skip:
+            return y
+        s1 = x1.view_as(x1)
+        s2 = x2.view_as(x2) if x2 is not None else None
+        for src, dst in ((x1, s1), (x2, s2)):                 # the maxima a producer left on x stay valid for the alias
+            c = getattr(src, "_absmax", None) if src is not None else None
+            if c is not None and c[1] == src._version:
+                dst._absmax = (c[0], dst._version)
+        return (y, s1, s2) if ctx.has2 else (y, s1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, ds1=None, ds2=None):
+        nones = (None,) * 7
+        if dy is None:     # only the skip path was used downstream
+            return (ds1, ds2) + (None,) * 6 + nones
+        x1, x2, gamma, beta, mean, rstd, ys, w, bound = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        conv = _Ctx(saved_tensors=(ys, w), planes=True, xmax=bound, wmax=ctx.wmax, has=ctx.has, gv=ctx.gv_conv,
+                    needs_input_grad=(True, need[4], need[5], need[6], need[7]))
+        dh, dw, dbias, dcb, dres = _conv3x3_backward(conv, dy)
+        gn = _Ctx(saved_tensors=(x1, x2, gamma, beta, mean, rstd), meta=ctx.meta, gv=ctx.gv_gn,
+                  bias_sink=ctx.bias_sink)
+        dx1, dx2, dgamma, dbeta = _gn_backward(gn, dh, ds1, ds2)
+        return (dx1, dx2, dgamma, dbeta, dw, dbias, dcb, dres) + nones
+
+
+def gn_conv3x3(x1, x2, gamma, beta, w, bias=None, cbias=None, res=None, *, groups=32, eps=1e-6, act=True, keep=1.0,
+               seed=0, offset=0, skip=False):
+    """-> y, or (y, s1, s2) with skip=True.  Falls back to group_norm(_skip) + conv3x3 where the plane hand-over does not
+    apply (other arithmetic modes, channel counts off the 128 grid)."""
+    C1 = x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    if gn_conv_ok(C1, C2, w.shape[-1], groups) and x1.is_cuda:
+        out = GnConv3x3Fn.apply(x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, int(act), keep, seed, offset, skip)
+        if not skip:
+            return out
+        return out if len(out) == 3 else (out[0], out[1], None)
+    if skip:
+        h, s1, s2 = group_norm_skip(x1, x2, gamma, beta, groups=groups, eps=eps, act=act, keep=keep, seed=seed, offset=offset)
+        return conv3x3(h, w, bias, cbias, res), s1, s2
+    return conv3x3(group_norm(x1, x2, gamma, beta, groups=groups, eps=eps, act=act, keep=keep, seed=seed, offset=offset),
+                   w, bias, cbias, res)
 
 
 # ----------------------------------------------------------------------------- attention core

@@ -673,3 +673,84 @@ def test_attention_dual_pack_equals_the_generic_packs(ops):
     assert torch.equal(xt, ops._pack_batched(x, True, m)) and torch.equal(xn, ops._pack_batched(x, False, m))
     only_t, none = ops._attn_packs(x, m, True, False)
     assert none is None and torch.equal(only_t, xt)
+
+
+@pytest.mark.parametrize("B,C1,C2,N,keep,with_res", [(3, 128, 0, 128, 1.0, False), (2, 128, 128, 128, 1.0, True),
+                                                     (5, 128, 0, 256, 0.9, True), (2, 256, 256, 256, 0.9, False)])
+def test_gn_conv_plane_hand_over_matches_the_two_op_path(ops, monkeypatch, B, C1, C2, N, keep, with_res):
+    """ops.gn_conv3x3: GroupNorm -> 3x3 convolution as one node, the normalised tensor handed over as split fp16 planes
+    under an a-priori bound (mulan_groupnorm_fwd_planes -> mulan_conv3x3_fwd_f16x3_planes_in -> plane-fed weight
+    gradient) against the two-op path with an fp32 tensor in between (per-image scale from the true maximum): output
+    and every gradient (inputs incl. the skip aliases, gamma, beta, kernel, bias, FiLM bias, residual) agree to the
+    split's rounding; the bound really bounds; no plane store leaves the convolution."""
+    torch.manual_seed(B + C1 + C2 + N)
+    Ct = C1 + C2
+    mk = lambda *s, scale=1.0: (torch.randn(*s, device="cuda") * scale).requires_grad_(True)
+    x1 = mk(B, 1024, C1, scale=3.0)
+    x2 = mk(B, 1024, C2) if C2 else None
+    gamma, beta = mk(Ct), mk(Ct, scale=0.3)
+    w, bias, cb = mk(3, 3, Ct, N, scale=0.03), mk(N), mk(B, N)
+    res = mk(B, 1024, N) if with_res else None
+    gy, g1 = torch.randn(B, 1024, N, device="cuda"), torch.randn(B, 1024, C1, device="cuda")
+    g2 = torch.randn(B, 1024, C2, device="cuda") if C2 else None
+    leaves = [t for t in (x1, x2, gamma, beta, w, bias, cb, res) if t is not None]
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    def run(planes):
+        monkeypatch.setattr(ops, "GN_CONV_PLANES", planes)
+        for t in leaves:
+            t.grad = None
+        names.clear()
+        y, s1, s2 = ops.gn_conv3x3(x1, x2, gamma, beta, w, bias, cbias=cb, res=res, act=True, keep=keep, seed=7, offset=32,
+                                   skip=True)
+        loss = (y * gy).sum() + (s1 * g1).sum() + ((s2 * g2).sum() if C2 else 0)
+        loss.backward()
+        return [y.detach().clone()] + [t.grad.clone() for t in leaves], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert "mulan_groupnorm_fwd_planes" in got_names and "mulan_conv3x3_fwd_f16x3_planes_in" in got_names
+    assert "mulan_groupnorm_fwd_dyn" not in got_names and "mulan_groupnorm_fwd_planes" not in ref_names
+    assert got_names.count("mulan_conv3x3_fwd_f16x3") == 1          # only the input-gradient launch is left on it
+    labels = ["y"] + [n for n, t in zip(("x1", "x2", "gamma", "beta", "w", "bias", "cb", "res"),
+                                         (x1, x2, gamma, beta, w, bias, cb, res)) if t is not None]
+    for a, r, nm in zip(got, ref, labels):
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-30, (nm, float((a - r).abs().max()), float(r.abs().max()))
+
+
+def test_gn_planes_bound_and_precision(ops):
+    """mulan_groupnorm_fwd_planes: the planes decode (hi + lo) / scale to the fp32 output of the ordinary kernel within
+    the split's 2^-22, the scale comes from a bound that really bounds (heavy-tailed input: |xhat| up to ~40 of the
+    possible 64), and the plane-fed convolution is as close to float64 as the fp32-input one."""
+    torch.manual_seed(4)
+    B, C, N = 3, 128, 128
+    x = torch.randn(B, 1024, C, device="cuda")
+    x[0, 17, 5] = 400.0                                           # one element far out: a large |xhat| in its group
+    x[1] *= 1e-3
+    gamma, beta = torch.randn(C, device="cuda") * 2, torch.randn(C, device="cuda")
+    y = ops.group_norm(x, None, gamma, beta, act=True).detach()
+    ys = torch.empty(B * 1024 * C * 4, device="cuda", dtype=torch.uint8)
+    bound = torch.empty(B, 16, device="cuda", dtype=torch.int32)
+    mean, rstd = torch.empty(B, 32, device="cuda"), torch.empty(B, 32, device="cuda")
+    ops.call("mulan_groupnorm_fwd_planes", ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta), ops.ptr(ys), ops.ptr(mean),
+             ops.ptr(rstd), B, 1024, 32, 1e-6, 1, 1.0, 0, 0, None, ops.ptr(bound), ops.stream())
+    bnd = bound.cpu().numpy().view(np.float32).max(1)
+    want = (np.sqrt(1024 * 4) * float(gamma.abs().max()) + float(beta.abs().max()))
+    assert np.allclose(bnd, want, rtol=1e-6) and float(y.abs().max()) <= want
+    e = int(np.frexp(bnd[0])[1]) - 1 + 127                        # biased exponent of the bound -> scale 2^(140 - e)
+    planes = ys.view(torch.float16).view(B, C // 16, 1024, 2, 16).float()
+    dec = (planes[:, :, :, 0] + planes[:, :, :, 1]).permute(0, 2, 1, 3).reshape(B, 1024, C) * 2.0 ** (e - 140)
+    assert float((dec - y).abs().max()) <= 2.0 ** -21 * float(y.abs().max())
+    w = torch.randn(3, 3, C, N, device="cuda") * 0.05
+    out = torch.empty(B, 1024, N, device="cuda")
+    wp, wmax = ops._pack_weights(w, C, N, 0)
+    ops.call("mulan_conv3x3_fwd_f16x3_planes_in", ops.ptr(ys), ops.ptr(bound), ops.ptr(wp), ops.ptr(wmax), None, None, 0,
+             None, ops.ptr(out), None, B, 32, 32, C, N, ops.stream())
+    ref = torch.nn.functional.conv2d(y.double().view(B, 32, 32, C).permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1),
+                                     padding=1).permute(0, 2, 3, 1).reshape(B, 1024, N)
+    two_op = ops.conv3x3_raw(y, w)
+    mag = float(ref.abs().max())
+    e_planes, e_two = float((out.double() - ref).abs().max()) / mag, float((two_op.double() - ref).abs().max()) / mag
+    assert e_planes <= 2.0 * e_two + 2e-7, (e_planes, e_two)
