@@ -232,7 +232,16 @@ def main():
             d[1] += fl
             d[2] += 1
         if per:
-            name, (tot_t, tot_f, n) = max(per.items(), key=lambda kv: kv[1][0])
+            # The dominant kernel: one kernel source can be launched as several instantiations (the f16x3 convolution:
+            # "conv3x3_f16x3_kernel" = conv3x3_f16x3_v3_kernel<0, false> in a rocprofv3 trace -- fp32 input, the input
+            # gradients of the step -- and "conv3x3_f16x3_kernel<planes_in>" = <0, true>, the plane-fed forward
+            # launches); they are summed for the choice and for the roofline, and listed one by one under "symbols".
+            fam = {}
+            for lab, (t_, f_, n_) in per.items():
+                d = fam.setdefault(lab.split("<")[0], [0.0, 0.0, 0])
+                d[0] += t_; d[1] += f_; d[2] += n_
+            name, (tot_t, tot_f, n) = max(fam.items(), key=lambda kv: kv[1][0])
+            labels = [lab for lab in per if lab.split("<")[0] == name]
             ach = tot_f / tot_t / 1e12
             passes = 6 if "bf16x6" in name else (3 if "f16x3" in name else 0)
             bf = passes > 0
@@ -241,25 +250,30 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / passes if bf else PEAK_F32_MFMA_TFLOPS
             # HBM bytes per launch: from the committed rocprofv3 PMC passes of this kernel (separate FETCH_SIZE /
             # WRITE_SIZE runs per launch shape, gfx950 corrections applied; tools/pmc_conv.py), not re-measured inside
-            # the bench: every launch of the step is priced with the bytes of its shape (by its FLOP count: 128->128
-            # vs the two 256 <-> 128 shapes) and `traffic` is the mean over the step's launches
+            # the bench: every launch of the step is priced with the bytes of its shape (instantiation, and 128->128
+            # vs the 256 <-> 128 shapes by its FLOP count) and `traffic` is the mean over the step's launches
             traffic, pmc = a.traffic, None
             pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_conv3x3_f16x3.json")
-            if "f16x3" in name and os.path.exists(pmc_file) and int(config.model.sm_n_embd) == 128:
+            if name == "conv3x3_f16x3_kernel" and os.path.exists(pmc_file) and int(config.model.sm_n_embd) == 128:
                 with open(pmc_file) as f:
                     pj = json.load(f)["shapes"]
                 scale = B / 128.0
-                small = pj["fwd_128_128_res"]["hbm_bytes_per_launch"]
-                big = 0.5 * (pj["fwd_256_128"]["hbm_bytes_per_launch"] + pj["dgrad_128_256"]["hbm_bytes_per_launch"])
                 fl_small = 2.0 * B * 1024 * 9 * 128 * 128
-                byts = [scale * (small if fl < 1.5 * fl_small else big) for (nm, _, _, fl) in recs if nm == name]
-                pmc = {"source": "profiles/r02_pmc_conv3x3_f16x3.json (B = 128; shapes 128->128 +residual, 256->128, "
-                                 "128->256 input gradient; scaled by batch / 128)",
-                       "hbm_bytes_per_launch_by_shape": {k: v["hbm_bytes_per_launch"] for k, v in pj.items()},
-                       "mfma_util_by_shape": {k: round(v["mfma_util"], 4) for k, v in pj.items()},
-                       "traffic_over_algorithmic_by_shape": {k: round(v["traffic_over_algorithmic"], 3) for k, v in pj.items()}}
+                hb = lambda k: pj[k]["hbm_bytes_per_launch"]
+                table = {"conv3x3_f16x3_kernel<planes_in>": (0.5 * (hb("pin_fwd_128_128_res") + hb("pin_fwd_128_128_film")),
+                                                             hb("pin_fwd_256_128_film")),
+                         "conv3x3_f16x3_kernel": (hb("dgrad_128_128"), hb("dgrad_128_256"))}
+                byts = [scale * table[nm][0 if fl < 1.5 * fl_small else 1] for (nm, _, _, fl) in recs if nm in table]
+                used = ("dgrad_128_128", "dgrad_128_256", "pin_fwd_128_128_res", "pin_fwd_128_128_film", "pin_fwd_256_128_film")
+                pmc = {"source": "profiles/r02_pmc_conv3x3_f16x3.json (B = 128, one entry per instantiation and launch "
+                                 "shape; scaled by batch / 128)",
+                       "hbm_bytes_per_launch_by_shape": {k: pj[k]["hbm_bytes_per_launch"] for k in used},
+                       "mfma_util_by_shape": {k: round(pj[k]["mfma_util"], 4) for k in used},
+                       "traffic_over_algorithmic_by_shape": {k: round(pj[k]["traffic_over_algorithmic"], 3) for k in used}}
                 if traffic is None and byts:
                     traffic = sum(byts) / len(byts)
+            symbols = {lab: {"launches_per_step": per[lab][2], "avg_launch_us": round(per[lab][0] / per[lab][2] * 1e6, 1),
+                             "tflops": round(per[lab][1] / per[lab][0] / 1e12, 1)} for lab in labels}
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": round(peak, 1),
                     "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "pmc": pmc,
                     "peak_note": (f"dense 16-bit MFMA 2500 TFLOP/s / {passes} passes (split operands, fp32-equivalent "
@@ -269,8 +283,9 @@ def main():
                     "event_pair_overhead_us": round(ev_overhead * 1e6, 2),
                     "avg_gflop_per_launch": round(tot_f / n / 1e9, 3),
                     "share_of_step": round(tot_t / (elapsed / a.steps), 3),
+                    "symbols": symbols,
                     "other_kernels": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] * 1e3, 2)}
-                                      for k, v in per.items() if k != name}}
+                                      for k, v in per.items() if k not in labels}}
     # ---- the dominant kernel without a neighbour: in the step as shipped the weight-gradient kernels run on a second
     # stream beside it (ops.weight_gradient_stream) and share the chip with it, which stretches its launches; one more
     # step with that stream off gives the kernel's own duration (profiles/*_serial_kernel_stats.csv is this mode)
@@ -279,7 +294,7 @@ def main():
         ops.KERNEL_TIMER = []
         state, _ = exp.train_step(exp._train_rng, state, batches[-1])
         torch.cuda.synchronize()
-        mine = [(s_, e_, fl) for (nm, s_, e_, fl) in ops.KERNEL_TIMER if nm == roof["kernel"]]
+        mine = [(s_, e_, fl) for (nm, s_, e_, fl) in ops.KERNEL_TIMER if nm.split("<")[0] == roof["kernel"]]
         ops.KERNEL_TIMER = None
         ops.SIDE_STREAM = True
         if mine:

@@ -1010,7 +1010,7 @@ class GnConv3x3Fn(torch.autograd.Function):
         ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
         mode = 0 if cbias is None else (1 if cbias.dim() == 2 else 2)
         bias_c, cb_c, res_c = _c(bias), _c(cbias), _c(res)
-        _timed("conv3x3_f16x3_kernel", 2.0 * B * HW * 9 * Ct * N,
+        _timed("conv3x3_f16x3_kernel<planes_in>", 2.0 * B * HW * 9 * Ct * N,
                lambda: call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c),
                             ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), B, H, W, Ct, N, stream()))
         if ymax is not None:

@@ -6,8 +6,9 @@ launch shapes at B = 128, a few launches each, for rocprofv3 --pmc passes (one c
   rocprofv3 --kernel-trace --pmc WRITE_SIZE ...        (separate passes: TCC has 4 slots, FETCH_SIZE takes 3)
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ...
 
-Shapes (grid sizes tell them apart in the trace): 128->128 with residual (grid 512 x 1, 6 launches), 256->128 up-block
-conv1 (512 x 1 with C = 256: 5 launches), 128->256 input gradient of the same layer (512 x 2: 4 launches).
+Shapes (launch order and counts tell them apart inside a kernel symbol): the fp32-input kernel (input gradients of the
+train step; forward where no GroupNorm is in front) 128->128 with residual, 256->128, 128->256 and 128->128 input
+gradients; the plane-fed forward kernel 128->128 + residual, 128->128 + FiLM bias, 256->128 + FiLM bias.
 `python3 tools/pmc_conv.py --parse <dir>` turns the three counter_collection CSVs found under <dir> into the JSON that
 bench.py reads (profiles/r02_pmc_conv3x3_f16x3.json)."""
 import csv
@@ -19,34 +20,56 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHAPES = [  # name, C, N, residual, launches (distinct counts identify the shape in the trace)
-    ("fwd_128_128_res", 128, 128, True, 6),
-    ("fwd_256_128", 256, 128, False, 5),
-    ("dgrad_128_256", 128, 256, False, 4),
+SHAPES = [  # name, kernel (fp32 input / plane-fed), C, N, residual, launches (distinct counts identify the shape in the trace)
+    ("fwd_128_128_res", "fp32", 128, 128, True, 6),
+    ("fwd_256_128", "fp32", 256, 128, False, 5),
+    ("dgrad_128_256", "fp32", 128, 256, False, 4),
+    ("dgrad_128_128", "fp32", 128, 128, False, 7),
+    ("pin_fwd_128_128_res", "pin", 128, 128, True, 6),
+    ("pin_fwd_128_128_film", "pin", 128, 128, False, 5),
+    ("pin_fwd_256_128_film", "pin", 256, 128, False, 4),
 ]
+SYMBOL = {"fp32": "conv3x3_f16x3_v3_kernel<0, false>", "pin": "conv3x3_f16x3_v3_kernel<0, true>"}
 B = 128
 
 
-def algorithmic_bytes(C, N, res):
-    """per launch: x with the vertical halo of the 8-row tiles (10/8), y, planes of x, residual"""
+def algorithmic_bytes(kind, C, N, res):
+    """per launch: x (fp32, or its planes: same bytes) with the vertical halo of the 8-row tiles (10/8), y, the planes
+    of x written as a by-product (fp32-input kernel only), residual"""
     px = B * 1024
-    return {"x_with_halo": px * C * 4 * 10 / 8 * (N // 128), "y": px * N * 4, "planes": px * C * 4,
+    return {"x_with_halo": px * C * 4 * 10 / 8 * (N // 128), "y": px * N * 4, "planes": px * C * 4 if kind == "fp32" else 0,
             "residual": px * N * 4 if res else 0}
 
 
 def run():
     import torch
     from mulan_amd import ops
+    from mulan_amd.lib import call, ptr, stream
     ops.lib.load()
     torch.manual_seed(0)
-    for name, C, N, has_res, n in SHAPES:
+    for name, kind, C, N, has_res, n in SHAPES:
         x, w = torch.randn(B, 1024, C, device="cuda"), torch.randn(3, 3, C, N, device="cuda") * 0.05
-        bias = torch.randn(N, device="cuda") if has_res else None
-        cb = torch.randn(B, N, device="cuda") if has_res else None
+        bias = torch.randn(N, device="cuda") if (has_res or kind == "pin") else None
+        cb = torch.randn(B, N, device="cuda") if (has_res or kind == "pin") else None
         res = torch.randn(B, 1024, N, device="cuda") if has_res else None
-        xmax, wmax = ops.absmax_rows(x), ops.absmax_rows(w.view(1, -1))
-        for _ in range(n):
-            y, xs = ops.conv3x3_raw(x, w, bias, cb, res, xmax=xmax, planes=True, wmax=wmax)
+        wmax = ops.absmax_rows(w.view(1, -1))
+        if kind == "fp32":
+            xmax = ops.absmax_rows(x)
+            for _ in range(n):
+                y, xs = ops.conv3x3_raw(x, w, bias, cb, res, xmax=xmax, planes=True, wmax=wmax)
+        else:           # the planes come from the GroupNorm kernel, as in the train step
+            g, b_ = torch.randn(C, device="cuda"), torch.randn(C, device="cuda")
+            ys = torch.empty(B * 1024 * C * 4, device="cuda", dtype=torch.uint8)
+            bound = torch.empty(B, 16, device="cuda", dtype=torch.int32)
+            mean, rstd = torch.empty(B, 32, device="cuda"), torch.empty(B, 32, device="cuda")
+            call("mulan_groupnorm_fwd_planes", ptr(x), None, C, 0, ptr(g), ptr(b_), ptr(ys), ptr(mean), ptr(rstd), B, 1024,
+                 32, 1e-6, 1, 1.0, 0, 0, None, ptr(bound), stream())
+            wp, _ = ops._pack_weights(w, C, N, 0, wmax)
+            y = torch.empty(B, 1024, N, device="cuda")
+            ym = torch.empty(B, 16, device="cuda", dtype=torch.int32)
+            for _ in range(n):
+                call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias), ptr(cb), 1,
+                     ptr(res), ptr(y), ptr(ym), B, 32, 32, C, N, stream())
         torch.cuda.synchronize()
         print("done", name, float(y[0, 0, 0]))
 
@@ -58,40 +81,43 @@ def parse(d):
             rows += [r for r in csv.DictReader(fh) if "conv3x3_f16x3_v3_kernel" in r["Kernel_Name"]]
     if not rows:
         raise SystemExit(f"no conv3x3_f16x3_v3_kernel rows under {d}")
-    # group dispatches by (C inferred from launch count and grid): key = (Grid_Size, Counter) -> values per dispatch
-    by = {}
-    for r in rows:
-        by.setdefault((int(r["Grid_Size"]), r["Counter_Name"]), []).append(
-            (int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-    out = {"kernel": "conv3x3_f16x3_v3_kernel", "batch": B,
+    out = {"kernel": "conv3x3_f16x3_v3_kernel (<0, false>: fp32 input, splits and stores planes; <0, true>: plane-fed)",
+           "batch": B,
            "corrections": "FETCH_SIZE x 1024 x 2 (gfx950 counts the 128-B requests of 16-B-per-lane loads as 64 B); "
-                          "WRITE_SIZE x 1024 exact for 16-B-per-lane stores; one counter group per rocprofv3 pass",
+                          "WRITE_SIZE x 1024 exact for 16-B-per-lane stores; one counter group per rocprofv3 pass; "
+                          "dispatches of one kernel symbol in launch order, the first of each shape dropped as cold",
            "shapes": {}}
-    # 128->128 and 256->128 share grid 512 x 256 threads = 131072; split them by launch order inside each pass
-    for name, C, N, has_res, n in SHAPES:
-        grid = B * 4 * (N // 128) * 256
-        ent = {"C": C, "N": N, "residual": has_res, "launches_profiled": n}
-        for counter in sorted({k[1] for k in by if k[0] == grid}):
-            vals = sorted(by[(grid, counter)])
-            if grid == B * 4 * 256:                 # two shapes on this grid: the first 6 dispatches are 128->128
-                vals = vals[:6] if C == 128 else vals[6:11]
-            if not vals:
+    for kind, sym in SYMBOL.items():
+        by = {}
+        for r in rows:
+            if sym in r["Kernel_Name"]:
+                by.setdefault(r["Counter_Name"], []).append(
+                    (int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        start = 0
+        for name, k2, C, N, has_res, n in SHAPES:
+            if k2 != kind:
                 continue
-            ent[counter] = sum(v for _, v, _ in vals[1:]) / max(1, len(vals) - 1)         # skip the first (cold) launch
-            ent["avg_duration_us"] = sum(t for _, _, t in vals[1:]) / max(1, len(vals) - 1) / 1e3
-        if "FETCH_SIZE" in ent and "WRITE_SIZE" in ent:
-            ent["hbm_read_bytes_per_launch"] = ent["FETCH_SIZE"] * 1024 * 2
-            ent["hbm_write_bytes_per_launch"] = ent["WRITE_SIZE"] * 1024
-            ent["hbm_bytes_per_launch"] = ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
-            ent["algorithmic_bytes_per_launch"] = algorithmic_bytes(C, N, has_res)
-            ent["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / sum(ent["algorithmic_bytes_per_launch"].values())
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in ent and "GRBM_GUI_ACTIVE" in ent:
-            mfmas = 3.0 * B * 1024 * N * 9 * C / (16 * 16 * 32)              # v_mfma_f32_16x16x32_f16 instructions
-            ent["mfma_instructions"] = mfmas
-            ent["clock_GHz_from_GRBM"] = ent["GRBM_GUI_ACTIVE"] / 8 / (ent["avg_duration_us"] * 1e3)
-            # SQ_VALU_MFMA_BUSY_CYCLES counts 16 cycles per 16x16x32 MFMA; 1024 SIMDs
-            ent["mfma_util"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / (ent["GRBM_GUI_ACTIVE"] / 8 * 1024)
-        out["shapes"][name] = ent
+            ent = {"kernel": sym, "C": C, "N": N, "residual": has_res, "launches_profiled": n}
+            for counter, vals in by.items():
+                vals = sorted(vals)[start:start + n][1:]
+                if not vals:
+                    continue
+                ent[counter] = sum(v for _, v, _ in vals) / len(vals)
+                ent["avg_duration_us"] = sum(t for _, _, t in vals) / len(vals) / 1e3
+            start += n
+            if "FETCH_SIZE" in ent and "WRITE_SIZE" in ent:
+                ent["hbm_read_bytes_per_launch"] = ent["FETCH_SIZE"] * 1024 * 2
+                ent["hbm_write_bytes_per_launch"] = ent["WRITE_SIZE"] * 1024
+                ent["hbm_bytes_per_launch"] = ent["hbm_read_bytes_per_launch"] + ent["hbm_write_bytes_per_launch"]
+                ent["algorithmic_bytes_per_launch"] = algorithmic_bytes(kind, C, N, has_res)
+                ent["traffic_over_algorithmic"] = ent["hbm_bytes_per_launch"] / sum(ent["algorithmic_bytes_per_launch"].values())
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in ent and "GRBM_GUI_ACTIVE" in ent:
+                mfmas = 3.0 * B * 1024 * N * 9 * C / (16 * 16 * 32)              # v_mfma_f32_16x16x32_f16 instructions
+                ent["mfma_instructions"] = mfmas
+                ent["clock_GHz_from_GRBM"] = ent["GRBM_GUI_ACTIVE"] / 8 / (ent["avg_duration_us"] * 1e3)
+                # SQ_VALU_MFMA_BUSY_CYCLES counts 16 cycles per 16x16x32 MFMA; 1024 SIMDs
+                ent["mfma_util"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / (ent["GRBM_GUI_ACTIVE"] / 8 * 1024)
+            out["shapes"][name] = ent
     print(json.dumps(out, indent=1))
 
 
