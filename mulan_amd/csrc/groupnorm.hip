@@ -180,12 +180,15 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
     if (pdst) {
       // (the clamp only acts where cancellation in E[x^2] - E[x]^2 left a variance far below the true one: the fp32
       // path would carry on with those values, fp16 planes must not overflow)
+      // two-wide: v_pk_mul / v_cvt_pk_f16_f32 / v_pk_add, the clamp is one v_med3 per element (same values as split2)
+      typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
       f16x3::f16x4 hi, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        _Float16 h, l;
-        f16x3::split2(fminf(fmaxf(o[e], -bound), bound) * psc, h, l);
-        hi[e] = h; lo[e] = l;
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 vs = f32x2{__builtin_amdgcn_fmed3f(o[e], -bound, bound), __builtin_amdgcn_fmed3f(o[e + 1], -bound, bound)} * psc;
+        const f16x2v h = __builtin_convertvector(vs, f16x2v);
+        const f16x2v l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x2), f16x2v);
+        hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
       }
       *reinterpret_cast<f16x3::f16x4*>(pdst + (size_t)px * 64) = hi;
       *reinterpret_cast<f16x3::f16x4*>(pdst + (size_t)px * 64 + 32) = lo;
