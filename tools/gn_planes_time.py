@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""GroupNorm forward at B = 128: planes output (mulan_groupnorm_fwd_planes) vs fp32 output, three variants."""
 import torch, sys
 sys.path.insert(0, ".")
 from mulan_amd import ops
