@@ -1029,7 +1029,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 int wgrad_splits_p(int B, int H, int C, int N) {   // 3 kh blocks per (tile, pixel range); S % 8 == 0 keeps them on one XCD
   const int tiles = (C / WG3_T) * (N / WG3_T);
   const int pairs = B * (H / WG_ROWS);
-  const int target = g_mulan_tune[1] > 0 ? g_mulan_tune[1] : 240;
+  // 240 blocks when the launch has the chip to itself; tune[9] = 1 (set by the caller while the launch shares the chip
+  // with another stream's kernels -- the train step's weight-gradient stream): 120 for the one- and two-tile shapes, so
+  // that the other stream keeps half of the CUs and both run side by side (a block owns its CU); four tiles and more
+  // keep 240 (measured: E = 256 is slower with fewer).  tune[1] > 0: explicit target (dev).
+  int target = g_mulan_tune[9] == 1 && tiles <= 2 ? 120 : 240;
+  if (g_mulan_tune[1] > 0) target = g_mulan_tune[1];
   int S = target / (3 * tiles);
   if (S >= 8 && g_mulan_tune[6] != 1) S &= ~7;      // tune[6] = 1: dev switch, no XCD alignment
   if (S < 1) S = 1;

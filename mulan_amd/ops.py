@@ -57,6 +57,12 @@ MAX_PARTS = 16
 # stays on the current stream.
 SIDE_STREAM = _os.environ.get("MULAN_SIDE_STREAM", "1") == "1"
 SIDE_DEPTH = 6                  # side launches whose operands are kept alive before the main stream waits for the oldest
+# While the weight-gradient launches share the chip with the input-gradient chain they aim for 120 blocks instead of
+# 240 (library knob 9, see wgrad_splits_p): a weight-gradient block owns its CU, so 240 of them leave 16 CUs to the
+# main stream; with 120 the launch takes about as long as the main stream's kernels of the same layer (GroupNorm
+# backward + input-gradient convolution) and both streams keep running side by side: -2.9 % per step (scan 96 ... 240,
+# DESIGN 3.2).  MULAN_SIDE_WGRAD_SHARE=0 keeps 240.
+SIDE_WGRAD_SHARE = _os.environ.get("MULAN_SIDE_WGRAD_SHARE", "1") == "1"
 _SIDE = {"stream": None, "pending": None, "active": False}
 
 
@@ -66,9 +72,13 @@ class weight_gradient_stream:
 
     def __enter__(self):
         _SIDE["active"] = SIDE_STREAM
+        if SIDE_STREAM and SIDE_WGRAD_SHARE:
+            call("mulan_set_tuning", 9, 1)
         return self
 
     def __exit__(self, *exc):
+        if _SIDE["active"] and SIDE_WGRAD_SHARE:
+            call("mulan_set_tuning", 9, 0)
         _SIDE["active"] = False
         side_join()
         return False

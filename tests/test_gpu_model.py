@@ -817,9 +817,10 @@ def test_weight_gradient_stream_changes_nothing_but_the_schedule(monkeypatch):
     from mulan_amd.experiment import Experiment_VDM
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-    def run(side, depth):
+    def run(side, depth, share=False):
         monkeypatch.setattr(ops, "SIDE_STREAM", side)
         monkeypatch.setattr(ops, "SIDE_DEPTH", depth)
+        monkeypatch.setattr(ops, "SIDE_WGRAD_SHARE", share)     # (True: other split counts, i.e. another summation order)
         config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
         config.model.sm_n_layer = 3
         config.model.forward_n_layer = 1
@@ -853,3 +854,7 @@ def test_weight_gradient_stream_changes_nothing_but_the_schedule(monkeypatch):
         assert n >= 3 * 2 * (3 + 2 + 4)                       # every ResnetBlock convolution of every step went there
         for a, b, name in zip(got, ref, ("params", "mu", "nu", "grad")):
             assert torch.equal(a, b), (depth, name, float((a - b).abs().max()))
+    # with the shared-chip block count of the weight-gradient launches (half the pixel-range splits): the same sums in
+    # another order
+    got, _ = run(True, 6, share=True)
+    assert float((got[3] - ref[3]).norm() / ref[3].norm()) < 1e-5
