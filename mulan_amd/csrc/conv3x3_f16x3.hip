@@ -1297,7 +1297,8 @@ MULAN_API int mulan_param_pack_f16x3(const float* flat, const long long* leaves,
 static int linear_wgrad_splits(int B, int H, int C, int N) {
   const int tiles = (C / WG3_T) * (N / WG3_T);
   const int pairs = B * (H / WG_ROWS);
-  int S = 240 / tiles;
+  const int target = g_mulan_tune[9] == 1 ? 160 : 240;     // (shared chip, see wgrad_splits_p: scan 64 ... 240)
+  int S = target / tiles;
   if (S < 1) S = 1;
   if (S > pairs) S = pairs;
   return S;
