@@ -284,6 +284,9 @@ def main():
                     "avg_gflop_per_launch": round(tot_f / n / 1e9, 3),
                     "share_of_step": round(tot_t / (elapsed / a.steps), 3),
                     "symbols": symbols,
+                    "note": ("as run: the weight-gradient kernels share the chip with these launches (second stream, "
+                             "balanced to run side by side), so a launch's duration includes the time it shares; "
+                             "`alone` is the same kernel with that stream off") if ops.SIDE_STREAM and world == 1 else None,
                     "other_kernels": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] * 1e3, 2)}
                                       for k, v in per.items() if k not in labels}}
     # ---- the dominant kernel without a neighbour: in the step as shipped the weight-gradient kernels run on a second
