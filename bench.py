@@ -285,8 +285,8 @@ def main():
                     "share_of_step": round(tot_t / (elapsed / a.steps), 3),
                     "symbols": symbols,
                     "note": ("as run: the weight-gradient kernels share the chip with these launches (second stream, "
-                             "balanced to run side by side), so a launch's duration includes the time it shares; "
-                             "`alone` is the same kernel with that stream off") if ops.SIDE_STREAM and world == 1 else None,
+                             "balanced to run side by side), so a launch's duration includes the time it shares the "
+                             "chip") if ops.SIDE_STREAM and world == 1 else None,
                     "other_kernels": {k: {"tflops": round(v[1] / v[0] / 1e12, 1), "ms_per_step": round(v[0] * 1e3, 2)}
                                       for k, v in per.items() if k not in labels}}
     # ---- the dominant kernel without a neighbour: in the step as shipped the weight-gradient kernels run on a second
@@ -297,16 +297,34 @@ def main():
         ops.KERNEL_TIMER = []
         state, _ = exp.train_step(exp._train_rng, state, batches[-1])
         torch.cuda.synchronize()
-        mine = [(s_, e_, fl) for (nm, s_, e_, fl) in ops.KERNEL_TIMER if nm.split("<")[0] == roof["kernel"]]
+        recs_alone = ops.KERNEL_TIMER
+        mine = [(s_, e_, fl) for (nm, s_, e_, fl) in recs_alone if nm.split("<")[0] == roof["kernel"]]
         ops.KERNEL_TIMER = None
         ops.SIDE_STREAM = True
         if mine:
             t_alone = sum(max(1e-7, s_.elapsed_time(e_) * 1e-3 - roof["event_pair_overhead_us"] * 1e-6) for s_, e_, _ in mine)
             ach_alone = sum(fl for _, _, fl in mine) / t_alone / 1e12
-            roof["alone"] = {"avg_launch_us": round(t_alone / len(mine) * 1e6, 1), "achieved": round(ach_alone, 2),
-                             "frac": round(ach_alone / roof["peak"], 4),
-                             "note": "same step with the weight-gradient stream off (MULAN_SIDE_STREAM=0): no other "
-                                     "kernel on the chip while this one runs"}
+            # The roofline of a kernel is about the kernel: the primary figures are those of the launches that own the
+            # chip (this extra step; profiles/*_serial_kernel_stats.csv is the rocprofv3 summary of the same mode).  The
+            # figures of the step as shipped, where the launches share the chip with the weight-gradient stream, move to
+            # "as_run" (profiles/*_kernel_stats.csv).
+            roof["as_run"] = {k: roof[k] for k in ("achieved", "frac", "executed_mfma_tflops", "avg_launch_us",
+                                                   "share_of_step", "symbols")}
+            roof["as_run"]["note"] = roof.pop("note")
+            per_lab = {}
+            for (nm, s_, e_, fl) in [r_ for r_ in recs_alone if r_[0].split("<")[0] == roof["kernel"]]:
+                d = per_lab.setdefault(nm, [0.0, 0.0, 0])
+                d[0] += max(1e-7, s_.elapsed_time(e_) * 1e-3 - roof["event_pair_overhead_us"] * 1e-6)
+                d[1] += fl
+                d[2] += 1
+            roof.update({"achieved": round(ach_alone, 2), "frac": round(ach_alone / roof["peak"], 4),
+                         "executed_mfma_tflops": round(3 * ach_alone, 1) if roof["executed_mfma_tflops"] else None,
+                         "avg_launch_us": round(t_alone / len(mine) * 1e6, 1),
+                         "share_of_step": None,
+                         "symbols": {k: {"launches_per_step": v[2], "avg_launch_us": round(v[0] / v[2] * 1e6, 1),
+                                         "tflops": round(v[1] / v[0] / 1e12, 1)} for k, v in per_lab.items()},
+                         "measured": "one extra train step with the weight-gradient stream off (MULAN_SIDE_STREAM=0): no "
+                                     "other kernel on the chip while a launch of this kernel runs"})
     # ---- the same step with the exact-fp32 MFMA convolution kernels (MULAN_CONV_MODE=f32), for reference
     if world == 1 and ops.CONV_MODE != "f32" and not a.no_f32_mode:
         saved = ops.CONV_MODE
