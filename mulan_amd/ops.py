@@ -1057,7 +1057,9 @@ class GnConv3x3Fn(torch.autograd.Function):
             return (ds1, ds2) + (None,) * 6 + nones
         x1, x2, gamma, beta, mean, rstd, ys, w, bound = ctx.saved_tensors
         need = ctx.needs_input_grad
-        conv = _Ctx(saved_tensors=(ys, w), planes=True, xmax=bound, wmax=ctx.wmax, has=ctx.has, gv=ctx.gv_conv,
+        # (planes = False when the kernel needs no gradient -- the ODE evaluator differentiates with respect to the input
+        # only: input gradient without plane output, no weight-gradient launch)
+        conv = _Ctx(saved_tensors=(ys, w), planes=bool(need[4]), xmax=bound, wmax=ctx.wmax, has=ctx.has, gv=ctx.gv_conv,
                     needs_input_grad=(True, need[4], need[5], need[6], need[7]))
         dh, dw, dbias, dcb, dres = _conv3x3_backward(conv, dy)
         gn = _Ctx(saved_tensors=(x1, x2, gamma, beta, mean, rstd), meta=ctx.meta, gv=ctx.gv_gn,
