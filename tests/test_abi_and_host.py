@@ -475,3 +475,38 @@ def test_cifar10_aug_stream_flags_augmented_images(tmp_path, monkeypatch):
     ev = data.BatchStream("cifar10_aug", 4, train=False, device="cpu")
     e = next(ev)
     assert int(e["conditioning"].sum()) == 0 and np.array_equal(e["images"].numpy(), imgs[:4])
+
+
+def test_plane_hand_over_gating_and_backward_scope(monkeypatch):
+    """host logic of the two round-2 schedulers, no GPU needed: which (GroupNorm, convolution) pairs take the plane
+    hand-over, and that the backward scope of the weight-gradient stream arms / disarms itself (also when the body
+    raises) and switches the library's shared-chip block count with it."""
+    from mulan_amd import ops
+    monkeypatch.setattr(ops, "CONV_MODE", "f16x3")
+    monkeypatch.setattr(ops, "GN_CONV_PLANES", True)
+    ok = ops.gn_conv_ok
+    assert ok(128, 0, 128, 32) and ok(128, 128, 128, 32) and ok(256, 256, 256, 32) and ok(256, 0, 512, 32)
+    assert not ok(64, 0, 128, 32)            # the plane-fed weight-gradient kernel wants 128-multiples of channels
+    assert not ok(128, 0, 3, 32)             # conv_out
+    assert not ok(512, 512, 128, 32)         # more than 16 maxima slots
+    assert not ok(128, 0, 128, 3)            # groups that do not divide the channels
+    monkeypatch.setattr(ops, "CONV_MODE", "f32")
+    assert not ok(128, 0, 128, 32)
+    calls = []
+    monkeypatch.setattr(ops, "call", lambda name, *a: calls.append((name,) + a))
+    monkeypatch.setattr(ops, "SIDE_STREAM", True)
+    monkeypatch.setattr(ops, "SIDE_WGRAD_SHARE", True)
+    assert not ops._side_ok(None)
+    with ops.weight_gradient_stream():
+        assert ops._SIDE["active"] and calls == [("mulan_set_tuning", 9, 1)]
+        assert not ops._side_ok(None)        # no sink in the flat gradient buffer: stays on the current stream
+    assert not ops._SIDE["active"] and calls[-1] == ("mulan_set_tuning", 9, 0)
+    with pytest.raises(RuntimeError):
+        with ops.weight_gradient_stream():
+            raise RuntimeError("backward failed")
+    assert not ops._SIDE["active"] and calls[-1] == ("mulan_set_tuning", 9, 0)
+    monkeypatch.setattr(ops, "SIDE_STREAM", False)
+    n = len(calls)
+    with ops.weight_gradient_stream():
+        assert not ops._SIDE["active"]
+    assert len(calls) == n
