@@ -49,9 +49,9 @@ MAX_PARTS = 16
 
 # ----------------------------------------------------------------------------- weight-gradient side stream
 # Nothing in the backward pass waits for a weight gradient (only the all-reduce of its bucket and the optimizer do), while
-# the input-gradient chain is strictly serial.  The weight-gradient kernels therefore go to a second HIP stream: they
-# run beside the GroupNorm / elementwise kernels of the layers in front (HBM-bound, few CUs' worth of work) and fill
-# the ramp-down of every kernel of the main chain, instead of taking their own slot in one queue.  Only gradients with
+# the input-gradient chain is strictly serial.  The weight-gradient kernels therefore go to a second HIP stream and
+# run beside the GroupNorm backward / input-gradient convolution of the layers in front (see SIDE_WGRAD_SHARE for the
+# split of the chip between the two streams), instead of taking their own slot in one queue.  Only gradients with
 # a sink in the flat gradient buffer take this path (nothing on the main stream reads them before side_join()).
 # Scope: `with weight_gradient_stream(): loss.backward()` (the train step does this); outside such a block everything
 # stays on the current stream.
