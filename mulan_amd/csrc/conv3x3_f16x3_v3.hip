@@ -58,7 +58,8 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const
 }
 
 // ABL: dev-only ablation bits (timing only, results wrong): 1 no LDS fragment reads, 2 no weight loads, 4 no patch
-// fills, 8 no barriers in the main loop
+// fills, 8 no barriers in the main loop, 32 patch fill without the split arithmetic, 16 without the split arithmetic
+// and without the plane stores
 // PIN: the input arrives as split planes (written by the GroupNorm in front, mulan_groupnorm_fwd_planes): the fill is a
 // 16-byte copy per slot -- no split arithmetic and, above all, no plane stores out of this kernel (they cost 5-13 % of
 // a launch: conv_ab ablation 16 / 32 of round 2).
@@ -131,15 +132,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
     const f32x4 v = __builtin_bit_cast(f32x4, raw);
     f16x4 hi, lo;
+    if (ABL & 48) {         // timing only (16 / 32): realistic operand values without the split arithmetic
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      _Float16 h, l;
-      split2(v[e] * sx, h, l);
-      hi[e] = h; lo[e] = l;
+      for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)(v[e] * sx); lo[e] = (_Float16)(v[e] * (sx * 0.0004f)); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        _Float16 h, l;
+        split2(v[e] * sx, h, l);
+        hi[e] = h; lo[e] = l;
+      }
     }
     unsigned char* d = smem + (sl.ldst >= P3_DUMMY ? sl.ldst : pbuf + sl.ldst);
     *reinterpret_cast<f16x4*>(d) = hi;
     *reinterpret_cast<f16x4*>(d + (sl.ldst >= P3_DUMMY ? 0 : P3_PLANE)) = lo;
+    if (ABL & 16) return;   // timing only: no plane stores either (32: the plane stores stay)
     const unsigned eo = sl.emit != 0xffffffffu ? sl.emit + (unsigned)cc * 65536u : 0xffffffffu;
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), xs_rsrc, eo, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo == 0xffffffffu ? eo : eo + 32, 0, 0);
@@ -392,6 +399,8 @@ int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream)
     case 4: MULAN_V3_LAUNCH(4) break;
     case 8: MULAN_V3_LAUNCH(8) break;
     case 15: MULAN_V3_LAUNCH(15) break;
+    case 16: MULAN_V3_LAUNCH(16) break;
+    case 32: MULAN_V3_LAUNCH(32) break;
     default: MULAN_V3_LAUNCH(0) break;
   }
 #undef MULAN_V3_LAUNCH
