@@ -53,6 +53,7 @@ def main(argv):
         raise SystemExit(f'unknown --bpd_eval_method {FLAGS.bpd_eval_method}')
     if rank == 0:
         print(f'Test BPD:{bpd} ckpt:{ckpt_num}')
+    return bpd
 
 
 if __name__ == '__main__':

@@ -135,8 +135,10 @@ class BatchStream:
             return self.x[k * n:(k + 1) * n], self.y[k * n:(k + 1) * n]
         idx = []
         while len(idx) < n:
-            # rank r reads a strided shard of the (shuffled) index stream shared by all ranks
-            if self.pos * self.world + self.rank >= len(self.perm):
+            # rank r reads a strided shard of the (shuffled) index stream shared by all ranks; the epoch ends for every
+            # rank at the same position (the len % world tail is dropped, like the reference's per-host split), so the
+            # ranks stay on the same permutation for any dataset size
+            if self.pos >= len(self.perm) // self.world:
                 self.pos = 0
                 self.epoch += 1
                 self.perm = self._permutation()
@@ -144,6 +146,15 @@ class BatchStream:
             self.pos += 1
         idx = np.asarray(idx, dtype=np.int64)
         return self.x[idx], self.y[idx]
+
+    def seek(self, samples_drawn):
+        """positions the infinite train stream as if `samples_drawn` samples per rank had been taken (resume from a
+        checkpoint: state.step * batch per rank); a no-op for synthetic data and one-pass streams"""
+        if self.x is None or self.one_pass:
+            return
+        per_epoch = max(1, len(self.x) // self.world)
+        self.epoch, self.pos = divmod(int(samples_drawn), per_epoch)
+        self.perm = self._permutation()
 
     def _batch(self, n):
         img, lab = self._take(n)

@@ -221,19 +221,28 @@ class Experiment(abc.ABC):
 
     # ---- schedules / optimiser ------------------------------------------------------------------
     def get_lr_schedule(self):
-        """optax.linear_schedule warm-up (+ optional linear decay), ldm/experiment.py:106-129."""
-        lr = self.config.optimizer.learning_rate
+        """ldm/experiment.py:106-129: optax.linear_schedule(0 -> lr over num_steps_lr_warmup), joined at the warm-up
+        boundary with linear_schedule(lr -> 0 over num_steps_train - warm-up) when optimizer.lr_decay is set.  optax's
+        linear_schedule with transition_steps <= 0 is the CONSTANT init_value, so num_steps_lr_warmup <= 0 without
+        decay trains at lr 0.0 in the reference; reproduced (with a warning), not repaired."""
+        lr = float(self.config.optimizer.learning_rate)
         tr = self.config.training
-        warm = tr.num_steps_lr_warmup
+        warm = int(tr.num_steps_lr_warmup)
         decay = bool(self.config.optimizer.lr_decay)
-        total = tr.num_steps_train
+        span = int(tr.num_steps_train) - warm
+
+        def ramp(first, last, steps, count):
+            if steps <= 0:
+                return first
+            return first + (last - first) * (min(max(count, 0), steps) / steps)
+
+        if warm <= 0 and not decay:
+            log.warning("num_steps_lr_warmup <= 0 without lr_decay: the reference's schedule is the constant 0.0")
 
         def schedule(step):
-            if warm <= 0:            # optax.linear_schedule with transition_steps <= 0 returns the end value
-                return lr if not decay else lr * max(0.0, 1.0 - step / max(1, total))
-            if step < warm or not decay:
-                return lr * min(max(step, 0), warm) / warm
-            return lr * max(0.0, 1.0 - (step - warm) / max(1, total - warm))
+            if decay and step >= warm:
+                return ramp(lr, 0.0, span, step - warm)
+            return ramp(0.0, lr, warm, step)
         return schedule
 
     @abc.abstractmethod
@@ -249,10 +258,15 @@ class Experiment(abc.ABC):
         ...
 
     # ---- steps ----------------------------------------------------------------------------------
+    def _profiling_now(self):
+        """True while the profile window of config.training.profile is open: those steps run eagerly, one roctx range
+        per phase; before and after the window the HIP-graph step is used"""
+        return self._profile is not None and self._profile.active
+
     def train_step(self, base_rng, state, batch):
         """Experiment.train_step (ldm/experiment.py:335-356): fold rank + step into the rng, value_and_grad,
         gradient mean over ranks, lr schedule, AdamW+EMA, scalar mean over ranks."""
-        if self.hip_graph and self._profile is None and ops_kernel_timer_off() and hasattr(self.model, "parameterization"):
+        if self.hip_graph and not self._profiling_now() and ops_kernel_timer_off() and hasattr(self.model, "parameterization"):
             g = self._graphed
             if g is None or not g.matches(batch):
                 if self._eager_steps >= 1:           # one eager step first: every kernel configured, allocator warm
@@ -268,7 +282,7 @@ class Experiment(abc.ABC):
                 return g.step(base_rng, state, batch)
         self._eager_steps += 1
         rng = base_rng.fold_in(self.rank).fold_in(state.step)
-        phase = self._profile.phase if self._profile is not None else (lambda name: contextlib.nullcontext())
+        phase = self._profile.phase if self._profiling_now() else (lambda name: contextlib.nullcontext())
         state.zero_grad()
         self.reducer.prepare()
         packer = state.param_packer()        # f16x3 mode: weight maxima + packed operands of all layers, two launches
@@ -329,6 +343,8 @@ class Experiment(abc.ABC):
             state.load_state_dict(ckpt_lib.restore_dict(latest))
         step = initial_step = int(state.step)
         substeps = config.substeps
+        if initial_step and hasattr(self.train_iter, "seek"):        # resume: the data stream continues where it was
+            self.train_iter.seek(initial_step * self.train_iter.local)
         writer = ckpt_lib.ScalarWriter(workdir if self.rank == 0 else None)
         if initial_step == 0:
             writer.write_hparams(self.config.to_dict())

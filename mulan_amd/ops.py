@@ -848,10 +848,12 @@ _TICKETS = {}
 
 
 def _gn_tickets(device):
-    """arrival counters of the in-kernel reductions (zero between launches; one stream at a time per device)"""
-    t = _TICKETS.get(device)
+    """arrival counters of the in-kernel reductions (zero between launches).  One array per (device, stream): launches
+    on one stream are ordered and each leaves its counters zero; two streams must never share them."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
+    t = _TICKETS.get(key)
     if t is None:
-        t = _TICKETS[device] = torch.zeros(16, device=device, dtype=torch.int32)
+        t = _TICKETS[key] = torch.zeros(16, device=device, dtype=torch.int32)
     return t
 
 

@@ -46,8 +46,10 @@ def trace_range(name):
 
 class Profile:
     """clu.periodic_actions.Profile look-alike (num_profile_steps = 5, first profile after `first_profile` steps):
-    while active the train step emits one range per phase (forward / backward / all-reduce / optimizer) and the HIP
-    profiler start / stop API brackets the window, so a collection period can be tied to it."""
+    while active the train step runs eagerly (no HIP-graph replay) and emits one roctx range per phase (forward /
+    backward / all-reduce / optimizer): the ranges are what `rocprofv3 --marker-trace` shows.  torch.cuda.profiler
+    start / stop are called around the window as well; on ROCm builds of torch they may be no-ops, nothing relies on
+    them."""
 
     def __init__(self, num_profile_steps=5, first_profile=10):
         self.n, self.first = num_profile_steps, first_profile

@@ -343,9 +343,19 @@ def mulan_forward(params, cfg, x, t0, raw_gamma, eps_0, eps, dt=np.float64, enc_
 
 
 # ------------------------------------------------------------------------------ A.6 optimiser
-def lr_schedule(step, lr=2e-4, warmup=100):
-    """optax.linear_schedule(0, lr, warmup) without decay (ldm/experiment.py:106-129)"""
-    return lr * min(max(step, 0), warmup) / warmup
+def lr_schedule(step, lr=2e-4, warmup=100, decay=False, total=None):
+    """ldm/experiment.py:106-129.  optax.linear_schedule(init, end, n) is polynomial_schedule with power 1:
+    value(count) = (init - end) * (1 - clip(count, 0, n) / n) + end, and the CONSTANT init when n <= 0.  Without
+    lr_decay the schedule is the warm-up ramp alone; with it, join_schedules switches at `warmup` to the decay ramp
+    evaluated at count - warmup."""
+    def linear(init, end, n, count):
+        if n <= 0:
+            return init
+        frac = 1.0 - min(max(count, 0), n) / n
+        return (init - end) * frac + end
+    if decay and step >= warmup:
+        return linear(lr, 0.0, total - warmup, step - warmup)
+    return linear(0.0, lr, warmup, step)
 
 
 def adamw_ema_step(p, g, m, v, ema, lr, step, decay_mask, b1=0.9, b2=0.99, eps=1e-8, wd=0.01, ema_rate=0.9999):

@@ -258,32 +258,10 @@ def test_verify_checkpoint_on_synthetic_flax_with_aliased_names(tmp_path):
     config.model.sm_n_layer = 1
     config.model.forward_n_layer = 1
     ocfg = vc.oracle_cfg(config)
-    ref = tr.init_params(ocfg, seed=4, dtype=torch.float64)
-    as_np = lambda tree, scale=1.0: tr.tree_map(lambda t: (t.detach().numpy() * scale).astype(np.float32), tree)
-    alias = {v: k for k, v in ck.GAMMA_NET_ALIASES.items()}
-
-    def aliased(tree):
-        out = dict(tree)
-        out["gamma"] = {alias[k]: v for k, v in tree["gamma"].items()}
-        return out
-
-    def masked(tree, keep_score):                      # optax.masked: the other sub-trees become empty MaskedNodes
-        empty = lambda t: {k: empty(v) for k, v in t.items()} if isinstance(t, dict) else {}
-        return {k: (v if (k == "score_model") == keep_score else empty(v)) for k, v in tree.items()}
-
-    params, ema = aliased(as_np(ref)), aliased(as_np(ref, 0.5))
-    mu, nu = aliased(as_np(ref, 0.1)), aliased(as_np(ref, 0.01))
-    adam = lambda keep: {"inner_state": {"0": {"count": np.int32(9), "mu": masked(mu, keep), "nu": masked(nu, keep)},
-                                         "1": {}, "2": {}}}
-    sd = {"step": np.int32(9), "params": params, "ema_params": ema, "opt_state": {"0": adam(True), "1": adam(False)}}
-    # one leaf in Flax's chunked-array form (arrays above 2^30 bytes in real checkpoints)
-    k = ema["score_model"]["dense0"]["kernel"]
-    sd["ema_params"] = copy.deepcopy(ema)
-    sd["ema_params"]["score_model"]["dense0"]["kernel"] = {
-        "__msgpack_chunked_array__": True, "shape": {"0": k.shape[0], "1": k.shape[1]},
-        "chunks": {"0": k.reshape(-1)[:100].copy(), "1": k.reshape(-1)[100:].copy()}}
     path = str(tmp_path / "ckpt-9.flax")
-    ck.save_flax(path, sd)
+    sd, ref, trees = vc.write_synthetic_flax_checkpoint(path, config, seed=4, step=9)
+    ema, mu, nu = trees["ema"], trees["mu"], trees["nu"]
+    k = ema["score_model"]["dense0"]["kernel"]
 
     back = ck.restore_dict(path)
     assert set(back["ema_params"]["gamma"]) == set(ck.GAMMA_NET_ALIASES.values())
@@ -510,3 +488,82 @@ def test_plane_hand_over_gating_and_backward_scope(monkeypatch):
     with ops.weight_gradient_stream():
         assert not ops._SIDE["active"]
     assert len(calls) == n
+
+
+# ------------------------------------------------------------------------------ round 3: schedule, stream sync, hazards
+def test_lr_schedule_matches_oracle_and_reference_edge_cases():
+    """H1: the product's Experiment.get_lr_schedule against the oracle's restatement of ldm/experiment.py:106-129 for
+    every step of a short run, with and without lr_decay, including the reference's own edge cases (optax's
+    linear_schedule with transition_steps <= 0 is the constant init_value: no warm-up and no decay -> lr 0.0)."""
+    import types
+    from mulan_amd.config import ConfigDict
+    from mulan_amd.experiment import Experiment
+    from oracle import mulan_np as onp
+    for warm, decay, total in [(100, False, 1000), (2, False, 10), (5, True, 40), (0, True, 20), (0, False, 20),
+                               (10, True, 10)]:
+        cfg = ConfigDict(dict(optimizer=dict(learning_rate=2e-4, lr_decay=decay),
+                              training=dict(num_steps_lr_warmup=warm, num_steps_train=total)))
+        sched = Experiment.get_lr_schedule(types.SimpleNamespace(config=cfg))
+        for step in list(range(0, total + 5)) + [10 * total]:
+            want = onp.lr_schedule(step, 2e-4, warm, decay, total)
+            assert abs(sched(step) - want) <= 1e-18 + 1e-12 * abs(want), (warm, decay, total, step, sched(step), want)
+    cfg = ConfigDict(dict(optimizer=dict(learning_rate=2e-4, lr_decay=False),
+                          training=dict(num_steps_lr_warmup=100, num_steps_train=1000)))
+    sched = Experiment.get_lr_schedule(types.SimpleNamespace(config=cfg))
+    assert sched(0) == 0.0 and abs(sched(50) - 1e-4) < 1e-15 and sched(100) == 2e-4 and sched(99999) == 2e-4
+
+
+def test_train_stream_ranks_stay_on_one_permutation_for_uneven_sizes(tmp_path):
+    """len(dataset) % world != 0: every rank ends its epoch at the same position (the tail is dropped), so after many
+    epochs the ranks still partition ONE permutation per epoch -- no cross-rank duplicates in any epoch -- and seek()
+    puts a fresh stream where a resumed run left off."""
+    from mulan_amd import data
+    N, world, bs = 103, 4, 20                       # 5 samples per rank and draw, 25 per rank and epoch, 3 dropped
+    imgs = np.zeros((N, 32, 32, 3), dtype=np.uint8)
+    imgs[:, 0, 0, 0] = np.arange(N)
+    np.savez(tmp_path / "d.npz", images=imgs)
+    name = f"npz:{tmp_path / 'd.npz'}"
+    streams = [data.BatchStream(name, bs, train=True, device="cpu", seed=3, rank=r, world=world) for r in range(world)]
+    ident = lambda b: b["images"][:, 0, 0, 0].long().tolist()
+    for epoch in range(7):
+        seen = []
+        for _ in range(5):
+            for st in streams:
+                seen += ident(next(st))
+        assert len(seen) == 100 and len(set(seen)) == 100, epoch          # disjoint shards of one permutation
+        assert {st.epoch for st in streams} == {epoch} or {st.pos for st in streams} == {25}
+    assert len({(st.epoch, st.pos) for st in streams}) == 1
+    # resume: a fresh stream positioned after 7 epochs + 2 draws yields what the running one yields next
+    for st in streams:
+        next(st), next(st)
+    fresh = data.BatchStream(name, bs, train=True, device="cpu", seed=3, rank=1, world=world)
+    fresh.seek((7 * 5 + 2) * 5)
+    assert ident(next(fresh)) == ident(next(streams[1]))
+
+
+def test_no_mfma_data_hazard_in_the_built_objects(built_lib):
+    """The inline-asm matrix instructions of conv3x3_f16x3_v3.hip are invisible to hipcc's hazard recognizer: a VALU
+    write of an A / B operand right in front of one, or an accumulator read too soon after one, would corrupt results
+    silently.  tools/mfma_hazard_scan.py walks the gfx950 disassembly of every object of this build (so a compiler
+    bump or an edit that moves a register copy is caught here, on the CPU); its two rules are checked on a synthetic
+    listing first."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import mfma_hazard_scan as scan
+    finally:
+        sys.path.pop(0)
+    bad = """
+0000000000000000 <kernel>:
+\tv_mov_b32_e32 v2, v9                                       // 000000000000: 7E040309
+\tv_mfma_f32_16x16x32_f16 a[0:3], v[2:5], v[6:9], a[0:3]     // 000000000004: 00000000
+\ts_nop 3                                                    // 000000000008: 00000000
+\tv_accvgpr_read_b32 v1, a2                                  // 00000000000c: 00000000
+"""
+    assert sorted(f[1] for f in scan.scan_text(bad)) == ["R1", "R2"]
+    good = bad.replace("v_mov_b32_e32 v2, v9 ", "v_mov_b32_e32 v2, v9\n\ts_nop 1 ").replace("s_nop 3", "s_nop 5")
+    assert scan.scan_text(good) == []
+    if not os.path.exists(scan.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    found = scan.scan_objects()
+    assert found == [], found[:5]

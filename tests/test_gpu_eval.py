@@ -59,8 +59,8 @@ def _oracle_bpd(ref_params, ocfg, x_u8, noise):
 
 def test_dense_and_sparse_eval_match_oracle(tmp_path):
     """eval_bpd_dense_sampling / eval_bpd_sparse_sampling on the HIP path == the oracle's mean of per-image (per-batch)
-    BPDs under the evaluators' own noise, E = 256 (imagenet32 configuration, velocity_from_epsilon).  Bar: 1e-3
-    relative (the north-star bar is +-0.005 absolute on a BPD of ~3.7)."""
+    BPDs under the evaluators' own noise, E = 256 (imagenet32 configuration, velocity_from_epsilon).  Bar: the
+    north-star's +-0.005 bits/dim, absolute."""
     from mulan_amd import evaluators as ev
     rng = np.random.default_rng(5)
     images = rng.integers(0, 256, (4, 32, 32, 3)).astype(np.uint8)
@@ -73,12 +73,12 @@ def test_dense_and_sparse_eval_match_oracle(tmp_path):
     got = ev.eval_bpd_dense_sampling(exp, config, n_timesteps=T, max_images=3)
     noise = _eval_noise(exp, T)
     want = np.mean([_oracle_bpd(ref_params, ocfg, np.repeat(images[i:i + 1], T, axis=0), noise) for i in range(3)])
-    assert abs(got - want) < 1e-3 * abs(want), (got, want)
+    assert abs(got - want) < 0.005, (got, want)
 
     got_s = ev.eval_bpd_sparse_sampling(exp, config)              # two batches of two distinct images
     noise2 = _eval_noise(exp, 2)
     want_s = np.mean([_oracle_bpd(ref_params, ocfg, images[k:k + 2], noise2) for k in (0, 2)])
-    assert abs(got_s - want_s) < 1e-3 * abs(want_s), (got_s, want_s)
+    assert abs(got_s - want_s) < 0.005, (got_s, want_s)
     assert abs(got - got_s) > 1e-6                                # two different estimators of the same bound
 
 

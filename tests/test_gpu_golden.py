@@ -68,4 +68,4 @@ def test_small_model_against_fixture(name, vdm_type, unet_type, vfe):
     assert _rel(out.loss_klz.cpu().numpy(), z[f"{name}_klz"]) < 1e-4
     assert _rel(out.loss_diff.cpu().numpy(), z[f"{name}_diff"]) < 5e-4
     bpd = float((out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()) / (3072 * np.log(2.0)))
-    assert abs(bpd - float(z[f"{name}_bpd"])) < 1e-3 * abs(float(z[f"{name}_bpd"]))
+    assert abs(bpd - float(z[f"{name}_bpd"])) < 0.005          # the north-star bar, absolute bits/dim

@@ -1,0 +1,200 @@
+"""Experiment.train_step as ONE unit -- rng fold-in, value_and_grad, lr(step), AdamW x 2
+masked, EMA, logged scalars (ldm/experiment.py:335-356, ldm/train_state.py:70-102, ldm/experiment.py:106-182) -- over
+several optimiser steps against the float64 oracle, with the eager step and with the HIP-graph replay
+(GraphedStep, the build's lax.scan).
+
+Two comparisons per step:
+  * teacher-forced: the oracle's AdamW + EMA + lr schedule is fed the gradient the HIP step produced; parameters, EMA
+    and both Adam moments must then agree to fp32 rounding (1e-5 of each leaf's scale: this pins the composition --
+    lr(step) with the warm-up index, the bias-correction count, the decay mask boundary, grad_scale, EMA order);
+  * free-running: the oracle computes its own gradient (float64 autograd through its own forward, with the step's
+    noise and dropout masks re-derived from the step's keys) at its own parameters: the logged BPD of every step
+    within +-0.005 absolute (the north-star bar; measured ~1e-5), gradients within the per-leaf bar of
+    test_gpu_model.run_case, Adam moments likewise.  Adam normalises each element by its own magnitude, so a
+    gradient element that is zero to fp32 noise moves by lr in either direction: the free-running parameters are
+    compared in the update's L2 norm, not element by element.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mulan_np as onp
+from oracle import torch_ref as tr
+
+from test_gpu_model import block_names, oracle_masks
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, E, STEPS, WARMUP = 4, 128, 4, 2
+
+
+def _experiment(graph, vdm_type):
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    config.vdm_type = vdm_type
+    config.data.dataset = "synthetic"
+    config.model.sm_n_layer = 1
+    config.model.forward_n_layer = 1
+    config.training.batch_size_train = B
+    config.training.batch_size_eval = B
+    config.training.substeps = 1
+    config.training.num_steps_lr_warmup = WARMUP
+    config.training.hip_graph = graph
+    config.optimizer.ema_rate = 0.9            # (0.9999 would hide an EMA mistake below the tolerance)
+    return Experiment_VDM(config), config
+
+
+def _leaf(tree, path):
+    for k in path:
+        tree = tree[k]
+    return tree
+
+
+def _flax_state(exp):
+    """(params, ema, mu, nu) of the product as float64 numpy trees in the reference layout"""
+    from mulan_amd import model as M
+    st = exp.state
+
+    def tree_of(flat):
+        views = {}
+        for path, off, shape in st.layout:
+            d = views
+            for k in path[:-1]:
+                d = d.setdefault(k, {})
+            d[path[-1]] = flat[off:off + int(np.prod(shape))].view(shape)
+        return M.tree_map(lambda t: t.detach().double().cpu().numpy(), M.to_flax_layout(views))
+    return tuple(tree_of(f) for f in (st.flat, st.ema, st.mu, st.nu)), tree_of(st.grad)
+
+
+def _oracle_step_inputs(exp, step, images, vdm_type):
+    """noise and dropout masks of train step `step`, re-derived from the experiment's keys the way
+    Experiment.train_step / loss_fn / VDM.apply derive them (ldm/experiment.py:336-337, experiment_vdm.py:48-53)"""
+    rng = exp._train_rng.fold_in(exp.rank).fold_in(step)
+    keys = exp.step_keys(rng, True)
+    _, sample_rng = rng.split()
+    noise = exp.model._noise({"sample": sample_rng}, None, B, exp.device, True)
+    enc_masks = oracle_masks(block_names(1, False), keys["enc"], B, E, 0.9)
+    score_masks = oracle_masks(block_names(1, True), keys["score"], B, E, 0.9)
+    f64 = lambda t: t.double().cpu()
+    return dict(t0=float(noise["t0"]), raw=f64(noise["gamma_raw"]), e0=f64(noise["eps_0"]).view(B, 32, 32, 3),
+                e=f64(noise["eps"]).view(B, 32, 32, 3), enc_masks=enc_masks, score_masks=score_masks)
+
+
+@pytest.mark.parametrize("vdm_type", ["mulan_epsilon", "mulan_velocity"])
+def test_train_step_trajectory_matches_oracle(vdm_type):
+    from mulan_amd import model as M
+    ocfg = dict(vdm_type=vdm_type, n_embd=E, n_layer=1, forward_n_layer=1, latent_k=15, unet_type="vdm",
+                velocity_from_epsilon=False, with_attention=False)
+    init = tr.init_params(ocfg, seed=13, dtype=torch.float64)           # non-zero everywhere: every gradient is live
+    paths = [p for p, _ in tr.tree_leaves(init)]
+    decay_mask = {p: float(p[-1] != "bias" and tuple(p[-2:]) not in (("layer_norm", "scale"), ("final_layer_norm", "scale")))
+                  for p in paths}                                        # ldm/experiment.py:139-146
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.randint(0, 256, (B, 32, 32, 3), generator=g, dtype=torch.uint8) for _ in range(STEPS)]
+    keep = float(np.float32(0.9))
+    lr0, ema_rate = 2e-4, 0.9
+
+    # ---- the oracle's own trajectory (free-running), computed once: inputs of step k depend on keys only
+    exp0, _ = _experiment(False, vdm_type)
+    step_inputs = [_oracle_step_inputs(exp0, k, batches[k], vdm_type) for k in range(STEPS)]
+    del exp0
+    ref_p = {p: _leaf(init, p).detach().clone().numpy() for p in paths}
+    ref_ema = {p: v.copy() for p, v in ref_p.items()}
+    ref_m = {p: np.zeros_like(v) for p, v in ref_p.items()}
+    ref_v = {p: np.zeros_like(v) for p, v in ref_p.items()}
+    free = []
+    for k in range(STEPS):
+        params_k = tr.tree_map(lambda t: t, init)
+        leaves = {}
+        for p in paths:
+            t = torch.tensor(ref_p[p], dtype=torch.float64, requires_grad=True)
+            d = params_k
+            for key in p[:-1]:
+                d = d[key]
+            d[p[-1]] = t
+            leaves[p] = t
+        si = step_inputs[k]
+        out = tr.mulan_forward(params_k, ocfg, batches[k], si["t0"], si["raw"], si["e0"], si["e"],
+                               enc_masks=si["enc_masks"], score_masks=si["score_masks"], keep=keep)
+        out["bpd"].backward()
+        lr = onp.lr_schedule(k, lr0, WARMUP)
+        grads = {}
+        for p in paths:
+            gk = leaves[p].grad.numpy() if leaves[p].grad is not None else np.zeros_like(ref_p[p])
+            grads[p] = gk
+            ref_p[p], ref_m[p], ref_v[p], ref_ema[p] = onp.adamw_ema_step(
+                ref_p[p], gk, ref_m[p], ref_v[p], ref_ema[p], lr, k + 1, decay_mask[p], ema_rate=ema_rate)
+        free.append(dict(bpd=float(out["bpd"]), grads=grads, p={q: v.copy() for q, v in ref_p.items()},
+                         m={q: v.copy() for q, v in ref_m.items()}, v={q: v.copy() for q, v in ref_v.items()},
+                         ema={q: v.copy() for q, v in ref_ema.items()}))
+
+    def rel_leaf(a, b):
+        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+    for graph in (False, True):
+        exp, config = _experiment(graph, vdm_type)
+        M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), init), exp.state.params)
+        with torch.no_grad():
+            exp.state.ema.copy_(exp.state.flat)
+        # teacher-forced oracle state, in float64, starting from the fp32-rounded parameters the device holds
+        (p0, _, _, _), _ = _flax_state(exp)
+        tf_p = {p: _leaf(p0, p).copy() for p in paths}
+        tf_ema = {p: v.copy() for p, v in tf_p.items()}
+        tf_m = {p: np.zeros_like(v) for p, v in tf_p.items()}
+        tf_v = {p: np.zeros_like(v) for p, v in tf_p.items()}
+        worst = dict(tf=0.0, grad=0.0, mom=0.0, upd=0.0, bpd=0.0)
+        for k in range(STEPS):
+            (before, _, _, _), _ = _flax_state(exp)
+            batch = {"images": batches[k].cuda(), "labels": torch.zeros(B, dtype=torch.int32).cuda(),
+                     "conditioning": torch.zeros(B, dtype=torch.uint8).cuda()}
+            assert exp.state.step == k
+            _, metrics = exp.train_step(exp._train_rng, exp.state, batch)
+            torch.cuda.synchronize()
+            assert exp.state.step == k + 1
+            (got_p, got_ema, got_m, got_v), got_g = _flax_state(exp)
+            lr = onp.lr_schedule(k, lr0, WARMUP)
+            # logged scalar: train_bpd of this step against the free-running oracle (+-0.005 absolute)
+            bpd = float(metrics["scalars"]["train_bpd"])
+            worst["bpd"] = max(worst["bpd"], abs(bpd - free[k]["bpd"]))
+            assert abs(bpd - free[k]["bpd"]) < 0.005, (graph, k, bpd, free[k]["bpd"])
+            num = den = 0.0
+            for p in paths:
+                gk = _leaf(got_g, p)
+                tf_p[p], tf_m[p], tf_v[p], tf_ema[p] = onp.adamw_ema_step(
+                    tf_p[p], gk, tf_m[p], tf_v[p], tf_ema[p], lr, k + 1, decay_mask[p], ema_rate=ema_rate)
+                # ---- teacher-forced: optimizer + EMA + schedule composition, fp32 rounding only
+                for name, got, want in (("params", got_p, tf_p), ("ema", got_ema, tf_ema), ("mu", got_m, tf_m),
+                                        ("nu", got_v, tf_v)):
+                    err = rel_leaf(_leaf(got, p), want[p])
+                    worst["tf"] = max(worst["tf"], err)
+                    assert err < 1e-5, (graph, k, name, "/".join(p), err)
+                # ---- free-running: gradients and moments at the per-leaf bar of the gradient tests; the first
+                # step's gradient is taken at identical parameters, later ones at parameters an Adam step apart
+                bar = 2e-3 if k == 0 else 2e-2
+                eg = rel_leaf(gk, free[k]["grads"][p])
+                worst["grad"] = max(worst["grad"], eg)
+                assert eg < bar, (graph, k, "grad", "/".join(p), eg)
+                em = rel_leaf(_leaf(got_m, p), free[k]["m"][p])
+                worst["mom"] = max(worst["mom"], em)
+                assert em < bar, (graph, k, "mu", "/".join(p), em)
+                assert rel_leaf(_leaf(got_v, p), free[k]["v"][p]) < 2 * bar, (graph, k, "nu", "/".join(p))
+                prev = _leaf(before, p)
+                num += float(((_leaf(got_p, p) - prev - (free[k]["p"][p] - (free[k - 1]["p"][p] if k else
+                                                                                _leaf(init, p).numpy()))) ** 2).sum())
+                den += float(((free[k]["p"][p] - (free[k - 1]["p"][p] if k else _leaf(init, p).numpy())) ** 2).sum())
+            if lr > 0:
+                upd = (num / max(den, 1e-300)) ** 0.5
+                worst["upd"] = max(worst["upd"], upd)
+                assert upd < 0.1, (graph, k, upd)            # sign flips of noise-level elements: measured ~1e-2
+            else:                                            # lr(0) = 0: the first step moves the moments only
+                for p in paths:
+                    assert np.array_equal(_leaf(got_p, p), _leaf(before, p)), (graph, k, "/".join(p))
+        assert (exp._graphed is not None) == graph
+        print(f"trajectory {vdm_type} graph={graph}: teacher-forced {worst['tf']:.2e}, gradient {worst['grad']:.2e}, "
+              f"moments {worst['mom']:.2e}, update L2 {worst['upd']:.2e}, |bpd - oracle| {worst['bpd']:.2e}")
+        del exp
+        torch.cuda.empty_cache()

@@ -64,6 +64,42 @@ def oracle_cfg(config):
                 with_attention=bool(m.with_attention))
 
 
+def write_synthetic_flax_checkpoint(path, config, seed=4, step=9):
+    """A Flax msgpack written the way the reference might write it, from seeded oracle parameters: the gamma network
+    under its attribute names l1 .. l3_c (ldm/model_mulan_epsilon.py:493-512), optax.chain(masked(adamw),
+    masked(adamw)) optimizer state in CLU / Flax state-dict form with masked-out leaves as empty nodes
+    (ldm/experiment.py:151-173), one array in Flax's chunked form; ema_params = 0.5 x params.  Returns (the state dict
+    as written, the float64 oracle tree it was made from, the fp32 trees params / ema / mu / nu under the aliased names)."""
+    import copy
+    from mulan_amd import checkpoint as ck
+    from oracle import torch_ref as tr
+    ref = tr.init_params(oracle_cfg(config), seed=seed, dtype=torch.float64)
+    as_np = lambda tree, scale=1.0: tr.tree_map(lambda t: (t.detach().numpy() * scale).astype(np.float32), tree)
+    alias = {v: k for k, v in ck.GAMMA_NET_ALIASES.items()}
+
+    def aliased(tree):
+        out = dict(tree)
+        out["gamma"] = {alias[k]: v for k, v in tree["gamma"].items()}
+        return out
+
+    def masked(tree, keep_score):                      # optax.masked: the other sub-trees become empty MaskedNodes
+        empty = lambda t: {k: empty(v) for k, v in t.items()} if isinstance(t, dict) else {}
+        return {k: (v if (k == "score_model") == keep_score else empty(v)) for k, v in tree.items()}
+
+    params, ema = aliased(as_np(ref)), aliased(as_np(ref, 0.5))
+    mu, nu = aliased(as_np(ref, 0.1)), aliased(as_np(ref, 0.01))
+    adam = lambda keep: {"inner_state": {"0": {"count": np.int32(step), "mu": masked(mu, keep), "nu": masked(nu, keep)},
+                                         "1": {}, "2": {}}}
+    sd = {"step": np.int32(step), "params": params, "ema_params": copy.deepcopy(ema),
+          "opt_state": {"0": adam(True), "1": adam(False)}}
+    k = ema["score_model"]["dense0"]["kernel"]         # one leaf in Flax's chunked-array form (arrays above 2^30 bytes)
+    sd["ema_params"]["score_model"]["dense0"]["kernel"] = {
+        "__msgpack_chunked_array__": True, "shape": {"0": k.shape[0], "1": k.shape[1]},
+        "chunks": {"0": k.reshape(-1)[:100].copy(), "1": k.reshape(-1)[100:].copy()}}
+    ck.save_flax(path, sd)
+    return sd, ref, dict(params=params, ema=ema, mu=mu, nu=nu)
+
+
 def verify(ckpt, config, images, n_timesteps=16, which="ema_params", use_gpu=None, seed=0, log=print):
     """Returns a dict with the tree diff and, per image, the oracle's and (if a device is present) the HIP path's dense
     variational bound in bits/dim."""
