@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """MuLAN training-throughput bench on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Started by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks; started plainly
+(`python bench.py --gpus 8`) it launches that command itself as a child process and relays rank 0's JSON line -- the
+reference needs no launcher either (ldm/experiment.py:89-95: pmap inside one process).
 
 One "step" = one full train step of the hot path (forward ELBO + backward + RCCL gradient all-reduce + AdamW/EMA)
 on one synthetic CIFAR-shaped uint8 batch that is already resident in HBM.  Default workload at every N: BASELINE.json
@@ -11,7 +16,10 @@ configs[1] -- MuLAN-epsilon, ldm/configs/cifar10-conditioned.py (E=128, 32+2+33 
 `--vdm-type mulan_velocity --global-batch 512`, configs[3] `--config ldm/configs/imagenet32.py --vdm-type mulan_velocity
 --vfe --global-batch 1024`.
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel: the 3x3-conv implicit GEMM) and
-`cpu_baseline` (oracle port on the host cores, bounded samples) objects.
+`cpu_baseline` (oracle port on the host cores, bounded samples) objects.  At N = 1 the line also carries, under
+"configs", a short timing of the other BASELINE configurations at their per-GPU size (#3 MuLAN-velocity at 64 images,
+#4 ImageNet-32 velocity_from_epsilon at 128 images, #5 dense VLB evaluation with T = 1000), each with the convolution
+kernel's own roofline fraction (`--no-also-configs` skips them, `--also-configs` forces them at N > 1).
 """
 import argparse
 import json
@@ -32,8 +40,8 @@ FWD_GFLOP_BY_WIDTH = {128: 57.78, 256: 228.58}   # CIFAR config / I
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--per-gpu-batch", type=int, default=128)
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: fixed global batch split over the ranks (BASELINE configs[2]: 512)")
@@ -47,7 +55,29 @@ def parse():
     ap.add_argument("--cpu-timeout", type=int, default=420)
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the reference measurement with exact-fp32 MFMA convs")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--also-configs", dest="also_configs", action="store_true", default=None,
+                    help="time BASELINE configs #3, #4, #5 after the headline (default: on at N = 1)")
+    ap.add_argument("--no-also-configs", dest="also_configs", action="store_false")
+    ap.add_argument("--also-steps", type=int, default=6, help="timed steps per extra training configuration")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run` with the same arguments
+    as a CHILD process (this parent never touches the GPU), pass its output through and exit with its code"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def cpu_baseline(cfg_path, vdm_type, batch, steps):
@@ -138,80 +168,27 @@ def cpu_baseline(cfg_path, vdm_type, batch, steps):
                                             f"learnable_nnet, no dropout), same U-Net, fp32, {dt_b:.1f} s of CPU work"}}
 
 
-def main():
-    a = parse()
-    if a.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(a.config, a.vdm_type, a.cpu_batch, a.cpu_steps)), flush=True)
-        return
+def _latest_pmc():
+    """the newest committed PMC summary of the convolution kernel (profiles/rNN_pmc_conv3x3_f16x3.json)"""
+    d = os.path.join(ROOT, "profiles")
+    names = sorted(f for f in os.listdir(d) if f.endswith("_pmc_conv3x3_f16x3.json")) if os.path.isdir(d) else []
+    return (os.path.join(d, names[-1]), "profiles/" + names[-1]) if names else (None, None)
+
+
+def conv_roofline(exp, state, batch, a, rank, world, B, E, step_s):
+    """HIP events (on the launch stream) around every convolution launch of one more step as shipped ("as_run") and --
+    on one rank -- of one further step with the weight-gradient stream off, so that every launch owns the chip: the
+    kernel's own roofline.  Every rank runs the steps (they contain the gradient all-reduce); rank 0 records."""
     import torch
     import torch.distributed as dist
-    from mulan_amd import ops, parallel
-    from mulan_amd.config import load_config_file
-    from mulan_amd.experiment import Experiment_VDM
-
-    rank, world, local = parallel.init_distributed()
-    if world != a.gpus:
-        if a.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    config = load_config_file(a.config)
-    config.vdm_type = a.vdm_type
-    config.data.dataset = "synthetic"
-    if a.vfe:
-        config.model.velocity_from_epsilon = True
-    strong = a.global_batch > 0
-    if strong and a.global_batch % world != 0:
-        raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} ranks")
-    B = a.global_batch // world if strong else a.per_gpu_batch
-    config.training.batch_size_train = B * world
-    config.training.batch_size_eval = B * world
-    config.training.substeps = 1
-    exp = Experiment_VDM(config)
-    dev = exp.device
-
-    g = torch.Generator().manual_seed(rank)
-    nb = a.steps + a.warmup
-    batches = [{"images": torch.randint(0, 256, (B, 32, 32, 3), generator=g, dtype=torch.uint8).to(dev),
-                "labels": torch.zeros(B, dtype=torch.int32, device=dev),
-                "conditioning": torch.zeros(B, dtype=torch.uint8, device=dev)} for _ in range(nb)]
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    state = exp.state
-    # One-time set-up outside the W + K steps (the counterpart of a compile step): the first call runs eagerly
-    # (kernel attributes, allocator), the second captures the HIP graph that every later call replays.  Without this a
-    # run with --warmup 0 or 1 would time the capture.
-    prime = 0
-    while exp.hip_graph and exp._graphed is None and prime < 2:
-        state, _ = exp.train_step(exp._train_rng, state, batches[0])
-        prime += 1
-    for i in range(a.warmup):
-        state, _ = exp.train_step(exp._train_rng, state, batches[i])
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        state, m = exp.train_step(exp._train_rng, state, batches[a.warmup + i])
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    last_bpd = float(m["scalars"]["train_bpd"])
-    graph_used = bool(exp.hip_graph and exp._graphed is not None)
-
-    # ---- dominant-kernel timing: HIP events (on the launch stream) around every convolution launch of one more step
+    from mulan_amd import ops
     roof = None
-    f32_mode = None
-    # (every rank runs the step -- it contains the gradient all-reduce -- but only rank 0 records events)
     if rank == 0:
         ops.KERNEL_TIMER = []
-    state, _ = exp.train_step(exp._train_rng, state, batches[-1])
+    state, _ = exp.train_step(exp._train_rng, state, batch)
     torch.cuda.synchronize()
-    barrier()
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         recs = ops.KERNEL_TIMER
         ops.KERNEL_TIMER = None
@@ -233,9 +210,9 @@ def main():
             d[2] += 1
         if per:
             # The dominant kernel: one kernel source can be launched as several instantiations (the f16x3 convolution:
-            # "conv3x3_f16x3_kernel" = conv3x3_f16x3_v3_kernel<0, false> in a rocprofv3 trace -- fp32 input, the input
-            # gradients of the step -- and "conv3x3_f16x3_kernel<planes_in>" = <0, true>, the plane-fed forward
-            # launches); they are summed for the choice and for the roofline, and listed one by one under "symbols".
+            # "conv3x3_f16x3_kernel" = conv3x3_f16x3_v3_kernel<0, false> in a rocprofv3 trace -- fp32 input -- and
+            # "conv3x3_f16x3_kernel<planes_in>" = <0, true>, the plane-fed launches); they are summed for the choice
+            # and for the roofline, and listed one by one under "symbols".
             fam = {}
             for lab, (t_, f_, n_) in per.items():
                 d = fam.setdefault(lab.split("<")[0], [0.0, 0.0, 0])
@@ -253,20 +230,22 @@ def main():
             # the bench: every launch of the step is priced with the bytes of its shape (instantiation, and 128->128
             # vs the 256 <-> 128 shapes by its FLOP count) and `traffic` is the mean over the step's launches
             traffic, pmc = a.traffic, None
-            pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_conv3x3_f16x3.json")
-            if name == "conv3x3_f16x3_kernel" and os.path.exists(pmc_file) and int(config.model.sm_n_embd) == 128:
+            pmc_file, pmc_name = _latest_pmc()
+            if name == "conv3x3_f16x3_kernel" and pmc_file and E == 128:
                 with open(pmc_file) as f:
                     pj = json.load(f)["shapes"]
                 scale = B / 128.0
                 fl_small = 2.0 * B * 1024 * 9 * 128 * 128
                 hb = lambda k: pj[k]["hbm_bytes_per_launch"]
+                pin_dg = ("pin_dgrad_128_128", "pin_dgrad_128_256") if "pin_dgrad_128_128" in pj else ("dgrad_128_128", "dgrad_128_256")
                 table = {"conv3x3_f16x3_kernel<planes_in>": (0.5 * (hb("pin_fwd_128_128_res") + hb("pin_fwd_128_128_film")),
                                                              hb("pin_fwd_256_128_film")),
+                         "conv3x3_f16x3_kernel<planes_in,dgrad>": (hb(pin_dg[0]), hb(pin_dg[1])),
                          "conv3x3_f16x3_kernel": (hb("dgrad_128_128"), hb("dgrad_128_256"))}
                 byts = [scale * table[nm][0 if fl < 1.5 * fl_small else 1] for (nm, _, _, fl) in recs if nm in table]
-                used = ("dgrad_128_128", "dgrad_128_256", "pin_fwd_128_128_res", "pin_fwd_128_128_film", "pin_fwd_256_128_film")
-                pmc = {"source": "profiles/r02_pmc_conv3x3_f16x3.json (B = 128, one entry per instantiation and launch "
-                                 "shape; scaled by batch / 128)",
+                used = tuple(dict.fromkeys(("dgrad_128_128", "dgrad_128_256") + pin_dg +
+                                           ("pin_fwd_128_128_res", "pin_fwd_128_128_film", "pin_fwd_256_128_film")))
+                pmc = {"source": f"{pmc_name} (B = 128, one entry per instantiation and launch shape; scaled by batch / 128)",
                        "hbm_bytes_per_launch_by_shape": {k: pj[k]["hbm_bytes_per_launch"] for k in used},
                        "mfma_util_by_shape": {k: round(pj[k]["mfma_util"], 4) for k in used},
                        "traffic_over_algorithmic_by_shape": {k: round(pj[k]["traffic_over_algorithmic"], 3) for k in used}}
@@ -282,7 +261,7 @@ def main():
                     "launches_per_step": n, "avg_launch_us": round(tot_t / n * 1e6, 1),
                     "event_pair_overhead_us": round(ev_overhead * 1e6, 2),
                     "avg_gflop_per_launch": round(tot_f / n / 1e9, 3),
-                    "share_of_step": round(tot_t / (elapsed / a.steps), 3),
+                    "share_of_step": round(tot_t / step_s, 3),
                     "symbols": symbols,
                     "note": ("as run: the weight-gradient kernels share the chip with these launches (second stream, "
                              "balanced to run side by side), so a launch's duration includes the time it shares the "
@@ -295,7 +274,7 @@ def main():
     if rank == 0 and world == 1 and roof is not None and ops.SIDE_STREAM:
         ops.SIDE_STREAM = False
         ops.KERNEL_TIMER = []
-        state, _ = exp.train_step(exp._train_rng, state, batches[-1])
+        state, _ = exp.train_step(exp._train_rng, state, batch)
         torch.cuda.synchronize()
         recs_alone = ops.KERNEL_TIMER
         mine = [(s_, e_, fl) for (nm, s_, e_, fl) in recs_alone if nm.split("<")[0] == roof["kernel"]]
@@ -325,22 +304,181 @@ def main():
                                          "tflops": round(v[1] / v[0] / 1e12, 1)} for k, v in per_lab.items()},
                          "measured": "one extra train step with the weight-gradient stream off (MULAN_SIDE_STREAM=0): no "
                                      "other kernel on the chip while a launch of this kernel runs"})
+    return state, roof
+
+
+def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f32_reference):
+    """W untimed + K timed train steps of one configuration (barrier + synchronize on both sides, MAX over ranks), then
+    the convolution kernel's roofline steps.  Returns a dict of raw results."""
+    import torch
+    import torch.distributed as dist
+    from mulan_amd import ops
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    config = load_config_file(cfg_path)
+    config.vdm_type = vdm_type
+    config.data.dataset = "synthetic"
+    if vfe:
+        config.model.velocity_from_epsilon = True
+    config.training.batch_size_train = B * world
+    config.training.batch_size_eval = B * world
+    config.training.substeps = 1
+    exp = Experiment_VDM(config)
+    dev = exp.device
+
+    g = torch.Generator().manual_seed(rank)
+    nb = min(steps + warmup, 24)                 # distinct resident batches (cycled: 24 x 393 KB)
+    batches = [{"images": torch.randint(0, 256, (B, 32, 32, 3), generator=g, dtype=torch.uint8).to(dev),
+                "labels": torch.zeros(B, dtype=torch.int32, device=dev),
+                "conditioning": torch.zeros(B, dtype=torch.uint8, device=dev)} for _ in range(max(1, nb))]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    state = exp.state
+    # One-time set-up outside the W + K steps (the counterpart of a compile step): the first call runs eagerly
+    # (kernel attributes, allocator), the second captures the HIP graph that every later call replays.  Without this a
+    # run with --warmup 0 or 1 would time the capture.
+    prime = 0
+    while exp.hip_graph and exp._graphed is None and prime < 2:
+        state, _ = exp.train_step(exp._train_rng, state, batches[0])
+        prime += 1
+    for i in range(warmup):
+        state, _ = exp.train_step(exp._train_rng, state, batches[i % len(batches)])
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        state, m = exp.train_step(exp._train_rng, state, batches[(warmup + i) % len(batches)])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    res = {"elapsed": elapsed, "last_bpd": float(m["scalars"]["train_bpd"]), "prime": prime,
+           "graph_used": bool(exp.hip_graph and exp._graphed is not None), "E": int(config.model.sm_n_embd),
+           "n_layer": int(config.model.sm_n_layer), "conv_mode": ops.CONV_MODE, "f32_mode": None}
+    state, res["roof"] = conv_roofline(exp, state, batches[-1], a, rank, world, B, res["E"], elapsed / steps)
     # ---- the same step with the exact-fp32 MFMA convolution kernels (MULAN_CONV_MODE=f32), for reference
-    if world == 1 and ops.CONV_MODE != "f32" and not a.no_f32_mode:
+    if f32_reference and world == 1 and ops.CONV_MODE != "f32":
         saved = ops.CONV_MODE
         ops.CONV_MODE = "f32"
         exp.hip_graph = False               # (the captured graph holds the split-operand kernels)
         state, _ = exp.train_step(exp._train_rng, state, batches[0])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        nref = max(2, a.steps // 2)
+        nref = max(2, min(steps // 2, 10))
         for i in range(nref):
-            state, _ = exp.train_step(exp._train_rng, state, batches[a.warmup + i % a.steps])
+            state, _ = exp.train_step(exp._train_rng, state, batches[i % len(batches)])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / nref
         ops.CONV_MODE = saved
-        f32_mode = {"value": round(B / dt, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "steps": nref,
-                    "note": "convolutions on v_mfma_f32_32x32x2_f32 (exact fp32 MFMA) instead of the split-operand kernels"}
+        res["f32_mode"] = {"value": round(B / dt, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 2), "steps": nref,
+                           "note": "convolutions on v_mfma_f32_32x32x2_f32 (exact fp32 MFMA) instead of the "
+                                   "split-operand kernels"}
+    exp._graphed = None
+    del exp, state, batches
+    torch.cuda.empty_cache()
+    return res
+
+
+def dense_eval_workload(images, T):
+    """BASELINE configs[4] per GPU: eval_bpd --bpd_eval_method=dense on the ImageNet-32 configuration -- every test
+    image is a batch of T copies through loss_fn(is_train=False) under one key (ldm/notebook_utils.py:176-191)"""
+    import torch
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    from mulan_amd.rng import PRNGKey
+    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "imagenet32.py"))
+    config.data.dataset = "synthetic"
+    config.vdm_type = "mulan_velocity"
+    config.model.velocity_from_epsilon = True
+    config.training.batch_size_train = 8
+    config.training.batch_size_eval = 8
+    exp = Experiment_VDM(config)
+    rng = PRNGKey(0)
+    packer = exp.state.param_packer("ema")
+    times = []
+    with torch.no_grad():
+        if packer is not None:
+            packer.refresh()                 # the weights are constant over the evaluation: prepared once
+        for i in range(images + 1):          # (the first image is the warm-up)
+            img = torch.randint(0, 256, (1, 32, 32, 3), dtype=torch.uint8, device=exp.device)
+            tiled = {"images": img.expand(T, 32, 32, 3).contiguous(),
+                     "labels": torch.zeros(T, dtype=torch.int32, device=exp.device),
+                     "conditioning": torch.zeros(T, dtype=torch.uint8, device=exp.device)}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bpd, _ = exp.loss_fn(exp.state.ema_params, tiled, i, rng=rng, is_train=False)
+            bpd = float(bpd)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        if packer is not None:
+            packer.invalidate()
+    dt = sum(times[1:]) / images
+    del exp
+    torch.cuda.empty_cache()
+    return {"workload": f"eval_bpd dense VLB, ldm/configs/imagenet32.py (E=256, velocity_from_epsilon), T={T} copies "
+                        f"per image, {images} images after one warm-up image, forward only, EMA weights",
+            "metric": "dense-eval seconds per test image", "value": round(dt, 4), "unit": "s/image",
+            "higher_is_better": False, "forward_images_per_s": round(T / dt, 1),
+            "model_tflops": round(T / dt * FWD_GFLOP_BY_WIDTH[256] / 1e3, 1), "bpd_random_init": round(bpd, 4)}
+
+
+def main():
+    a = parse()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(a.config, a.vdm_type, a.cpu_batch, a.cpu_steps)), flush=True)
+        return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
+    import torch
+    import torch.distributed as dist
+    from mulan_amd import ops, parallel
+
+    rank, world, local = parallel.init_distributed()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    backend = dist.get_backend() if world > 1 else None
+    if world > 1:
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    strong = a.global_batch > 0
+    if strong and a.global_batch % world != 0:
+        raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} ranks")
+    B = a.global_batch // world if strong else a.per_gpu_batch
+    head = train_workload(a, rank, world, a.config, a.vdm_type, a.vfe, B, a.steps, a.warmup, not a.no_f32_mode)
+    elapsed, roof = head["elapsed"], head["roof"]
+
+    # ---- the other BASELINE configurations at their per-GPU size (driver-timed with the headline: "configs")
+    also = a.also_configs if a.also_configs is not None else world == 1
+    extra = None
+    if also:
+        extra = {}
+        cif = os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")
+        inet = os.path.join(ROOT, "ldm", "configs", "imagenet32.py")
+        for key, (cfgp, vt, vfe, bsz, label) in {
+                "3": (cif, "mulan_velocity", False, 64, "BASELINE configs[2]: MuLAN-velocity CIFAR-10, global batch 512 "
+                                                        "over 8 GPUs = 64 images per GPU"),
+                "4": (inet, "mulan_velocity", True, 128, "BASELINE configs[3]: MuLAN-velocity ImageNet-32 (E=256), "
+                                                         "velocity_from_epsilon, global batch 1024 over 8 GPUs = 128 per GPU")}.items():
+            r = train_workload(a, rank, world, cfgp, vt, vfe, bsz, a.also_steps, 3, False)
+            ips = bsz * world * a.also_steps / r["elapsed"]
+            gf = FWD_GFLOP_BY_WIDTH[r["E"]]
+            rr = r["roof"] or {}
+            extra[key] = {"workload": label + f"; full train step, {world} GPU(s) x {bsz}", "value": round(ips, 2),
+                          "unit": "images/s", "ms_per_step": round(r["elapsed"] / a.also_steps * 1e3, 2),
+                          "steps": a.also_steps, "warmup": 3, "hip_graph": r["graph_used"],
+                          "model_tflops_per_gpu": round(ips / world * 3 * gf / 1e3, 2),
+                          "conv_kernel": {k: rr.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us",
+                                                                 "launches_per_step", "measured")},
+                          "conv_kernel_as_run_frac": (rr.get("as_run") or {}).get("frac"),
+                          "last_train_bpd": round(r["last_bpd"], 4)}
+        if world == 1:
+            extra["5"] = dense_eval_workload(2, 1000)
+            extra["5"]["workload"] = "BASELINE configs[4]: " + extra["5"]["workload"]
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -360,10 +498,11 @@ def main():
             cpu = {"value": None, "error": f"cpu baseline exceeded {a.cpu_timeout}s"}
     ms = elapsed / a.steps * 1e3
     value = B * world * a.steps / elapsed
-    FWD_GFLOP_PER_IMAGE = FWD_GFLOP_BY_WIDTH.get(int(config.model.sm_n_embd), 57.78)
+    fwd_gflop = FWD_GFLOP_BY_WIDTH.get(head["E"], FWD_GFLOP_PER_IMAGE)
     out = {
         "metric": "train images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
-        "steps": a.steps, "warmup": a.warmup, "setup_steps": prime, "ms_per_step": round(ms, 2), "higher_is_better": True,
+        "steps": a.steps, "warmup": a.warmup, "setup_steps": head["prime"], "ms_per_step": round(ms, 2),
+        "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "conv_mode": ops.CONV_MODE + {
             "bf16x6": ": fp32 operands split into 3 bf16 pieces, 6 bf16 MFMA passes, fp32 accumulate",
@@ -372,19 +511,24 @@ def main():
                      "reference requests, ldm/main.py:39)",
             "f32": ": exact fp32 MFMA"}.get(ops.CONV_MODE, ""),
         "config": {"workload": f"MuLAN ({a.vdm_type}) config ldm/configs/{os.path.basename(a.config)} "
-                               f"(E={config.model.sm_n_embd}, {config.model.sm_n_layer}+2+{config.model.sm_n_layer + 1} "
+                               f"(E={head['E']}, {head['n_layer']}+2+{head['n_layer'] + 1} "
                                f"ResnetBlocks{', velocity_from_epsilon' if a.vfe else ''}), full train step "
                                f"(fwd+bwd+all-reduce+AdamW/EMA), " +
                                (f"global batch {B * world} fixed (strong scaling), {B}/GPU" if strong else
                                 f"batch {B}/GPU (weak scaling)"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
-        "model_tflops_per_gpu": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3, 2),
-        "model_roofline_frac": round(value / world * 3 * FWD_GFLOP_PER_IMAGE / 1e3 /
+        "collective": ({"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                        "note": "torch.distributed backend 'nccl' is RCCL on ROCm; bucketed gradient all-reduce on a "
+                                "side stream, overlapped with the backward pass"} if world > 1 else None),
+        "model_tflops_per_gpu": round(value / world * 3 * fwd_gflop / 1e3, 2),
+        "model_roofline_frac": round(value / world * 3 * fwd_gflop / 1e3 /
                                      {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(
                                          ops.CONV_MODE, PEAK_F32_MFMA_TFLOPS), 4),
-        "last_train_bpd": round(last_bpd, 4),
-        "hip_graph": graph_used,
-        "roofline": roof, "f32_mfma_mode": f32_mode, "cpu_baseline": cpu,
+        "last_train_bpd": round(head["last_bpd"], 4),
+        "hip_graph": head["graph_used"],
+        "oracle_pin": "unpinned: the reference has no golden vectors, JAX / Flax are not installable here and no "
+                      "released checkpoint is in the image (tools/verify_checkpoint.py pins it in one command)",
+        "roofline": roof, "f32_mfma_mode": head["f32_mode"], "cpu_baseline": cpu, "configs": extra,
     }
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -9,7 +9,9 @@
  *   - all tensors are contiguous fp32 device buffers unless stated; images are NHWC with W == 32 and
  *     H*W == 1024 (the model never resamples: ldm/model_vdm.py:353-371), matrices are row-major;
  *   - the caller owns every buffer including workspaces; the library never allocates, frees or
- *     synchronises; every call is asynchronous on `stream` and re-entrant;
+ *     synchronises; every call is asynchronous on `stream` and re-entrant; the production entry points read no
+ *     process-global state (mulan_set_tuning / mulan_set_debug_buffer are developer switches for kernel-variant A/B
+ *     runs and timing probes: all zero by default, never set by the product path);
  *   - the return value is a hipError_t as int (0 == hipSuccess); no exceptions cross the boundary;
  *   - `hipStream_t` is passed as an opaque pointer so plain C callers need no HIP headers.
  */
@@ -100,10 +102,13 @@ int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float*
  * the per-image maxima the planes were scaled with.  Needs C % 128 == 0 and N % 128 == 0.
  * ymax (optional, [B][16]): the maxima of the convolution's own output, for whichever f16x3 kernel reads it next. */
 size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C);
-size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N);
+/* share_chip (0 / 1; the same value for the workspace query and the launch): 1 = the caller runs this launch beside
+ * another stream's matrix-core kernels (the train step's weight-gradient stream beside the input-gradient chain): the
+ * launch then uses about half as many blocks, so that both streams keep running side by side. */
+size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip);
 int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
                                      float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
-                                     mulan_stream_t stream);
+                                     int share_chip, mulan_stream_t stream);
 
 /* Once-per-step weight preparation for all eligible parameter leaves of the flat parameter buffer in two launches
  * (instead of maxima + pack per layer and direction).  Leaf record = 8 x int64: element offset in `flat`, kind (0: 3x3
@@ -132,10 +137,10 @@ int mulan_linear_f16x3(const float* x1, const unsigned* x1max, const float* x2, 
  * of the two maxima).  Its weight gradient dw[K1+K2, N] (+)= [x1|x2]^T dy then comes from those planes and the planes of
  * dy handed on by the convolution that consumed the same dy (nin_shortcut and conv2 of a ResnetBlock share dy):
  * H x W = 32 x 32 pixels per image; C = K1 + K2 and N multiples of 128; xmax = elementwise max of x1max, x2max. */
-size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N);
+size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip);
 int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
                                     float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
-                                    mulan_stream_t stream);
+                                    int share_chip, mulan_stream_t stream);
 /* The attention products (lax.dot_general in dot_product_attention, model_vdm.py:775-796, and their autodiff) on the
  * same kernels, one operand per image:  y[b] = x[b] @ W[b] (+ res) with W[b] packed by the batched pack (w: batch
  * operands [K, N], or [N, K] with transpose = 1; wmax [batch][16] = mulan_absmax_rows(w, batch rows)) at
@@ -283,6 +288,11 @@ int mulan_decode_argmax(const float* z0, const float* g0, unsigned char* out, si
 /* sample_softmax = True: jax.random.categorical over the same logits (Gumbel-max with Philox4x32-10 draws) */
 int mulan_decode_sample(const float* z0, const float* g0, unsigned char* out, size_t n, int g_per_sample,
                         unsigned long long seed, unsigned long long offset, mulan_stream_t stream);
+/* EncDec.decode as a table (model_vdm.py:282-296): out[n][256] = log_softmax over the 256 bins of
+ * -0.5 ((z - v_j) exp(-0.5 g_0))^2 per sub-pixel (z as given: no rescaling).  Module-surface only: the train / eval
+ * path evaluates the bin of x inside mulan_qsample_fwd and never materialises the table. */
+int mulan_decode_logprobs(const float* z, const float* g0, float* out, size_t n, int g_per_sample,
+                          mulan_stream_t stream);
 /* out[r] = mean(x[r, :])  (VDM._get_score_model_gt, model_mulan_velocity.py:141-146) */
 int mulan_rowmean(const float* x, float* out, int rows, int cols, mulan_stream_t stream);
 

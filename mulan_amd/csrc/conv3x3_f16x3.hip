@@ -1026,14 +1026,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
   if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
 }
 
-int wgrad_splits_p(int B, int H, int C, int N) {   // 3 kh blocks per (tile, pixel range); S % 8 == 0 keeps them on one XCD
+int wgrad_splits_p(int B, int H, int C, int N, int share_chip) {   // 3 kh blocks per (tile, pixel range); S % 8 == 0 keeps them on one XCD
   const int tiles = (C / WG3_T) * (N / WG3_T);
   const int pairs = B * (H / WG_ROWS);
-  // 240 blocks when the launch has the chip to itself; tune[9] = 1 (set by the caller while the launch shares the chip
-  // with another stream's kernels -- the train step's weight-gradient stream): 120 for the one- and two-tile shapes, so
-  // that the other stream keeps half of the CUs and both run side by side (a block owns its CU); four tiles and more
-  // keep 240 (measured: E = 256 is slower with fewer).  tune[1] > 0: explicit target (dev).
-  int target = g_mulan_tune[9] == 1 && tiles <= 2 ? 120 : 240;
+  // 240 blocks when the launch has the chip to itself; share_chip = 1 (an ARGUMENT of the entry point: the caller says
+  // that the launch shares the chip with another stream's kernels -- the train step's weight-gradient stream): 120 for
+  // the one- and two-tile shapes, so that the other stream keeps half of the CUs and both run side by side (a block
+  // owns its CU); four tiles and more keep 240 (measured: E = 256 is slower with fewer).  tune[1] > 0: explicit
+  // target (dev only).
+  int target = share_chip == 1 && tiles <= 2 ? 120 : 240;
   if (g_mulan_tune[1] > 0) target = g_mulan_tune[1];
   int S = target / (3 * tiles);
   if (S >= 8 && g_mulan_tune[6] != 1) S &= ~7;      // tune[6] = 1: dev switch, no XCD alignment
@@ -1244,16 +1245,16 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, co
   MULAN_CHECK_LAUNCH();
 }
 
-MULAN_API size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N) {
+MULAN_API size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip) {
   if (W != kW || H % WG_ROWS != 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
-  return (size_t)wgrad_splits_p(B, H, C, N) * 9 * C * N * sizeof(float);
+  return (size_t)wgrad_splits_p(B, H, C, N, share_chip) * 9 * C * N * sizeof(float);
 }
 
 // dw[3,3,C,N] (+)= sum x (x) dy from the split planes written by mulan_conv3x3_fwd_f16x3 (xs: of the forward input,
 // dys: of the output gradient, written by the input-gradient convolution); needs C % 128 == 0 and N % 128 == 0.
 MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys,
                                                const unsigned* dymax, float* dw, float* workspace, int B, int H, int W,
-                                               int C, int N, int accumulate, hipStream_t stream) {
+                                               int C, int N, int accumulate, int share_chip, hipStream_t stream) {
   if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0 || !xs || !dys || !xmax || !dymax ||
       (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
     return (int)hipErrorInvalidValue;
@@ -1264,7 +1265,7 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  const int S = wgrad_splits_p(B, H, C, N);
+  const int S = wgrad_splits_p(B, H, C, N, share_chip);
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
                B, H, C, N, S, g_mulan_debug_buffer};
   hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<3>, dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256), WG3_SMEM + 64,
@@ -1294,24 +1295,24 @@ MULAN_API int mulan_param_pack_f16x3(const float* flat, const long long* leaves,
 // ---- weight gradient of a per-pixel dense layer from split planes: dw[C, N] (+)= x^T dy, x planes [B][C/16][HW][2][16]
 // (handed on by mulan_linear_f16x3), dy planes [B][N/16][HW][2][16] (handed on by the convolution that consumed the same
 // dy); xmax / dymax are the per-image maxima the planes were scaled with.  Needs C % 128 == 0, N % 128 == 0.
-static int linear_wgrad_splits(int B, int H, int C, int N) {
+static int linear_wgrad_splits(int B, int H, int C, int N, int share_chip) {
   const int tiles = (C / WG3_T) * (N / WG3_T);
   const int pairs = B * (H / WG_ROWS);
-  const int target = g_mulan_tune[9] == 1 ? 160 : 240;     // (shared chip, see wgrad_splits_p: scan 64 ... 240)
+  const int target = share_chip == 1 ? 160 : 240;     // (shared chip, see wgrad_splits_p: scan 64 ... 240)
   int S = target / tiles;
   if (S < 1) S = 1;
   if (S > pairs) S = pairs;
   return S;
 }
 
-MULAN_API size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N) {
+MULAN_API size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip) {
   if (W != kW || H % WG_ROWS != 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
-  return (size_t)linear_wgrad_splits(B, H, C, N) * C * N * sizeof(float);
+  return (size_t)linear_wgrad_splits(B, H, C, N, share_chip) * C * N * sizeof(float);
 }
 
 MULAN_API int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys,
                                               const unsigned* dymax, float* dw, float* workspace, int B, int H, int W,
-                                              int C, int N, int accumulate, hipStream_t stream) {
+                                              int C, int N, int accumulate, int share_chip, hipStream_t stream) {
   if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0 || !xs || !dys || !xmax || !dymax ||
       (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
     return (int)hipErrorInvalidValue;
@@ -1322,7 +1323,7 @@ MULAN_API int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xm
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  const int S = linear_wgrad_splits(B, H, C, N);
+  const int S = linear_wgrad_splits(B, H, C, N, share_chip);
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
                B, H, C, N, S, g_mulan_debug_buffer};
   hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<1>, dim3(S, 1, (C / WG3_T) * (N / WG3_T)), dim3(256),

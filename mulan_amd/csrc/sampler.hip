@@ -63,6 +63,34 @@ __global__ void decode_argmax_kernel(const float* __restrict__ z0, const float* 
   }
 }
 
+// EncDec.decode (ldm/model_vdm.py:282-296) as a table: out[i, j] = log_softmax_j(-0.5 ((z_i - v_j) exp(-0.5 g_i))^2), the 256
+// decoder log-probabilities of every sub-pixel.  One wave per element (4 bins per lane, one 1 KB row written per wave);
+// the train / eval path never materialises this table (mulan_qsample_fwd evaluates the bin of x in registers): this
+// entry point backs the reference's module-level EncDec.decode / EncDec.__call__.
+__global__ __launch_bounds__(256) void decode_logprobs_kernel(const float* __restrict__ z, const float* __restrict__ g0,
+                                                              float* __restrict__ out, size_t n, int g_per_sample) {
+  const int lane = threadIdx.x & 63;
+  for (size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (size_t)gridDim.x * 4) {
+    const float g = g0[g_per_sample ? i / (size_t)g_per_sample : i];
+    const float zi = z[i], istd = expf(-0.5f * g);
+    float l[4], mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = 2.f * (((float)(lane * 4 + e) + 0.5f) / 256.f) - 1.f;
+      const float u = (zi - v) * istd;
+      l[e] = -0.5f * u * u;
+      mx = fmaxf(mx, l[e]);
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = expf(l[0] - mx) + expf(l[1] - mx) + expf(l[2] - mx) + expf(l[3] - mx);
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    float4 o4 = make_float4(l[0] - lse, l[1] - lse, l[2] - lse, l[3] - lse);
+    *reinterpret_cast<float4*>(out + i * 256 + lane * 4) = o4;
+  }
+}
+
 // out[r] = mean of x[r, 0:cols]  (VDM._get_score_model_gt, ldm/model_mulan_velocity.py:141-146); one wave per row
 __global__ __launch_bounds__(256) void rowmean_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
                                                       int cols) {
@@ -91,6 +119,15 @@ MULAN_API int mulan_decode_argmax(const float* z0, const float* g0, unsigned cha
   if (n == 0 || g_per_sample < 0) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(decode_argmax_kernel, dim3(grid_for(n)), dim3(256), 0, stream, z0, g0, out, n, g_per_sample, 0, 0ull,
                      0ull);
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_decode_logprobs(const float* z, const float* g0, float* out, size_t n, int g_per_sample,
+                                    hipStream_t stream) {
+  if (n == 0 || g_per_sample < 0 || !z || !g0 || !out) return (int)hipErrorInvalidValue;
+  const size_t blocks = (n + 3) / 4;
+  hipLaunchKernelGGL(decode_logprobs_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, stream, z, g0,
+                     out, n, g_per_sample);
   MULAN_CHECK_LAUNCH();
 }
 

@@ -30,8 +30,8 @@ SIGNATURES = {
     "mulan_conv3x3_pack_f16x3": [P, P, P, I, I, I, P],
     "mulan_conv3x3_fwd_f16x3": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],
     "mulan_conv3x3_planes_bytes": [I, I, I, I],
-    "mulan_conv3x3_wgrad_f16x3_planes_workspace": [I, I, I, I, I],
-    "mulan_conv3x3_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "mulan_conv3x3_wgrad_f16x3_planes_workspace": [I, I, I, I, I, I],
+    "mulan_conv3x3_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "mulan_conv3x3_wgrad_f16x3_workspace": [I, I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_param_maxima": [P, P, I, P, P],
@@ -39,8 +39,8 @@ SIGNATURES = {
     "mulan_linear_pack_f16x3_bytes": [I, I],
     "mulan_linear_pack_f16x3": [P, P, P, I, I, I, P],
     "mulan_linear_f16x3": [P, P, P, P, I, I, P, P, P, P, P, P, P, I, I, I, I, P],
-    "mulan_linear_wgrad_f16x3_planes_workspace": [I, I, I, I, I],
-    "mulan_linear_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "mulan_linear_wgrad_f16x3_planes_workspace": [I, I, I, I, I, I],
+    "mulan_linear_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P],
     "mulan_gemm_workspace": [I, I, I, I],
     "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P],
@@ -85,6 +85,7 @@ SIGNATURES = {
     "mulan_ancestral_step": [P, P, P, P, P, P, Z, I, I, P],
     "mulan_decode_argmax": [P, P, P, Z, I, P],
     "mulan_decode_sample": [P, P, P, Z, I, U, U, P],
+    "mulan_decode_logprobs": [P, P, P, Z, I, P],
     "mulan_rowmean": [P, P, I, I, P],
     "mulan_ode_drift": [P, P, P, P, P, P, P, Z, I, I, P],
     "mulan_ode_div": [P, P, P, P, P, I, I, I, I, P],

@@ -755,14 +755,49 @@ class NoiseSchedule_polynomial_fixedend(_Module):
 
 class EncDec:
     """model_vdm.EncDec (ldm/model_vdm.py:265-303): no parameters.  encode(x uint8) -> f in (-1, 1);
-    logprob(x, z, g_0) -> [B] sum over sub-pixels of the 256-bin decoder log-probabilities (the fused q-sample kernel
-    evaluated at eps_0 = 0 around z: -loss_recon)."""
+    decode(z, g_0) -> [..., 256] decoder log-probabilities; logprob(x, z, g_0) -> [B] sum over sub-pixels of the
+    log-probability of x's bin (the fused q-sample kernel, which never builds the 256-bin table)."""
 
     def __init__(self, config: VDMConfig):
         self.config = config
 
+    def __call__(self, x, g_0):
+        """EncDec.__call__ (:269-272): decode(encode(x), g_0)"""
+        return self.decode(self.encode(x), g_0)
+
     def encode(self, x):
         return encode_images(x.reshape(x.shape[0], D).to(torch.uint8)).reshape(*x.shape)
+
+    def _g(self, g_0, z):
+        """g_0 as the reference accepts it -- a scalar, [B], or the shape of z -- as [B] or [B, D] fp32"""
+        B = z.shape[0]
+        g = torch.as_tensor(g_0, dtype=torch.float32, device=z.device)
+        if g.numel() == 1:
+            return g.reshape(1).expand(B).contiguous()
+        if g.numel() == B:
+            return g.reshape(B).contiguous()
+        if g.numel() != z.numel():
+            raise ValueError(f"g_0 of shape {tuple(g.shape)} does not broadcast over z {tuple(z.shape)}")
+        return g.reshape(B, D).contiguous()
+
+    def decode(self, z, g_0):
+        """EncDec.decode (:282-296): log_softmax over the 256 bins of -0.5 ((z - v_j) exp(-g_0 / 2))^2, shape
+        z.shape + (256,)"""
+        return ops.decode_logprobs(z.reshape(z.shape[0], D), self._g(g_0, z)).reshape(*z.shape, self.config.vocab_size)
+
+    def logprob(self, x, z, g_0):
+        """EncDec.logprob (:298-303): sum over (H, W, C) of decode(z, g_0)[x] -> [B].  Evaluated by mulan_qsample_fwd
+        (its reconstruction term at z_0 = f + exp(g_0 / 2) eps_0 with eps_0 chosen so that z_0 = z), no [.., 256]
+        tensor.  z may carry a gradient (the kernel's backward covers g_0; z is a leaf here, like in the train path
+        where z_0 is sampled, not learned)."""
+        B = z.shape[0]
+        xu = x.reshape(B, D).round().to(torch.uint8).contiguous()
+        g = self._g(g_0, z)
+        g = g if g.dim() == 2 else g[:, None].expand(B, D).contiguous()
+        f = encode_images(xu)
+        eps_0 = (z.reshape(B, D).to(torch.float32) - f) * torch.exp(-0.5 * g)
+        _, _, recon, _, _, _ = ops.qsample(xu, g, g, g, eps_0, torch.zeros_like(eps_0))
+        return -recon
 
     def decode_argmax(self, z, g_0):
         """argmax over the 256 bins of decode(z, g_0) (:282-293); g_0 per sample [B] or per element"""

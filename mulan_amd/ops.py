@@ -59,7 +59,8 @@ SIDE_STREAM = _os.environ.get("MULAN_SIDE_STREAM", "1") == "1"
 # side launches whose operands are kept alive before the main stream waits for the oldest (2: +1.0 ms, 16: +0.2 ms per step)
 SIDE_DEPTH = int(_os.environ.get("MULAN_SIDE_DEPTH", "6"))
 # While the weight-gradient launches share the chip with the input-gradient chain they aim for 120 blocks instead of
-# 240 (library knob 9, see wgrad_splits_p): a weight-gradient block owns its CU, so 240 of them leave 16 CUs to the
+# 240 (the `share_chip` argument of the plane-fed weight-gradient entry points, see wgrad_splits_p; no library-global
+# state is involved): a weight-gradient block owns its CU, so 240 of them leave 16 CUs to the
 # main stream; with 120 the launch takes about as long as the main stream's kernels of the same layer (GroupNorm
 # backward + input-gradient convolution) and both streams keep running side by side: -2.9 % per step (scan 96 ... 240,
 # DESIGN 3.2).  MULAN_SIDE_WGRAD_SHARE=0 keeps 240.
@@ -73,16 +74,17 @@ class weight_gradient_stream:
 
     def __enter__(self):
         _SIDE["active"] = SIDE_STREAM
-        if SIDE_STREAM and SIDE_WGRAD_SHARE:
-            call("mulan_set_tuning", 9, 1)
         return self
 
     def __exit__(self, *exc):
-        if _SIDE["active"] and SIDE_WGRAD_SHARE:
-            call("mulan_set_tuning", 9, 0)
         _SIDE["active"] = False
         side_join()
         return False
+
+
+def _share_chip():
+    """the share_chip argument of the plane-fed weight-gradient launches: 1 inside a weight_gradient_stream() scope"""
+    return int(bool(_SIDE["active"] and SIDE_WGRAD_SHARE))
 
 
 def side_stream():
@@ -370,12 +372,13 @@ def conv3x3_wgrad_raw(x, dy, out=None, xmax=None, dymax=None):
 
 def conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, B, C, N, out=None):
     """dw from the split planes of x (written by the forward conv) and of dy (written by the input-gradient conv)"""
-    nbytes = lib.load().mulan_conv3x3_wgrad_f16x3_planes_workspace(B, H, W, C, N)
+    share = _share_chip()
+    nbytes = lib.load().mulan_conv3x3_wgrad_f16x3_planes_workspace(B, H, W, C, N, share)
     ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((3, 3, C, N), device=xs.device, dtype=torch.float32)
     _timed("conv3x3_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * 9 * C * N,
            lambda: call("mulan_conv3x3_wgrad_f16x3_planes", ptr(xs), ptr(xmax), ptr(dys), ptr(dymax), ptr(dw), ptr(ws), B,
-                        H, W, C, N, 0, stream()))
+                        H, W, C, N, 0, share, stream()))
     return dw
 
 
@@ -589,12 +592,13 @@ def linear_f16x3_raw(x1, x2, wp, wmax, N1, N2, bias=None, res=None, planes=False
 def linear_wgrad_planes_raw(xs, xmax, dys, dymax, B, K, N, out=None):
     """dw[K,N] = [x1|x2]^T dy from the planes handed on by linear_f16x3_raw (xs) and by the convolution that consumed
     the same dy (dys)"""
-    nbytes = lib.load().mulan_linear_wgrad_f16x3_planes_workspace(B, H, W, K, N)
+    share = _share_chip()
+    nbytes = lib.load().mulan_linear_wgrad_f16x3_planes_workspace(B, H, W, K, N, share)
     ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((K, N), device=xs.device, dtype=torch.float32)
     _timed("linear_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * K * N,
            lambda: call("mulan_linear_wgrad_f16x3_planes", ptr(xs), ptr(xmax), ptr(dys), ptr(dymax), ptr(dw), ptr(ws), B, H,
-                        W, K, N, 0, stream()))
+                        W, K, N, 0, share, stream()))
     return dw
 
 
@@ -1584,6 +1588,16 @@ def decode_argmax(z0, g0):
     out = torch.empty(z0.shape, device=z0.device, dtype=torch.uint8)
     per = z0.numel() // g0.numel()
     call("mulan_decode_argmax", ptr(z0), ptr(g0), ptr(out), z0.numel(), 0 if per == 1 else per, stream())
+    return out
+
+
+def decode_logprobs(z, g0):
+    """[..., 256] decoder log-probabilities of every element of z (EncDec.decode, ldm/model_vdm.py:282-296); g0 per
+    element or one value per sample (broadcast over the trailing elements)"""
+    z, g0 = _c(z.to(torch.float32)), _c(g0.to(torch.float32))
+    out = torch.empty(tuple(z.shape) + (256,), device=z.device, dtype=torch.float32)
+    per = z.numel() // g0.numel()
+    call("mulan_decode_logprobs", ptr(z), ptr(g0), ptr(out), z.numel(), 0 if per == 1 else per, stream())
     return out
 
 

@@ -458,7 +458,8 @@ def test_cifar10_aug_stream_flags_augmented_images(tmp_path, monkeypatch):
 def test_plane_hand_over_gating_and_backward_scope(monkeypatch):
     """host logic of the two round-2 schedulers, no GPU needed: which (GroupNorm, convolution) pairs take the plane
     hand-over, and that the backward scope of the weight-gradient stream arms / disarms itself (also when the body
-    raises) and switches the library's shared-chip block count with it."""
+    raises); the shared-chip block count of the weight-gradient launches is an ARGUMENT derived from that scope
+    (ops._share_chip), no library-global switch is touched."""
     from mulan_amd import ops
     monkeypatch.setattr(ops, "CONV_MODE", "f16x3")
     monkeypatch.setattr(ops, "GN_CONV_PLANES", True)
@@ -475,19 +476,22 @@ def test_plane_hand_over_gating_and_backward_scope(monkeypatch):
     monkeypatch.setattr(ops, "SIDE_STREAM", True)
     monkeypatch.setattr(ops, "SIDE_WGRAD_SHARE", True)
     assert not ops._side_ok(None)
+    assert ops._share_chip() == 0
     with ops.weight_gradient_stream():
-        assert ops._SIDE["active"] and calls == [("mulan_set_tuning", 9, 1)]
+        assert ops._SIDE["active"] and ops._share_chip() == 1
         assert not ops._side_ok(None)        # no sink in the flat gradient buffer: stays on the current stream
-    assert not ops._SIDE["active"] and calls[-1] == ("mulan_set_tuning", 9, 0)
+    assert not ops._SIDE["active"] and ops._share_chip() == 0
     with pytest.raises(RuntimeError):
         with ops.weight_gradient_stream():
             raise RuntimeError("backward failed")
-    assert not ops._SIDE["active"] and calls[-1] == ("mulan_set_tuning", 9, 0)
-    monkeypatch.setattr(ops, "SIDE_STREAM", False)
-    n = len(calls)
+    assert not ops._SIDE["active"] and ops._share_chip() == 0
+    monkeypatch.setattr(ops, "SIDE_WGRAD_SHARE", False)
     with ops.weight_gradient_stream():
-        assert not ops._SIDE["active"]
-    assert len(calls) == n
+        assert ops._SIDE["active"] and ops._share_chip() == 0
+    monkeypatch.setattr(ops, "SIDE_STREAM", False)
+    with ops.weight_gradient_stream():
+        assert not ops._SIDE["active"] and ops._share_chip() == 0
+    assert not any(c[0] == "mulan_set_tuning" for c in calls)       # the product path never touches the dev switches
 
 
 # ------------------------------------------------------------------------------ round 3: schedule, stream sync, hazards
@@ -567,3 +571,32 @@ def test_no_mfma_data_hazard_in_the_built_objects(built_lib):
         pytest.skip("llvm-objdump not in this image")
     found = scan.scan_objects()
     assert found == [], found[:5]
+
+
+def test_bench_self_launches_for_several_gpus(monkeypatch):
+    """`python bench.py --gpus 8` without WORLD_SIZE in the environment starts `python -m torch.distributed.run
+    --nproc-per-node 8 ... bench.py <same arguments>` as a CHILD process (the parent never initialises the GPU) and
+    exits with the child's code; with WORLD_SIZE set (it is one of the ranks) it does not."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "torch.cuda" not in sys.modules or not __import__("torch").cuda.is_initialized()

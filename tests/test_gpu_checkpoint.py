@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_flax_checkpoint_through_eval_bpd_matches_oracle(tmp_path, config_file, vdm_type, vfe):
     import importlib
     import ldm.eval_bpd
-    import verify_checkpoint as vc
+    from tests import verify_checkpoint as vc
     from mulan_amd import model as M
     from mulan_amd.config import load_config_file
     from mulan_amd.rng import PRNGKey

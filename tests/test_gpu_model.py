@@ -444,13 +444,15 @@ def test_gradient_sink_equals_autograd_accumulation():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("graph", ["", "1"])
-def test_bench_two_ranks_share_one_gpu(graph):
+@pytest.mark.parametrize("graph,launcher", [("", "self"), ("1", "torchrun")])
+def test_bench_two_ranks_share_one_gpu(graph, launcher):
     """bench.py's N > 1 control flow (sharded batches, bucketed side-stream all-reduce, barriers, max-over-ranks timing,
     rank-0 JSON) with two ranks on the one GPU of this box.  RCCL refuses two ranks per device, so the collective
     backend is gloo over the device tensors here; the calls are the same torch.distributed ones.  graph = "": the
     multi-rank default (eager step, all-reduce overlapped with backward); "1": MULAN_HIP_GRAPH=1 (replayed backward,
-    collectives and optimizer behind it)."""
+    collectives and optimizer behind it).  launcher = "self": plain `python bench.py --gpus 2` -- the bench starts
+    torch.distributed.run itself as a child process and relays rank 0's line (the reference needs no launcher either,
+    ldm/experiment.py:89-95); "torchrun": the driver's command line."""
     import json
     import os
     import socket
@@ -462,19 +464,24 @@ def test_bench_two_ranks_share_one_gpu(graph):
     port = s.getsockname()[1]
     s.close()
     env = {**os.environ, "MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"}
-    env.pop("MULAN_HIP_GRAPH", None)
+    for k in ("MULAN_HIP_GRAPH", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
     if graph:
         env["MULAN_HIP_GRAPH"] = graph
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8"],
-                       capture_output=True, text=True, timeout=840, env=env, cwd=root)
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8"]
+    if launcher == "self":
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=840, env=env, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
-    assert out["roofline"] is not None and out["cpu_baseline"] is None
+    assert out["roofline"] is not None and out["cpu_baseline"] is None and out["configs"] is None
     assert out["hip_graph"] == bool(graph)
+    assert out["collective"]["backend"] == "gloo" and out["collective"]["rccl_ranks"] == 0    # (nccl on a multi-GPU node)
 
 
 @pytest.mark.timeout(900)
@@ -634,6 +641,23 @@ def test_module_surface_matches_oracle(unet_type):
         x = torch.tensor(rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8))
         f = mv.EncDec(cfg).encode(x.cuda())
         assert torch.equal(f.cpu().double(), tr.encode(x.double()))
+        # EncDec.decode / logprob / __call__ (ldm/model_vdm.py:269-303) with per-element, per-sample and scalar g_0
+        ed = mv.EncDec(cfg)
+        zz = torch.tensor(rng.uniform(-1.3, 1.3, (B, 32, 32, 3)))
+        for g0 in (torch.tensor(rng.uniform(-13.5, -6.0, (B, 32, 32, 3))), torch.tensor(rng.uniform(-13.5, -6.0, B)), -9.7):
+            g_np = g0.numpy() if torch.is_tensor(g0) else g0
+            g_bc = g_np[:, None, None, None] * np.ones((1, 32, 32, 3)) if np.ndim(g_np) == 1 else g_np
+            want_lp = onp.decode_logprobs(zz.float().double().numpy(), np.float32(g_bc).astype(np.float64))
+            g_dev = g0.float().cuda() if torch.is_tensor(g0) else g0
+            got_lp = ed.decode(zz.float().cuda(), g_dev)
+            assert got_lp.shape == (B, 32, 32, 3, 256)
+            assert float(np.abs(got_lp.cpu().double().numpy() - want_lp).max()) < 2e-3 * (1 + 0)   # logits reach -1e5: fp32
+            assert float(np.abs(np.exp(got_lp.cpu().double().numpy()).sum(-1) - 1).max()) < 1e-5
+            want = onp.logprob(x.numpy(), zz.float().double().numpy(), np.float32(g_bc).astype(np.float64))
+            got = ed.logprob(x.cuda(), zz.float().cuda(), g_dev)
+            assert got.shape == (B,) and rel(got, torch.tensor(want)) < 2e-5, (got, want)
+        g1 = torch.tensor(rng.uniform(-13.5, -6.0, B))
+        assert torch.equal(ed(x.cuda(), g1.float().cuda()), ed.decode(ed.encode(x.cuda()), g1.float().cuda()))
         logits = me.UnetEncoder(cfg)(params["encoder_model"], f, deterministic=True)
         assert rel(logits, tr.unet_encoder(tr.encode(x.double()), ref["encoder_model"], E, 1)) < 2e-4
         sched = me.NoiseSchedule_polynomial_fixedend(cfg)

@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 from oracle import mulan_np as onp
 from oracle import torch_ref as tr
 
-from test_gpu_model import block_names, oracle_masks
+from tests.test_gpu_model import block_names, oracle_masks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, E, STEPS, WARMUP = 4, 128, 4, 2
