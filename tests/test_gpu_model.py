@@ -651,7 +651,8 @@ def test_module_surface_matches_oracle(unet_type):
             g_dev = g0.float().cuda() if torch.is_tensor(g0) else g0
             got_lp = ed.decode(zz.float().cuda(), g_dev)
             assert got_lp.shape == (B, 32, 32, 3, 256)
-            assert float(np.abs(got_lp.cpu().double().numpy() - want_lp).max()) < 2e-3 * (1 + 0)   # logits reach -1e5: fp32
+            err = np.abs(got_lp.cpu().double().numpy() - want_lp)
+            assert bool((err < 1e-4 + 2e-6 * np.abs(want_lp)).all()), float(err.max())     # (logits reach -2e6 in fp32)
             assert float(np.abs(np.exp(got_lp.cpu().double().numpy()).sum(-1) - 1).max()) < 1e-5
             want = onp.logprob(x.numpy(), zz.float().double().numpy(), np.float32(g_bc).astype(np.float64))
             got = ed.logprob(x.cuda(), zz.float().cuda(), g_dev)
