@@ -236,6 +236,20 @@ int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const float* x2,
                               unsigned* dx1max, unsigned* dx2max, const float* add1, const float* add2,
                               float* dxsum_part, float* dgamma, float* dbeta, float* dxsum, float* dxsum2,
                               unsigned* tickets, mulan_stream_t stream);
+/* _fused_planes (round 3; autodiff of ldm/model_vdm.py:643-650, the gradient norm2 hands to conv1): single input, no
+ * skip-path gradient; dx is written ONLY as the split fp16 operand planes of the f16x3 kernels of the convolution in
+ * front ([B][C/16][1024][plane][16], mulan_conv3x3_planes_bytes bytes) -- its input-gradient convolution
+ * (mulan_conv3x3_fwd_f16x3_planes_in on the tap-flipped weights) and its weight gradient
+ * (mulan_conv3x3_wgrad_f16x3_planes) -- scaled per image with an a-priori bound of |dx[b]| derived from dymax ([B][16]
+ * maxima of dy, a by-product of the convolution kernel that wrote dy), rstd and max|gamma|; dxmax [B][16] receives the
+ * bound in the maxima format.  Bias / FiLM gradients of that convolution come from dxsum_part / dxsum as before. */
+int mulan_groupnorm_bwd_fused_planes(const float* dy, const unsigned* dymax, const float* x, int C, const float* gamma,
+                                     const float* beta, const float* mean, const float* rstd, void* dxplanes,
+                                     float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
+                                     unsigned long long seed, unsigned long long offset,
+                                     const unsigned long long* seed_dev, unsigned* dxmax, float* dxsum_part,
+                                     float* dgamma, float* dbeta, float* dxsum, float* dxsum2, unsigned* tickets,
+                                     mulan_stream_t stream);
 /* add1 / add2 (optional): gradients arriving through a skip path of x1 / x2 (the ResnetBlock residual, nin_shortcut),
  * added while dx is written, so that no separate accumulation pass exists.  By-products of the written gradients (the
  * dy of the convolution in front): dx1max / dx2max (optional, [B][16], mulan_absmax_rows format) and dxsum_part

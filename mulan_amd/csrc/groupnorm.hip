@@ -229,6 +229,10 @@ struct GnBwdArgs {
   float* dgamma; float* dbeta;                 // [Ct] totals
   float* dxsum; float* dxsum2;                 // optional [C1] each: sum over samples of dxsum_part's x1 columns (the bias
                                                // gradient of the convolution in front, and of a shortcut layer sharing it)
+  // optional (single-pass kernel, C2 == 0, no add1, no accumulate): dx1 is written as the split fp16 operand planes of
+  // the input-gradient convolution / weight-gradient kernel in front ([B][C1/16][HW][plane][16]) INSTEAD of as fp32,
+  // scaled by an a-priori bound (below) that dx1max receives; dymax: [B][16] maxima of dy (the bound needs max|dy[b]|)
+  unsigned char* dx1planes; const unsigned* dymax;
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -353,6 +357,21 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     xh[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)px * ld));
     gq[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dyp + (size_t)px * Ct));
   }
+  // Planes mode: the operand scale must be known before the first element is written and must be the same in every
+  // block of an image, so it comes from a bound instead of the maximum.  With g = dy mask / keep act'(u) gamma:
+  //   dx = rstd (g - mean(g) - xhat mean(g xhat)),  |g| <= G0 = max|dy[b]| 1.1 max|gamma| / keep  (|silu'| < 1.0999),
+  //   |mean(g)| <= G0,  |mean(g xhat)| <= G0 sqrt(mean(xhat^2)) <= G0,  |xhat| < sqrt(n)  (n elements per group)
+  //   => |dx| <= max_g rstd[b, g] G0 (2 + sqrt(n)).
+  // Every wave takes the three maxima itself (identical in all waves and blocks; the loads hide behind the slabs').
+  float bound = 0.f;
+  if (p.dx1planes) {
+    const int ln = tid & 63;
+    float rm = 0.f, gm = 0.f, dm = ln < 16 ? __uint_as_float(p.dymax[b * 16 + ln]) : 0.f;
+    for (int gg = ln; gg < p.G; gg += 64) rm = fmaxf(rm, p.rstd[b * p.G + gg]);
+    for (int cc = ln; cc < Ct; cc += 64) gm = fmaxf(gm, fabsf(p.gamma[cc]));
+    rm = wave_max(rm); gm = wave_max(gm); dm = wave_max(dm);
+    bound = ((sqrtf((float)(HW * cpg)) + 2.f) * (p.act ? 1.1f : 1.f)) * rm * gm * (dm / p.keep);
+  }
   // the forward pass's dropout mask, re-drawn while the two slabs are in flight (see gn_fwd_kernel)
   unsigned mb[NPB / 8];
   const bool dropping = p.keep < 1.f;
@@ -430,6 +449,10 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     for (int w = 0; w < 8; ++w) { t1 += red[w * 8 + q]; t2 += red[64 + w * 8 + q]; }
   const float inv_n = 1.f / (float)(HW * cpg);
   const float m1 = t1 * inv_n, m2 = t2 * inv_n;
+  float psc, pinv;
+  f16x3::scale_of(__float_as_uint(bound), psc, pinv);
+  // plane record of pixel px, channels c .. c + 3: [b][c / 16][px][plane][c % 16]
+  unsigned char* pdst = p.dx1planes ? p.dx1planes + ((size_t)(b * (Ct >> 4) + (c >> 4)) * HW) * 64 + (c & 15) * 2 : nullptr;
 #pragma unroll
   for (int i = 0; i < NPB; ++i) {
     const int px = prow + 64 * i;
@@ -437,6 +460,22 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     {
       const f32x2 oa = (lo2(gq[i]) - m1 - lo2(xh[i]) * m2) * rstd, ob = (hi2(gq[i]) - m1 - hi2(xh[i]) * m2) * rstd;
       o = f32x4{oa[0], oa[1], ob[0], ob[1]};
+    }
+    if (pdst) {     // (the clamp never acts while the bound holds; fp16 planes must not overflow whatever the input)
+      typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+      f16x3::f16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const f32x2 vs = f32x2{__builtin_amdgcn_fmed3f(o[e], -bound, bound), __builtin_amdgcn_fmed3f(o[e + 1], -bound, bound)} * psc;
+        const f16x2v h = __builtin_convertvector(vs, f16x2v);
+        const f16x2v l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x2), f16x2v);
+        hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
+      }
+      *reinterpret_cast<f16x3::f16x4*>(pdst + (size_t)px * 64) = hi;
+      *reinterpret_cast<f16x3::f16x4*>(pdst + (size_t)px * 64 + 32) = lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += o[e];
+      continue;
     }
     float* dp = dxp + (size_t)px * ld;
     if (p.accumulate) {
@@ -486,7 +525,8 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
       unsigned m = 0;
 #pragma unroll
       for (int w = 0; w < 8; ++w) m = max(m, ured[w]);
-      mout[b * 16 + slab] = m;
+      // planes: what they were scaled with is the consumers' "maximum" (the same value from every block of the image)
+      mout[b * 16 + slab] = p.dx1planes ? __float_as_uint(bound) : m;
     }
     if (slab == 0 && tid >= nslab && tid < 16) mout[b * 16 + tid] = 0u;
   }
@@ -605,7 +645,7 @@ MULAN_API int mulan_groupnorm_bwd_dyn(const float* dy, const float* x1, const fl
   if ((dx1max && C1 / 32 > 16) || (dx2max && C2 / 32 > 16)) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
               B, G, act, keep, seed, offset, accumulate, dx1max, dx2max, add1, add2, dxsum_part, seed_dev, nullptr, nullptr,
-              nullptr, nullptr, nullptr};
+              nullptr, nullptr, nullptr, nullptr, nullptr};
   if (g_mulan_tune[2] == 1 && !dx1max && !dx2max && !add1 && !add2 && !dxsum_part)   // dev A/B: two-pass 256-thread variant
     hipLaunchKernelGGL(gn_bwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   else
@@ -634,8 +674,34 @@ MULAN_API int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const 
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
               B, G, act, keep, seed, offset, 0, dx1max, dx2max, add1, add2, dxsum_part, seed_dev, tickets, dgamma, dbeta,
-              dxsum, dxsum2};
+              dxsum, dxsum2, nullptr, nullptr};
   hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+// mulan_groupnorm_bwd_fused for a single input whose gradient feeds ONLY the f16x3 kernels of the convolution in front
+// (its input-gradient convolution and its weight gradient; the bias / FiLM gradients come from dxsum_part / dxsum): dx is
+// written as their split fp16 operand planes (dxplanes: mulan_conv3x3_planes_bytes(B, 32, 32, C) bytes) instead of as
+// fp32, so that the convolution neither splits its input nor stores planes out of the MFMA kernel.  The planes are
+// scaled with an a-priori bound of |dx[b]| (see gn_bwd_kernel_1pass) formed from dymax ([B][16] maxima of dy, as the
+// convolution that produced dy leaves them), rstd and max|gamma|; dxmax [B][16] receives that bound in the maxima format.
+MULAN_API int mulan_groupnorm_bwd_fused_planes(const float* dy, const unsigned* dymax, const float* x, int C,
+                                               const float* gamma, const float* beta, const float* mean,
+                                               const float* rstd, void* dxplanes, float* dgamma_part, float* dbeta_part,
+                                               int B, int hw, int G, int act, float keep, unsigned long long seed,
+                                               unsigned long long offset, const unsigned long long* seed_dev,
+                                               unsigned* dxmax, float* dxsum_part, float* dgamma, float* dbeta,
+                                               float* dxsum, float* dxsum2, unsigned* tickets, hipStream_t stream) {
+  if (hw != HW || B <= 0 || G <= 0 || C % G != 0 || !tickets || !dgamma || !dbeta || !dgamma_part || !dbeta_part ||
+      !dxplanes || !dymax || !dxmax || !(keep > 0.f) || (dxsum && !dxsum_part) || (dxsum2 && !dxsum) || C / 32 > 16 ||
+      C % 32 != 0 || (size_t)B * HW * C * 4 >= 0x80000000ull)
+    return (int)hipErrorInvalidValue;
+  const int cpg = C / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0) return (int)hipErrorInvalidValue;
+  GnBwdArgs a{dy, x, nullptr, C, 0, gamma, beta, mean, rstd, nullptr, nullptr, dgamma_part, dbeta_part,
+              B, G, act, keep, seed, offset, 0, dxmax, nullptr, nullptr, nullptr, dxsum_part, seed_dev, tickets, dgamma,
+              dbeta, dxsum, dxsum2, static_cast<unsigned char*>(dxplanes), dymax};
+  hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, C / 32), dim3(512), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
 

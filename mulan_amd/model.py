@@ -175,8 +175,9 @@ def resnet_block(p, x1, x2, cond, drop):
             res = ops.linear2(s1, s2, p["nin_shortcut"]["kernel"], p["nin_shortcut"]["bias"])
     else:
         res = s1
+    # (h = conv1's output has no other consumer: its gradient may travel as split planes only, ops.GRAD_PLANES)
     return ops.gn_conv3x3(h, None, p["GroupNorm_1"]["scale"], p["GroupNorm_1"]["bias"], p["conv2"]["kernel"],
-                          p["conv2"]["bias"], res=res, act=True, keep=keep, seed=seed, offset=off)
+                          p["conv2"]["bias"], res=res, act=True, keep=keep, seed=seed, offset=off, x1_grad_planes=True)
 
 
 def attn_block(p, x):

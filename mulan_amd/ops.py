@@ -313,8 +313,10 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False, 
     return y
 
 
-def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None):
-    """dx = conv3x3(dy, flipped w).  planes=True (f16x3 mode): returns (dx, dys), dys = the split planes of dy."""
+def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None, want_max=False):
+    """dx = conv3x3(dy, flipped w).  planes=True (f16x3 mode): returns (dx, dys), dys = the split planes of dy.
+    want_max (f16x3 mode): the kernel leaves the maxima of dx on the tensor (a GroupNorm backward that hands its own
+    result on as planes needs them for its bound)."""
     C, N = w.shape[2], w.shape[3]
     if CONV_MODE in ("bf16x6", "f16x3") and N % 16 == 0 and C % 128 == 0:
         B = dy.shape[0]
@@ -325,9 +327,13 @@ def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None):
             if dymax is None:
                 dymax = absmax_rows(dy)
             dys = torch.empty(B * HW * N * 4, device=dy.device, dtype=torch.uint8) if planes else None
+            dxmax = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
+                     if want_max and (H // 8) * (C // 128) <= MAX_PARTS else None)
             _timed("conv3x3_f16x3_kernel", flops,
                    lambda: call("mulan_conv3x3_fwd_f16x3", ptr(dy), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
-                                ptr(dx), ptr(dys), None, B, H, W, N, C, stream()))
+                                ptr(dx), ptr(dys), ptr(dxmax), B, H, W, N, C, stream()))
+            if dxmax is not None:
+                dx._absmax = (dxmax, dx._version)
             if planes:
                 return dx, dys
         else:
@@ -338,6 +344,49 @@ def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None):
     wT = torch.empty((3, 3, N, C), device=w.device, dtype=torch.float32)
     call("mulan_conv3x3_wflip", ptr(w), ptr(wT), C, N, stream())
     return conv3x3_raw(dy, wT)
+
+
+def conv3x3_dgrad_planes_raw(dys, dymax, w, wmax=None, want_max=False):
+    """dx = conv3x3(dy, flipped w) with dy given as split planes (scaled with dymax: what a GroupNorm backward hands on,
+    mulan_groupnorm_bwd_fused_planes): the plane-fed instantiation of the convolution kernel -- no split, no plane stores"""
+    C, N = w.shape[2], w.shape[3]
+    B = dymax.shape[0]
+    dx = torch.empty((B, HW, C), device=dys.device, dtype=torch.float32)
+    wp, wmax = _pack_weights(w, C, N, 1, wmax)
+    dxmax = (torch.empty((B, MAX_PARTS), device=dys.device, dtype=torch.int32)
+             if want_max and (H // 8) * (C // 128) <= MAX_PARTS else None)
+    _timed("conv3x3_f16x3_kernel<planes_in,dgrad>", 2.0 * B * HW * 9 * C * N,
+           lambda: call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(dys), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
+                        ptr(dx), ptr(dxmax), B, H, W, N, C, stream()))
+    if dxmax is not None:
+        dx._absmax = (dxmax, dx._version)
+    return dx
+
+
+def grad_planes_eligible(C, N):
+    """a convolution C -> N whose output gradient may arrive as split planes only: plane-fed weight gradient (128-grids)
+    and the two-blocks-per-CU kernel for the input gradient (N % 32 == 0, C % 128 == 0)"""
+    return GRAD_PLANES and planes_eligible(C, N) and N % 32 == 0 and C % 128 == 0 and N // 32 <= MAX_PARTS
+
+
+_NAN = {}
+
+
+def _planes_only_grad(shape, device, planes, bound):
+    """The stand-in autograd carries for a gradient that exists only as split planes: a NaN scalar expanded to the
+    gradient's shape (4 bytes; anything that consumed it as numbers would turn NaN at once -- loud, not silent) with the
+    real content attached as `_grad_planes = (planes, bound maxima, version)`"""
+    n = _NAN.get(device)
+    if n is None:
+        n = _NAN[device] = torch.full((1,), float("nan"), device=device, dtype=torch.float32)
+    g = n.expand(*shape)
+    g._grad_planes = (planes, bound, g._version)
+    return g
+
+
+def _grad_planes_of(dy):
+    gp = getattr(dy, "_grad_planes", None)
+    return gp if (gp is not None and gp[2] == dy._version) else None
 
 
 def _gv(t):
@@ -465,26 +514,45 @@ def _conv3x3_backward(ctx, dy):
     needs_input_grad[0..4])"""
     if True:
         x, w = ctx.saved_tensors
-        dy = _c(dy)
         has_bias, cb_dim, has_res = ctx.has
         gvw, gvb = ctx.gv
         B, N = dy.shape[0], dy.shape[-1]
-        dymax = cached_absmax(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
-        if ctx.planes:                # x is the plane tensor here
-            dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True, wmax=ctx.wmax)
+        want_max = bool(getattr(ctx, "want_dx_max", False))
+
+        def wgrad_from_planes(dys, dymax):
+            if _side_ok(gvw):
+                dw_, xmax = _fresh(gvw), ctx.xmax
+                _on_side(lambda: conv3x3_wgrad_planes_raw(x, xmax, dys, dymax, B, w.shape[2], N, out=dw_),
+                         (x, xmax, dys, dymax))
+                return dw_
+            return conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
+                                            out=_fresh(gvw) if gvw is not None else None)
+
+        gp = _grad_planes_of(dy)
+        if gp is not None:
+            # dy exists only as split planes (written by the GroupNorm backward behind this convolution,
+            # mulan_groupnorm_bwd_fused_planes): the plane-fed convolution kernel forms dx, the weight-gradient kernel
+            # reads the same planes, bias / FiLM gradients come from the channel sums that kernel left.  Nothing here
+            # may read dy's numbers (the tensor is a NaN stand-in).
+            assert not has_res and cb_dim != 3 and getattr(dy, "_colsum", None) is not None, "planes-only gradient misrouted"
+            dys, dymax = gp[0], gp[1]
+            dx = conv3x3_dgrad_planes_raw(dys, dymax, w, wmax=ctx.wmax, want_max=want_max)
+            dw = wgrad_from_planes(dys, dymax) if ctx.needs_input_grad[1] else None
+        else:
+            dy = _c(dy)
+            dymax = cached_absmax(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
+        if gp is not None:
+            pass
+        elif ctx.planes:                # x is the plane tensor here
+            dx, dys = conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True, wmax=ctx.wmax, want_max=want_max)
             try:       # the shortcut layer that shares this dy takes its weight gradient from the same planes
                 dy._planes = (dys, dymax, dy._version)
             except (AttributeError, RuntimeError):
                 pass
-            if _side_ok(gvw):
-                dw, xmax = _fresh(gvw), ctx.xmax
-                _on_side(lambda: conv3x3_wgrad_planes_raw(x, xmax, dys, dymax, B, w.shape[2], N, out=dw),
-                         (x, xmax, dys, dymax))
-            else:
-                dw = conv3x3_wgrad_planes_raw(x, ctx.xmax, dys, dymax, B, w.shape[2], N,
-                                              out=_fresh(gvw) if gvw is not None else None)
+            dw = wgrad_from_planes(dys, dymax)
         else:
-            dx = conv3x3_dgrad_raw(dy, w, dymax=dymax, wmax=ctx.wmax) if ctx.needs_input_grad[0] else None
+            dx = (conv3x3_dgrad_raw(dy, w, dymax=dymax, wmax=ctx.wmax, want_max=want_max)
+                  if ctx.needs_input_grad[0] else None)
             dw = None
             if ctx.needs_input_grad[1]:   # written straight into the flat gradient buffer when the weight is a leaf
                 if _side_ok(gvw) and (dymax is None or ctx.xmax is not None):
@@ -515,6 +583,7 @@ def _conv3x3_backward(ctx, dy):
         if cb_dim is not None and ctx.needs_input_grad[3]:
             dcb = per_sample if cb_dim == 2 else dy
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        assert gp is None or (dres is None and dcb is not dy)
         return dx, dw, dbias, dcb, dres
 
 
@@ -891,15 +960,39 @@ def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     return y, x1, x2
 
 
-def _gn_backward(ctx, dy, add1=None, add2=None):
+def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False):
     """dx1, dx2 (+ the gradients add1 / add2 that reach x1 / x2 through a skip path), dgamma, dbeta.  The written dx1
-    carries its maxima and per-sample channel sums for the convolution in front (whose dy it is)."""
+    carries its maxima and per-sample channel sums for the convolution in front (whose dy it is).
+    planes_out: the caller vouches that dx1 is consumed ONLY by the f16x3 kernels of the convolution that produced x1
+    (GnConv3x3Fn with x1_grad_planes): where the kernel variant applies (single input, no skip-path gradient, dy with
+    its maxima) dx1 is then written as split planes and returned as a planes-only stand-in (_planes_only_grad)."""
     x1, x2, gamma, beta, mean, rstd = ctx.saved_tensors
     groups, act, keep, seed, offset = ctx.meta
     dy = _c(dy)
     B, C1 = x1.shape[0], x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
     Ct = C1 + C2
+    dymax_in = getattr(dy, "_absmax", None)
+    if (planes_out and GN_FUSED_REDUCE and x2 is None and add1 is None and dymax_in is not None and
+            dymax_in[1] == dy._version and C1 % 32 == 0 and C1 // 32 <= 16 and (C1 // groups) % 4 == 0 and
+            32 % (C1 // groups) == 0 and B * HW * C1 * 4 < 2 ** 31):
+        dxp = torch.empty(B * HW * C1 * 4, device=dy.device, dtype=torch.uint8)
+        bound = torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
+        parts = torch.empty((2, B, C1), device=dy.device, dtype=torch.float32)
+        csum = torch.empty((B, C1), device=dy.device, dtype=torch.float32)
+        sv, sd = _seed_args(seed)
+        gvg, gvb = ctx.gv
+        dgamma = _fresh(gvg) if gvg is not None else torch.empty(C1, device=dy.device, dtype=torch.float32)
+        dbeta = _fresh(gvb) if gvb is not None else torch.empty(C1, device=dy.device, dtype=torch.float32)
+        sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
+        call("mulan_groupnorm_bwd_fused_planes", ptr(dy), ptr(dymax_in[0]), ptr(x1), C1, ptr(gamma), ptr(beta), ptr(mean),
+             ptr(rstd), ptr(dxp), ptr(parts[0]), ptr(parts[1]), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(bound),
+             ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2), ptr(_gn_tickets(dy.device)), stream())
+        dx1 = _planes_only_grad(x1.shape, dy.device, dxp, bound)
+        if sink is not None:
+            dx1._biasdone = (sink, sink2, dx1._version)
+        dx1._colsum = (csum, dx1._version)
+        return dx1, None, dgamma, dbeta
     dx1 = torch.empty_like(x1)
     dx2 = torch.empty_like(x2) if x2 is not None else None
     parts = torch.empty((2, B, Ct), device=dy.device, dtype=torch.float32)     # dgamma / dbeta per-sample partials
@@ -989,6 +1082,10 @@ def group_norm_skip(x1, x2, gamma, beta, *, groups=32, eps=1e-6, act=True, keep=
 
 
 GN_CONV_PLANES = _os.environ.get("MULAN_GN_CONV_PLANES", "1") == "1"    # A/B switch: 0 = fp32 hand-over (two ops)
+# Backward counterpart (round 3): the gradient a GroupNorm backward hands to the convolution in front of it (norm2 ->
+# conv1 of a ResnetBlock) goes as split planes too -- the input-gradient convolution then runs on the plane-fed
+# instantiation of the kernel (no split, no plane stores out of the MFMA kernel).  A/B switch: 0 = fp32 hand-over.
+GRAD_PLANES = _os.environ.get("MULAN_GRAD_PLANES", "1") == "1"
 
 
 def gn_conv_ok(C1, C2, N, groups):
@@ -1009,7 +1106,12 @@ class GnConv3x3Fn(torch.autograd.Function):
     GroupNorm backward kernel (as GroupNormSkipFn)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, act, keep, seed, offset, skip):
+    def forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, act, keep, seed, offset, skip,
+                x1_grad_planes=False):
+        # x1_grad_planes: the caller vouches that x1 has no consumer besides this op (conv1's output inside a
+        # ResnetBlock); if x1's producer accepts it (tag below), d x1 then travels as split planes only
+        acc = getattr(x1, "_accepts_grad_planes", None)
+        ctx.x1_grad_planes = bool(x1_grad_planes and not skip and x2 is None and acc is not None and acc == x1._version)
         x1, x2, w = _c(x1), _c(x2), _c(w)
         B, C1 = x1.shape[0], x1.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
@@ -1045,6 +1147,8 @@ class GnConv3x3Fn(torch.autograd.Function):
             y._bias_sink = (ctx.gv_conv[1], twin[0] if (twin is not None and twin[1] == res._version) else None, y._version)
         ctx.skip = bool(skip)
         ctx.has2 = x2 is not None
+        if res is None and mode != 2 and grad_planes_eligible(Ct, N):
+            y._accepts_grad_planes = y._version      # this op's backward understands a planes-only output gradient
         if not skip:
             return y
         s1 = x1.view_as(x1)
@@ -1058,30 +1162,32 @@ class GnConv3x3Fn(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy, ds1=None, ds2=None):
-        nones = (None,) * 7
+        nones = (None,) * 8
         if dy is None:     # only the skip path was used downstream
             return (ds1, ds2) + (None,) * 6 + nones
         x1, x2, gamma, beta, mean, rstd, ys, w, bound = ctx.saved_tensors
         need = ctx.needs_input_grad
+        planes_out = ctx.x1_grad_planes and GRAD_PLANES and ds1 is None
         # (planes = False when the kernel needs no gradient -- the ODE evaluator differentiates with respect to the input
         # only: input gradient without plane output, no weight-gradient launch)
         conv = _Ctx(saved_tensors=(ys, w), planes=bool(need[4]), xmax=bound, wmax=ctx.wmax, has=ctx.has, gv=ctx.gv_conv,
-                    needs_input_grad=(True, need[4], need[5], need[6], need[7]))
+                    needs_input_grad=(True, need[4], need[5], need[6], need[7]), want_dx_max=planes_out)
         dh, dw, dbias, dcb, dres = _conv3x3_backward(conv, dy)
         gn = _Ctx(saved_tensors=(x1, x2, gamma, beta, mean, rstd), meta=ctx.meta, gv=ctx.gv_gn,
                   bias_sink=ctx.bias_sink)
-        dx1, dx2, dgamma, dbeta = _gn_backward(gn, dh, ds1, ds2)
+        dx1, dx2, dgamma, dbeta = _gn_backward(gn, dh, ds1, ds2, planes_out=planes_out)
         return (dx1, dx2, dgamma, dbeta, dw, dbias, dcb, dres) + nones
 
 
 def gn_conv3x3(x1, x2, gamma, beta, w, bias=None, cbias=None, res=None, *, groups=32, eps=1e-6, act=True, keep=1.0,
-               seed=0, offset=0, skip=False):
+               seed=0, offset=0, skip=False, x1_grad_planes=False):
     """-> y, or (y, s1, s2) with skip=True.  Falls back to group_norm(_skip) + conv3x3 where the plane hand-over does not
     apply (other arithmetic modes, channel counts off the 128 grid)."""
     C1 = x1.shape[-1]
     C2 = 0 if x2 is None else x2.shape[-1]
     if gn_conv_ok(C1, C2, w.shape[-1], groups) and x1.is_cuda:
-        out = GnConv3x3Fn.apply(x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, int(act), keep, seed, offset, skip)
+        out = GnConv3x3Fn.apply(x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, int(act), keep, seed, offset, skip,
+                                x1_grad_planes)
         if not skip:
             return out
         return out if len(out) == 3 else (out[0], out[1], None)

@@ -754,3 +754,120 @@ def test_gn_planes_bound_and_precision(ops):
     mag = float(ref.abs().max())
     e_planes, e_two = float((out.double() - ref).abs().max()) / mag, float((two_op.double() - ref).abs().max()) / mag
     assert e_planes <= 2.0 * e_two + 2e-7, (e_planes, e_two)
+
+
+def test_gn_backward_planes_bound_and_precision(ops):
+    """mulan_groupnorm_bwd_fused_planes (round 3): the GroupNorm backward writes dx as the split fp16 planes of the
+    convolution in front instead of as fp32.  The planes decode (hi + lo) / scale to the fp32 dx of the ordinary kernel
+    within the split's 2^-21 of the image's maximum, the scale comes from an a-priori bound that really bounds (one
+    outlier pixel: |xhat| ~ 40 of the possible 64; an image 1000 x smaller; a heavy-tailed incoming gradient), dgamma /
+    dbeta / the channel sums are those of the fp32 kernel bit for bit, and the plane-fed input-gradient convolution is as
+    close to float64 as the fp32-input one."""
+    torch.manual_seed(9)
+    B, C, N = 3, 128, 128
+    for keep in (1.0, 0.9):
+        x = torch.randn(B, 1024, C, device="cuda")
+        x[0, 17, 5] = 300.0
+        x[1] *= 1e-3
+        dy = torch.randn(B, 1024, C, device="cuda")
+        dy[2] = dy[2] ** 3 * 1e-4                                      # heavy tails, small magnitude
+        dy[0, 100, 7] = 50.0
+        gamma, beta = torch.randn(C, device="cuda") * 2, torch.randn(C, device="cuda")
+        mean, rstd = torch.empty(B, 32, device="cuda"), torch.empty(B, 32, device="cuda")
+        y = torch.empty_like(x)
+        ops.call("mulan_groupnorm_fwd_dyn", ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta), ops.ptr(y), ops.ptr(mean),
+                 ops.ptr(rstd), B, 1024, 32, 1e-6, 1, keep, 11, 64, None, None, ops.stream())
+        dymax = ops.absmax_rows(dy)
+        tick = torch.zeros(16, device="cuda", dtype=torch.int32)
+
+        def run(planes):
+            dx = torch.empty_like(x)
+            dxp = torch.empty(B * 1024 * C * 4, device="cuda", dtype=torch.uint8)
+            m = torch.empty(B, 16, device="cuda", dtype=torch.int32)
+            parts = torch.empty(2, B, C, device="cuda")
+            csum = torch.empty(B, C, device="cuda")
+            dg, db, sink = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+            if planes:
+                ops.call("mulan_groupnorm_bwd_fused_planes", ops.ptr(dy), ops.ptr(dymax), ops.ptr(x), C, ops.ptr(gamma),
+                         ops.ptr(beta), ops.ptr(mean), ops.ptr(rstd), ops.ptr(dxp), ops.ptr(parts[0]), ops.ptr(parts[1]), B,
+                         1024, 32, 1, keep, 11, 64, None, ops.ptr(m), ops.ptr(csum), ops.ptr(dg), ops.ptr(db), ops.ptr(sink),
+                         None, ops.ptr(tick), ops.stream())
+            else:
+                ops.call("mulan_groupnorm_bwd_fused", ops.ptr(dy), ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta),
+                         ops.ptr(mean), ops.ptr(rstd), ops.ptr(dx), None, ops.ptr(parts[0]), ops.ptr(parts[1]), B, 1024, 32, 1,
+                         keep, 11, 64, None, ops.ptr(m), None, None, None, ops.ptr(csum), ops.ptr(dg), ops.ptr(db),
+                         ops.ptr(sink), None, ops.ptr(tick), ops.stream())
+            return dx, dxp, m, csum, dg, db, sink
+
+        dx, _, m_ref, csum_ref, dg_ref, db_ref, sink_ref = run(False)
+        _, dxp, bound, csum, dg, db, sink = run(True)
+        assert int(tick.abs().sum()) == 0
+        for a, r in ((csum, csum_ref), (dg, dg_ref), (db, db_ref), (sink, sink_ref)):
+            assert torch.equal(a, r)
+        bnd = bound.cpu().numpy().view(np.float32)
+        assert np.all(bnd[:, :4] == bnd[:, :1]) and np.all(bnd[:, 4:] == 0)       # the same bound from every slab's block
+        true_max = dx.abs().amax(dim=(1, 2)).cpu().numpy()
+        assert np.all(bnd[:, 0] >= true_max), (bnd[:, 0], true_max)
+        print("GroupNorm backward planes: bound / true maximum per image =", bnd[:, 0] / true_max)
+        assert np.all(bnd[:, 0] <= 2.0 ** 12 * true_max)                         # loose by a few hundred at most
+        planes = dxp.view(torch.float16).view(B, C // 16, 1024, 2, 16).float()
+        for b in range(B):
+            e = int(np.frexp(bnd[b, 0])[1]) - 1 + 127                            # biased exponent -> scale 2^(140 - e)
+            dec = (planes[b, :, :, 0] + planes[b, :, :, 1]).permute(1, 0, 2).reshape(1024, C) * 2.0 ** (e - 140)
+            # two fp16 pieces of v * scale: relative 2^-22 of the element, absolute floor 2^-25 in scaled units
+            tol = 2.0 ** -21 * dx[b].abs() + 2.0 ** (-25 + e - 140)
+            assert bool(((dec - dx[b]).abs() <= tol).all()), (b, float((dec - dx[b]).abs().max()), float(dx[b].abs().max()))
+        # the input-gradient convolution fed with these planes against the fp32-input launch, both against float64
+        w = torch.randn(3, 3, N, C, device="cuda") * 0.05                        # conv N -> C; its dgrad maps C -> N
+        got = ops.conv3x3_dgrad_planes_raw(dxp, bound, w)
+        two = ops.conv3x3_dgrad_raw(dx, w)
+        ref = torch.nn.functional.conv_transpose2d(dx.double().view(B, 32, 32, C).permute(0, 3, 1, 2),
+                                                   w.double().permute(2, 3, 0, 1), padding=1).permute(0, 2, 3, 1).reshape(B, 1024, N)
+        for b in range(B):
+            mag = float(ref[b].abs().max())
+            e_p, e_t = float((got[b].double() - ref[b]).abs().max()) / mag, float((two[b].double() - ref[b]).abs().max()) / mag
+            assert e_p <= 2.0 * e_t + 2e-7, (keep, b, e_p, e_t)
+
+
+@pytest.mark.parametrize("B,C,E,keep,shortcut", [(3, 128, 128, 0.9, False), (2, 256, 128, 0.9, True), (2, 256, 256, 1.0, False)])
+def test_grad_planes_hand_over_matches_the_fp32_path(ops, monkeypatch, B, C, E, keep, shortcut):
+    """A ResnetBlock-shaped pair of ops.gn_conv3x3 nodes (norm1 + swish -> conv1 + FiLM bias; norm2 + swish + dropout ->
+    conv2 + residual): with x1_grad_planes the gradient norm2's backward hands to conv1 exists only as split planes
+    (mulan_groupnorm_bwd_fused_planes -> plane-fed input-gradient convolution + plane-fed weight gradient); every
+    gradient (input, both GroupNorms, both kernels and biases, FiLM bias, shortcut) agrees with the fp32 hand-over to
+    the split's rounding, the stand-in tensor autograd carries is never read, and one fp32-input convolution launch per
+    block is gone."""
+    torch.manual_seed(B + C + E)
+    mk = lambda *s, scale=1.0: (torch.randn(*s, device="cuda") * scale).requires_grad_(True)
+    x = mk(B, 1024, C, scale=2.0)
+    g1, b1, g2, b2 = mk(C), mk(C, scale=0.3), mk(E), mk(E, scale=0.3)
+    w1, c1b, w2, c2b, cb = mk(3, 3, C, E, scale=0.03), mk(E), mk(3, 3, E, E, scale=0.03), mk(E), mk(B, E)
+    wn = mk(C, E, scale=0.05) if shortcut else None
+    gy = torch.randn(B, 1024, E, device="cuda")
+    leaves = [t for t in (x, g1, b1, g2, b2, w1, c1b, w2, c2b, cb, wn) if t is not None]
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    def run(planes):
+        monkeypatch.setattr(ops, "GRAD_PLANES", planes)
+        for t in leaves:
+            t.grad = None
+        names.clear()
+        h, s1, _ = ops.gn_conv3x3(x, None, g1, b1, w1, c1b, cbias=cb, act=True, skip=True)
+        res = ops.linear(s1, wn, None) if shortcut else (s1 if C == E else None)
+        y = ops.gn_conv3x3(h, None, g2, b2, w2, c2b, res=res, act=True, keep=keep, seed=5, offset=1 << 34, x1_grad_planes=True)
+        (y * gy).sum().backward()
+        return [y.detach().clone()] + [t.grad.clone() for t in leaves], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert "mulan_groupnorm_bwd_fused_planes" in got_names and "mulan_groupnorm_bwd_fused_planes" not in ref_names
+    assert got_names.count("mulan_conv3x3_fwd_f16x3") == ref_names.count("mulan_conv3x3_fwd_f16x3") - 1
+    assert got_names.count("mulan_conv3x3_fwd_f16x3_planes_in") == ref_names.count("mulan_conv3x3_fwd_f16x3_planes_in") + 1
+    assert torch.equal(got[0], ref[0])
+    labels = ["y"] + [n for n, t in zip(("x", "g1", "b1", "g2", "b2", "w1", "c1b", "w2", "c2b", "cb", "wn"),
+                                         (x, g1, b1, g2, b2, w1, c1b, w2, c2b, cb, wn)) if t is not None]
+    for a, r, nm in zip(got, ref, labels):
+        assert bool(torch.isfinite(a).all()), nm
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-30, (nm, float((a - r).abs().max()), float(r.abs().max()))

@@ -132,8 +132,11 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
                          m={q: v.copy() for q, v in ref_m.items()}, v={q: v.copy() for q, v in ref_v.items()},
                          ema={q: v.copy() for q, v in ref_ema.items()}))
 
-    def rel_leaf(a, b):
-        return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    def rel_leaf(a, b, floor=1e-30):
+        """max |a - b| relative to the leaf's scale; `floor`: the scale below which a leaf counts as zero (the bias of
+        the attention keys has an exactly vanishing gradient -- softmax ignores a constant added to a row of scores --
+        which fp32 and float64 both approximate by their own rounding noise)"""
+        return float(np.abs(a - b).max() / (np.abs(b).max() + floor))
 
     for graph in (False, True):
         exp, config = _experiment(graph, vdm_type)
@@ -175,13 +178,13 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
                 # ---- free-running: gradients and moments at the per-leaf bar of the gradient tests; the first
                 # step's gradient is taken at identical parameters, later ones at parameters an Adam step apart
                 bar = 2e-3 if k == 0 else 2e-2
-                eg = rel_leaf(gk, free[k]["grads"][p])
+                eg = rel_leaf(gk, free[k]["grads"][p], 1e-6)
                 worst["grad"] = max(worst["grad"], eg)
                 assert eg < bar, (graph, k, "grad", "/".join(p), eg)
-                em = rel_leaf(_leaf(got_m, p), free[k]["m"][p])
+                em = rel_leaf(_leaf(got_m, p), free[k]["m"][p], 1e-7)
                 worst["mom"] = max(worst["mom"], em)
                 assert em < bar, (graph, k, "mu", "/".join(p), em)
-                assert rel_leaf(_leaf(got_v, p), free[k]["v"][p]) < 2 * bar, (graph, k, "nu", "/".join(p))
+                assert rel_leaf(_leaf(got_v, p), free[k]["v"][p], 1e-13) < 2 * bar, (graph, k, "nu", "/".join(p))
                 prev = _leaf(before, p)
                 num += float(((_leaf(got_p, p) - prev - (free[k]["p"][p] - (free[k - 1]["p"][p] if k else
                                                                                 _leaf(init, p).numpy()))) ** 2).sum())
