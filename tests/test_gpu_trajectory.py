@@ -165,6 +165,7 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
             worst["bpd"] = max(worst["bpd"], abs(bpd - free[k]["bpd"]))
             assert abs(bpd - free[k]["bpd"]) < 0.005, (graph, k, bpd, free[k]["bpd"])
             num = den = 0.0
+            bad = []
             for p in paths:
                 gk = _leaf(got_g, p)
                 tf_p[p], tf_m[p], tf_v[p], tf_ema[p] = onp.adamw_ema_step(
@@ -178,17 +179,24 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
                 # ---- free-running: gradients and moments at the per-leaf bar of the gradient tests; the first
                 # step's gradient is taken at identical parameters, later ones at parameters an Adam step apart
                 bar = 2e-3 if k == 0 else 2e-2
+                if np.abs(free[k]["grads"][p]).max() < 1e-12:
+                    # a gradient that vanishes identically (the bias of the attention keys: softmax ignores a constant
+                    # added to a row of scores; float64 leaves 1e-17 of rounding noise, fp32 1e-8): noise on both sides
+                    assert np.abs(gk).max() < 1e-6, (graph, k, "/".join(p), float(np.abs(gk).max()))
+                    continue
                 eg = rel_leaf(gk, free[k]["grads"][p], 1e-6)
                 worst["grad"] = max(worst["grad"], eg)
-                assert eg < bar, (graph, k, "grad", "/".join(p), eg)
                 em = rel_leaf(_leaf(got_m, p), free[k]["m"][p], 1e-7)
                 worst["mom"] = max(worst["mom"], em)
-                assert em < bar, (graph, k, "mu", "/".join(p), em)
-                assert rel_leaf(_leaf(got_v, p), free[k]["v"][p], 1e-13) < 2 * bar, (graph, k, "nu", "/".join(p))
+                ev = rel_leaf(_leaf(got_v, p), free[k]["v"][p], 1e-13)
+                if eg >= bar or em >= bar or ev >= 2 * bar:
+                    bad.append((round(max(eg, em, ev / 2) / bar, 2), "/".join(p), f"grad {eg:.2e} mu {em:.2e} nu {ev:.2e}",
+                                f"scale {np.abs(free[k]['grads'][p]).max():.2e}"))
                 prev = _leaf(before, p)
                 num += float(((_leaf(got_p, p) - prev - (free[k]["p"][p] - (free[k - 1]["p"][p] if k else
                                                                                 _leaf(init, p).numpy()))) ** 2).sum())
                 den += float(((free[k]["p"][p] - (free[k - 1]["p"][p] if k else _leaf(init, p).numpy())) ** 2).sum())
+            assert not bad, (graph, k, bar, sorted(bad, reverse=True)[:6])
             if lr > 0:
                 upd = (num / max(den, 1e-300)) ** 0.5
                 worst["upd"] = max(worst["upd"], upd)
