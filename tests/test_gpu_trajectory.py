@@ -3,16 +3,22 @@ masked, EMA, logged scalars (ldm/experiment.py:335-356, ldm/train_state.py:70-10
 several optimiser steps against the float64 oracle, with the eager step and with the HIP-graph replay
 (GraphedStep, the build's lax.scan).
 
-Two comparisons per step:
-  * teacher-forced: the oracle's AdamW + EMA + lr schedule is fed the gradient the HIP step produced; parameters, EMA
-    and both Adam moments must then agree to fp32 rounding (1e-5 of each leaf's scale: this pins the composition --
-    lr(step) with the warm-up index, the bias-correction count, the decay mask boundary, grad_scale, EMA order);
-  * free-running: the oracle computes its own gradient (float64 autograd through its own forward, with the step's
-    noise and dropout masks re-derived from the step's keys) at its own parameters: the logged BPD of every step
-    within +-0.005 absolute (the north-star bar; measured ~1e-5), gradients within the per-leaf bar of
-    test_gpu_model.run_case, Adam moments likewise.  Adam normalises each element by its own magnitude, so a
-    gradient element that is zero to fp32 noise moves by lr in either direction: the free-running parameters are
-    compared in the update's L2 norm, not element by element.
+Every step is checked three ways:
+  * value_and_grad: the oracle (float64 autograd through its own forward, with the step's noise and dropout masks
+    re-derived from the step's keys: fold_in(rank), fold_in(step), the 'sample' / 'dropout' splits) is evaluated at
+    the parameters the device holds BEFORE the step; the logged train_bpd agrees to 1e-4 (bar: +-0.005 absolute) and
+    every parameter gradient to the per-leaf bar of test_gpu_model.run_case (2e-3 of the leaf's scale);
+  * optimizer, teacher-forced: the oracle's AdamW + EMA + lr schedule, run in float64 from step 0 on the gradients
+    the HIP steps produced, reproduces parameters, EMA and both Adam moments after EVERY step to fp32 rounding
+    (1e-5 of each leaf's scale): this pins the composition -- lr(step) with the warm-up index (lr(0) = 0: the first
+    step moves the moments only), the bias-correction count, the decay-mask boundary in the flat buffer, grad_scale,
+    the EMA order -- on the eager and on the graph-replayed path (stream-ordered lr / bias corrections);
+  * optimizer, on the oracle's own gradients: the Adam moments accumulated from the oracle's gradients agree with the
+    device's at the gradient bar.
+Why the parameters are not compared free-running: Adam divides every element by its own magnitude, so an element whose
+gradient is zero to fp32 noise moves by +-lr whichever way the noise points, and the hard top-k latent turns such a
+difference into a different discrete code within two steps (measured: encoder gradients 100 % apart at step 2).  Two
+correct implementations diverge like that; the three checks above leave no part of the step unpinned.
 """
 import os
 
@@ -98,44 +104,29 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
     keep = float(np.float32(0.9))
     lr0, ema_rate = 2e-4, 0.9
 
-    # ---- the oracle's own trajectory (free-running), computed once: inputs of step k depend on keys only
     exp0, _ = _experiment(False, vdm_type)
-    step_inputs = [_oracle_step_inputs(exp0, k, batches[k], vdm_type) for k in range(STEPS)]
+    step_inputs = [_oracle_step_inputs(exp0, k, batches[k], vdm_type) for k in range(STEPS)]     # depend on keys only
     del exp0
-    ref_p = {p: _leaf(init, p).detach().clone().numpy() for p in paths}
-    ref_ema = {p: v.copy() for p, v in ref_p.items()}
-    ref_m = {p: np.zeros_like(v) for p, v in ref_p.items()}
-    ref_v = {p: np.zeros_like(v) for p, v in ref_p.items()}
-    free = []
-    for k in range(STEPS):
-        params_k = tr.tree_map(lambda t: t, init)
+
+    def oracle_value_and_grad(k, flax_params):
+        """(bpd, {path: gradient}) of train step k at the given parameters (a float64 numpy tree, reference layout)"""
+        tree = tr.tree_map(lambda t: t, init)
         leaves = {}
         for p in paths:
-            t = torch.tensor(ref_p[p], dtype=torch.float64, requires_grad=True)
-            d = params_k
+            t = torch.tensor(_leaf(flax_params, p), dtype=torch.float64, requires_grad=True)
+            d = tree
             for key in p[:-1]:
                 d = d[key]
             d[p[-1]] = t
             leaves[p] = t
         si = step_inputs[k]
-        out = tr.mulan_forward(params_k, ocfg, batches[k], si["t0"], si["raw"], si["e0"], si["e"],
+        out = tr.mulan_forward(tree, ocfg, batches[k], si["t0"], si["raw"], si["e0"], si["e"],
                                enc_masks=si["enc_masks"], score_masks=si["score_masks"], keep=keep)
         out["bpd"].backward()
-        lr = onp.lr_schedule(k, lr0, WARMUP)
-        grads = {}
-        for p in paths:
-            gk = leaves[p].grad.numpy() if leaves[p].grad is not None else np.zeros_like(ref_p[p])
-            grads[p] = gk
-            ref_p[p], ref_m[p], ref_v[p], ref_ema[p] = onp.adamw_ema_step(
-                ref_p[p], gk, ref_m[p], ref_v[p], ref_ema[p], lr, k + 1, decay_mask[p], ema_rate=ema_rate)
-        free.append(dict(bpd=float(out["bpd"]), grads=grads, p={q: v.copy() for q, v in ref_p.items()},
-                         m={q: v.copy() for q, v in ref_m.items()}, v={q: v.copy() for q, v in ref_v.items()},
-                         ema={q: v.copy() for q, v in ref_ema.items()}))
+        return float(out["bpd"].detach()), {p: (leaves[p].grad.numpy() if leaves[p].grad is not None
+                                                else np.zeros(tuple(leaves[p].shape))) for p in paths}
 
     def rel_leaf(a, b, floor=1e-30):
-        """max |a - b| relative to the leaf's scale; `floor`: the scale below which a leaf counts as zero (the bias of
-        the attention keys has an exactly vanishing gradient -- softmax ignores a constant added to a row of scores --
-        which fp32 and float64 both approximate by their own rounding noise)"""
         return float(np.abs(a - b).max() / (np.abs(b).max() + floor))
 
     for graph in (False, True):
@@ -143,15 +134,16 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
         M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), init), exp.state.params)
         with torch.no_grad():
             exp.state.ema.copy_(exp.state.flat)
-        # teacher-forced oracle state, in float64, starting from the fp32-rounded parameters the device holds
         (p0, _, _, _), _ = _flax_state(exp)
+        zeros = lambda: {p: np.zeros_like(_leaf(p0, p)) for p in paths}
+        # teacher-forced oracle state (float64, fed the device's gradients) and the moments of the oracle's own gradients
         tf_p = {p: _leaf(p0, p).copy() for p in paths}
         tf_ema = {p: v.copy() for p, v in tf_p.items()}
-        tf_m = {p: np.zeros_like(v) for p, v in tf_p.items()}
-        tf_v = {p: np.zeros_like(v) for p, v in tf_p.items()}
-        worst = dict(tf=0.0, grad=0.0, mom=0.0, upd=0.0, bpd=0.0)
+        tf_m, tf_v, own_m, own_v = zeros(), zeros(), zeros(), zeros()
+        worst = dict(tf=0.0, grad=0.0, mom=0.0, bpd=0.0)
         for k in range(STEPS):
             (before, _, _, _), _ = _flax_state(exp)
+            want_bpd, want_g = oracle_value_and_grad(k, before)
             batch = {"images": batches[k].cuda(), "labels": torch.zeros(B, dtype=torch.int32).cuda(),
                      "conditioning": torch.zeros(B, dtype=torch.uint8).cuda()}
             assert exp.state.step == k
@@ -160,52 +152,41 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
             assert exp.state.step == k + 1
             (got_p, got_ema, got_m, got_v), got_g = _flax_state(exp)
             lr = onp.lr_schedule(k, lr0, WARMUP)
-            # logged scalar: train_bpd of this step against the free-running oracle (+-0.005 absolute)
             bpd = float(metrics["scalars"]["train_bpd"])
-            worst["bpd"] = max(worst["bpd"], abs(bpd - free[k]["bpd"]))
-            assert abs(bpd - free[k]["bpd"]) < 0.005, (graph, k, bpd, free[k]["bpd"])
-            num = den = 0.0
+            worst["bpd"] = max(worst["bpd"], abs(bpd - want_bpd))
+            assert abs(bpd - want_bpd) < 1e-3, (graph, k, bpd, want_bpd)          # (the north-star bar is 0.005)
             bad = []
             for p in paths:
                 gk = _leaf(got_g, p)
                 tf_p[p], tf_m[p], tf_v[p], tf_ema[p] = onp.adamw_ema_step(
                     tf_p[p], gk, tf_m[p], tf_v[p], tf_ema[p], lr, k + 1, decay_mask[p], ema_rate=ema_rate)
-                # ---- teacher-forced: optimizer + EMA + schedule composition, fp32 rounding only
                 for name, got, want in (("params", got_p, tf_p), ("ema", got_ema, tf_ema), ("mu", got_m, tf_m),
                                         ("nu", got_v, tf_v)):
                     err = rel_leaf(_leaf(got, p), want[p])
                     worst["tf"] = max(worst["tf"], err)
                     assert err < 1e-5, (graph, k, name, "/".join(p), err)
-                # ---- free-running: gradients and moments at the per-leaf bar of the gradient tests; the first
-                # step's gradient is taken at identical parameters, later ones at parameters an Adam step apart
-                bar = 2e-3 if k == 0 else 2e-2
-                if np.abs(free[k]["grads"][p]).max() < 1e-12:
+                _, own_m[p], own_v[p], _ = onp.adamw_ema_step(tf_p[p], want_g[p], own_m[p], own_v[p], tf_ema[p], lr, k + 1,
+                                                              decay_mask[p], ema_rate=ema_rate)
+                if np.abs(want_g[p]).max() < 1e-12:
                     # a gradient that vanishes identically (the bias of the attention keys: softmax ignores a constant
                     # added to a row of scores; float64 leaves 1e-17 of rounding noise, fp32 1e-8): noise on both sides
                     assert np.abs(gk).max() < 1e-6, (graph, k, "/".join(p), float(np.abs(gk).max()))
                     continue
-                eg = rel_leaf(gk, free[k]["grads"][p], 1e-6)
-                worst["grad"] = max(worst["grad"], eg)
-                em = rel_leaf(_leaf(got_m, p), free[k]["m"][p], 1e-7)
-                worst["mom"] = max(worst["mom"], em)
-                ev = rel_leaf(_leaf(got_v, p), free[k]["v"][p], 1e-13)
-                if eg >= bar or em >= bar or ev >= 2 * bar:
-                    bad.append((round(max(eg, em, ev / 2) / bar, 2), "/".join(p), f"grad {eg:.2e} mu {em:.2e} nu {ev:.2e}",
-                                f"scale {np.abs(free[k]['grads'][p]).max():.2e}"))
-                prev = _leaf(before, p)
-                num += float(((_leaf(got_p, p) - prev - (free[k]["p"][p] - (free[k - 1]["p"][p] if k else
-                                                                                _leaf(init, p).numpy()))) ** 2).sum())
-                den += float(((free[k]["p"][p] - (free[k - 1]["p"][p] if k else _leaf(init, p).numpy())) ** 2).sum())
-            assert not bad, (graph, k, bar, sorted(bad, reverse=True)[:6])
-            if lr > 0:
-                upd = (num / max(den, 1e-300)) ** 0.5
-                worst["upd"] = max(worst["upd"], upd)
-                assert upd < 0.1, (graph, k, upd)            # sign flips of noise-level elements: measured ~1e-2
-            else:                                            # lr(0) = 0: the first step moves the moments only
+                eg = rel_leaf(gk, want_g[p], 1e-6)
+                em = rel_leaf(_leaf(got_m, p), own_m[p], 1e-7)
+                ev = rel_leaf(_leaf(got_v, p), own_v[p], 1e-13)
+                worst["grad"], worst["mom"] = max(worst["grad"], eg), max(worst["mom"], em)
+                if eg >= 2e-3 or em >= 2e-3 or ev >= 4e-3:
+                    bad.append((round(max(eg, em, ev / 2) / 2e-3, 2), "/".join(p), f"grad {eg:.2e} mu {em:.2e} nu {ev:.2e}",
+                                f"scale {np.abs(want_g[p]).max():.2e}"))
+            assert not bad, (graph, k, sorted(bad, reverse=True)[:6])
+            if lr == 0:                                      # lr(0) = 0: the first step moves the moments only
                 for p in paths:
                     assert np.array_equal(_leaf(got_p, p), _leaf(before, p)), (graph, k, "/".join(p))
+            else:
+                assert any(not np.array_equal(_leaf(got_p, p), _leaf(before, p)) for p in paths)
         assert (exp._graphed is not None) == graph
         print(f"trajectory {vdm_type} graph={graph}: teacher-forced {worst['tf']:.2e}, gradient {worst['grad']:.2e}, "
-              f"moments {worst['mom']:.2e}, update L2 {worst['upd']:.2e}, |bpd - oracle| {worst['bpd']:.2e}")
+              f"moments {worst['mom']:.2e}, |bpd - oracle| {worst['bpd']:.2e}")
         del exp
         torch.cuda.empty_cache()
