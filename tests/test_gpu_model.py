@@ -652,7 +652,9 @@ def test_module_surface_matches_oracle(unet_type):
             got_lp = ed.decode(zz.float().cuda(), g_dev)
             assert got_lp.shape == (B, 32, 32, 3, 256)
             err = np.abs(got_lp.cpu().double().numpy() - want_lp)
-            bad = err - (1e-4 + 1e-5 * np.abs(want_lp))                   # (logits reach -2e6; measured 3e-6 relative)
+            # fp32 like the reference: each logit -0.5 u^2 (down to -2e6) carries ~3e-6 of relative error, and the
+            # log-sum-exp of a row inherits the absolute error of its largest logits
+            bad = err - (1e-4 + 1e-5 * np.abs(want_lp).max(axis=-1, keepdims=True))
             assert float(bad.max()) < 0, (float(err.max()), float(want_lp.reshape(-1)[bad.argmax()]),
                                           float(got_lp.cpu().reshape(-1)[bad.argmax()]))
             assert float(np.abs(np.exp(got_lp.cpu().double().numpy()).sum(-1) - 1).max()) < 1e-5
