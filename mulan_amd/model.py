@@ -795,7 +795,7 @@ class EncDec:
         xu = x.reshape(B, D).round().to(torch.uint8).contiguous()
         g = self._g(g_0, z)
         g = g if g.dim() == 2 else g[:, None].expand(B, D).contiguous()
-        f = encode_images(xu)
+        f = encode_images(xu).reshape(B, D)
         eps_0 = (z.reshape(B, D).to(torch.float32) - f) * torch.exp(-0.5 * g)
         _, _, recon, _, _, _ = ops.qsample(xu, g, g, g, eps_0, torch.zeros_like(eps_0))
         return -recon
