@@ -10,7 +10,7 @@ Shapes (launch order and counts tell them apart inside a kernel symbol): the fp3
 train step; forward where no GroupNorm is in front) 128->128 with residual, 256->128, 128->256 and 128->128 input
 gradients; the plane-fed forward kernel 128->128 + residual, 128->128 + FiLM bias, 256->128 + FiLM bias.
 `python3 tools/pmc_conv.py --parse <dir>` turns the three counter_collection CSVs found under <dir> into the JSON that
-bench.py reads (profiles/r02_pmc_conv3x3_f16x3.json)."""
+bench.py reads (the newest profiles/rNN_pmc_conv3x3_f16x3.json)."""
 import csv
 import glob
 import json
@@ -28,8 +28,13 @@ SHAPES = [  # name, kernel (fp32 input / plane-fed), C, N, residual, launches (d
     ("pin_fwd_128_128_res", "pin", 128, 128, True, 6),
     ("pin_fwd_128_128_film", "pin", 128, 128, False, 5),
     ("pin_fwd_256_128_film", "pin", 256, 128, False, 4),
+    # round 3: the input-gradient launches of conv1 (its dy arrives as planes from the GroupNorm backward behind it):
+    # no bias / FiLM / residual, output maxima written
+    ("pin_dgrad_128_128", "pin_plain", 128, 128, False, 7),
+    ("pin_dgrad_128_256", "pin_plain", 128, 256, False, 3),
 ]
 SYMBOL = {"fp32": "conv3x3_f16x3_v3_kernel<0, false>", "pin": "conv3x3_f16x3_v3_kernel<0, true>"}
+KIND_SYMBOL = {"fp32": "fp32", "pin": "pin", "pin_plain": "pin"}
 B = 128
 
 
@@ -51,6 +56,7 @@ def run():
         x, w = torch.randn(B, 1024, C, device="cuda"), torch.randn(3, 3, C, N, device="cuda") * 0.05
         bias = torch.randn(N, device="cuda") if (has_res or kind == "pin") else None
         cb = torch.randn(B, N, device="cuda") if (has_res or kind == "pin") else None
+        mode = 1 if cb is not None else 0
         res = torch.randn(B, 1024, N, device="cuda") if has_res else None
         wmax = ops.absmax_rows(w.view(1, -1))
         if kind == "fp32":
@@ -68,7 +74,7 @@ def run():
             y = torch.empty(B, 1024, N, device="cuda")
             ym = torch.empty(B, 16, device="cuda", dtype=torch.int32)
             for _ in range(n):
-                call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias), ptr(cb), 1,
+                call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias), ptr(cb), mode,
                      ptr(res), ptr(y), ptr(ym), B, 32, 32, C, N, stream())
         torch.cuda.synchronize()
         print("done", name, float(y[0, 0, 0]))
@@ -95,7 +101,7 @@ def parse(d):
                     (int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         start = 0
         for name, k2, C, N, has_res, n in SHAPES:
-            if k2 != kind:
+            if KIND_SYMBOL[k2] != kind:
                 continue
             ent = {"kernel": sym, "C": C, "N": N, "residual": has_res, "launches_profiled": n}
             for counter, vals in by.items():
