@@ -33,8 +33,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--width", type=int, default=128)
+    ap.add_argument("--tune", default="", help="k=v,... developer switches (mulan_set_tuning)")
     a = ap.parse_args()
-    ops.lib.load()
+    L = ops.lib.load()
+    for kv in filter(None, a.tune.split(",")):
+        k, v = kv.split("=")
+        L.mulan_set_tuning(int(k), int(v))
     B, E = a.batch, a.width
     M = B * 1024
     torch.manual_seed(0)
@@ -66,6 +70,27 @@ def main():
     dymax = ops.cached_absmax(dy)
     us = timeit(lambda: ops.linear_wgrad_planes_raw(xs, xmax, dys, dymax, B, 2 * E, E))
     report(f"dense weight gradient from planes {2 * E}x{E} (+ slab reduce)", us, M * 3 * E * 4, 2.0 * M * 2 * E * E)
+    # the same with operands that are not in the 256 MB Infinity Cache (three rotating operand sets, as in a train step)
+    sets = [(xs.clone(), dys.clone()) for _ in range(3)]
+    state = {"i": 0}
+
+    def cold():
+        a_, b_ = sets[state["i"] % 3]
+        state["i"] += 1
+        ops.linear_wgrad_planes_raw(a_, xmax, b_, dymax, B, 2 * E, E)
+    us = timeit(cold)
+    report(f"  ... cache-cold operands (3 rotating sets)", us, M * 3 * E * 4, 2.0 * M * 2 * E * E)
+    y0 = [torch.empty(B, 1024, E, device="cuda") for _ in range(3)]
+    hs = [(torch.randn(B, 1024, E, device="cuda"), torch.randn(B, 1024, E, device="cuda")) for _ in range(3)]
+    for t_ in hs:
+        ops.cached_absmax(t_[0]); ops.cached_absmax(t_[1])
+
+    def cold_fwd():
+        a_, b_ = hs[state["i"] % 3]
+        state["i"] += 1
+        ops.linear_f16x3_raw(a_, b_, wp, wmax, E, 0, planes=True)
+    us = timeit(cold_fwd)
+    report(f"nin_shortcut fwd + planes, cache-cold operands", us, M * 5 * E * 4, 2.0 * M * 2 * E * E)
     x1 = torch.randn(B, 1024, E, device="cuda")
     gn = lambda: ops.group_norm(x1, None, torch.ones(E, device="cuda"), torch.zeros(E, device="cuda"), act=True)
     us = timeit(gn)
