@@ -166,7 +166,9 @@ int mulan_gemm(const float* A, const float* B, float* C, const float* bias, cons
 /* bytes of split-K workspace mulan_gemm can use for this shape (0: none needed; workspace may be NULL) */
 size_t mulan_gemm_workspace(int M, int N, int K, int batch);
 
-/* ---- fused attention core (f16x3), S = 1024 positions, one head, C = 128 ------------------------------------
+/* ---- fused attention core (f16x3), S = 1024 positions, one head ----------------------------------------------
+ * C = 128: forward and backward (the CIFAR width, configs/cifar10-conditioned.py:70).  C = 256 (configs/imagenet32.py:70):
+ * pack + forward only -- evaluation and sampling; a training step at that width keeps the unfused products.
  * AttnBlock core softmax((q / sqrt(C)) k^T) v and its gradients (model_vdm.py:679-683, 704-802) without the
  * [1024 x 1024] score / probability matrices in HBM.  Operands are the packs of mulan_linear_pack_f16x3_batched:
  * "T" pack of x [B,1024,C]: (K = C, N = 1024, transpose = 1); "N" pack: (K = 1024, N = C, transpose = 0); *max: the

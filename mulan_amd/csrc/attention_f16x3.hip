@@ -19,7 +19,10 @@
 // the a-priori bound C max|do| max|v| + max|delta| (the split is accurate relative to each element: a loose bound only
 // raises the absolute error floor, 2^-38 of the bound).
 // Block = 4 waves = 128 columns; X / X2 / Z / Z2 tiles of the current 32 rows go through LDS (next tile's global loads
-// are in flight in registers meanwhile), the column-side fragments Y / Y2 stay in registers.  C = 128.
+// are in flight in registers meanwhile), the column-side fragments Y / Y2 stay in registers.  C = 128 for all three
+// kernels; the forward kernel also exists for C = 256 (round 3: the ImageNet-32 width; evaluation and sampling paths,
+// one block per CU at ~370 registers).  The backward kernels at C = 256 would hold Y, Y2 and the output accumulators in
+// 128 + 128 + 128 (+ 128) registers: beyond the 512 of one wave per SIMD -- they need the 16-column / 16x16x32 form.
 #include "common.h"
 #include "f16x3_common.h"
 
@@ -28,13 +31,8 @@ namespace {
 using namespace f16x3;
 
 constexpr int AS = 1024;                 // positions
-constexpr int AC = 128;                  // channels
-constexpr int NCH = AC / 16;             // 8 channel chunks
-constexpr int NDT = AC / 32;             // 4 output-channel tiles
 constexpr int XP = 80;                   // LDS pitch of a T-packed row (64 B + 16: conflict-free ds_read_b128, see PIXB)
 constexpr int ZP = 72;                   // LDS pitch of an N-packed row (conflict-free ds_read_b64 over 32 lanes)
-constexpr int X_BYTES = NCH * 32 * XP;   // 20480
-constexpr int Z_BYTES = 2 * AC * ZP;     // 18432
 constexpr float kPScale = 8192.f, kPInv = 1.f / 8192.f;
 
 struct AttnArgs {
@@ -49,9 +47,16 @@ struct AttnArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>
-__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void attn_f16x3_kernel(AttnArgs p) {
+template <int MODE, int AC = 128>
+__global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f16x3_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(AC == 128 || (AC == 256 && MODE == 0), "C = 256: forward kernel only");
+  constexpr int NCH = AC / 16;             // channel chunks (8 / 16)
+  constexpr int NDT = AC / 32;             // output-channel tiles (4 / 8)
+  constexpr int X_BYTES = NCH * 32 * XP;   // 20480 / 40960
+  constexpr int Z_BYTES = 2 * AC * ZP;     // 18432 / 36864
+  constexpr int NPX = NCH / 2;             // 16-byte pieces per thread and T-packed tile (NCH * 128 pieces)
+  constexpr int NPZ = AC / 32;             // ... and N-packed tile (8 AC pieces)
   constexpr bool BWD = MODE != 0;
   constexpr int NZ = MODE == 2 ? 2 : 1;
   unsigned char* xs = smem;                               // X tile
@@ -109,36 +114,45 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void attn_f16x3_kernel(Attn
     for (int e = 0; e < 16; ++e) { out[i][e] = 0.f; if (MODE == 2) out2[i][e] = 0.f; }
   float m_run = -3.0e38f, l_run = 0.f;                    // MODE 0: online softmax state of this lane's column (own half of the rows)
 
-  // ---- staging: 16-byte pieces, 4 per thread and tile (1024 pieces = 16 KB per tile)
-  constexpr int NSTG = 4 * ((BWD ? 2 : 1) + NZ);
+  // ---- staging: 16-byte pieces, NPX / NPZ per thread and tile (C = 128: 1024 pieces = 16 KB per tile)
+  constexpr int OX2 = NPX, OZ = (BWD ? 2 : 1) * NPX, OZ2 = OZ + NPZ;
+  constexpr int NSTG = OZ + NZ * NPZ;
   i32x4 stg[NSTG];
   auto gload = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPX; ++i) {
       const int idx = tid + 256 * i;
       // T pack: chunk c = idx >> 7, row = (idx >> 2) & 31, piece = idx & 3
       const size_t xo = (((size_t)(idx >> 7) * AS + t * 32 + ((idx >> 2) & 31)) * 64) + (idx & 3) * 16;
       stg[i] = *reinterpret_cast<const i32x4*>(X + xo);
-      if (BWD) stg[4 + i] = *reinterpret_cast<const i32x4*>(X2 + xo);
+      if (BWD) stg[OX2 + i] = *reinterpret_cast<const i32x4*>(X2 + xo);
+    }
+#pragma unroll
+    for (int i = 0; i < NPZ; ++i) {
+      const int idx = tid + 256 * i;
       // N pack: the two 16-row chunks of the tile are contiguous: [2][C][64 B]
       const size_t zo = (size_t)t * 2 * AC * 64 + (size_t)idx * 16;
-      stg[(BWD ? 8 : 4) + i] = *reinterpret_cast<const i32x4*>(Z + zo);
-      if (MODE == 2) stg[12 + i] = *reinterpret_cast<const i32x4*>(Z2 + zo);
+      stg[OZ + i] = *reinterpret_cast<const i32x4*>(Z + zo);
+      if (MODE == 2) stg[OZ2 + i] = *reinterpret_cast<const i32x4*>(Z2 + zo);
     }
   };
   auto lstore = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPX; ++i) {
       const int idx = tid + 256 * i;
       const int xd = ((idx >> 7) * 32 + ((idx >> 2) & 31)) * XP + (idx & 3) * 16;
       *reinterpret_cast<i32x4*>(xs + xd) = stg[i];
-      if (BWD) *reinterpret_cast<i32x4*>(x2s + xd) = stg[4 + i];
+      if (BWD) *reinterpret_cast<i32x4*>(x2s + xd) = stg[OX2 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPZ; ++i) {
+      const int idx = tid + 256 * i;
       const int zd = (idx >> 2) * ZP + (idx & 3) * 16;       // 72-byte pitch: 8-byte aligned stores
-      const i32x4 z = stg[(BWD ? 8 : 4) + i];
+      const i32x4 z = stg[OZ + i];
       *reinterpret_cast<i32x2*>(zs + zd) = i32x2{z[0], z[1]};
       *reinterpret_cast<i32x2*>(zs + zd + 8) = i32x2{z[2], z[3]};
       if (MODE == 2) {
-        const i32x4 z2 = stg[12 + i];
+        const i32x4 z2 = stg[OZ2 + i];
         *reinterpret_cast<i32x2*>(zs + Z_BYTES + zd) = i32x2{z2[0], z2[1]};
         *reinterpret_cast<i32x2*>(zs + Z_BYTES + zd + 8) = i32x2{z2[2], z2[3]};
       }
@@ -296,9 +310,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void attn_f16x3_kernel(Attn
     }
 }
 
-// delta[b, i] = sum_c do[b, i, c] * o[b, i, c]   (the row term of the softmax gradient)
+// delta[b, i] = sum_c do[b, i, c] * o[b, i, c]   (the row term of the softmax gradient; C = 128)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ o,
                                                          float* __restrict__ delta, size_t rows) {
+  constexpr int AC = 128;
   const size_t row = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   const int l = threadIdx.x & 31;
   if (row >= rows) return;
@@ -310,11 +325,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
   if (l == 0) delta[row] = s;
 }
 
-// Both packs of x [B, 1024, 128] in one pass over x: "T" [C/16][1024][plane][16 channels] and "N"
-// [1024/16][C][plane][16 rows] (either may be omitted).  A block takes 16 rows x 128 channels: the split values go
+// Both packs of x [B, 1024, C] in one pass over x: "T" [C/16][1024][plane][16 channels] and "N"
+// [1024/16][C][plane][16 rows] (either may be omitted).  A block takes 16 rows x C channels: the split values go
 // through LDS once as fp16 [plane][row][channel] and leave as 16-byte pieces in both orders.
+template <int AC>
 __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict__ x, const unsigned* __restrict__ xmax,
                                                         unsigned char* __restrict__ xt, unsigned char* __restrict__ xn) {
+  constexpr int NV = AC / 64;                                             // float4s / pieces per thread (2 or 4)
   __shared__ __attribute__((aligned(16))) _Float16 sp[2][16][AC + 8];     // +8 halves: rows 16 B apart in banks
   const int tid = threadIdx.x;
   const int b = blockIdx.y, rc = blockIdx.x;                // row chunk of 16 rows
@@ -322,9 +339,9 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
   scale_of(row_max16(xmax, b), sx, inv);
   const float* src = x + ((size_t)b * AS + rc * 16) * AC;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = tid + 256 * i;                          // float4 number idx of the 16 x 128 slab
-    const int row = idx >> 5, c4 = (idx & 31) * 4;
+  for (int i = 0; i < NV; ++i) {
+    const int idx = tid + 256 * i;                          // float4 number idx of the 16 x C slab
+    const int row = idx / (AC / 4), c4 = (idx % (AC / 4)) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * AC + c4);
     f16x4 hi, lo;
 #pragma unroll
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
   if (xt) {       // pieces (chunk c, row, plane, half): 16 B = 8 channels; for a chunk the 16 rows are 1 KB contiguous
     unsigned char* dst = xt + b * img;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int pc = tid + 256 * i;
       const int c = pc >> 6, row = (pc >> 2) & 15, pl = (pc >> 1) & 1, half = pc & 1;
       const i32x4 v = *reinterpret_cast<const i32x4*>(&sp[pl][row][c * 16 + half * 8]);
@@ -351,7 +368,7 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
   if (xn) {       // pieces (channel, plane, half): 8 rows of one channel; the whole row chunk is 8 KB contiguous
     unsigned char* dst = xn + b * img + (size_t)rc * AC * 64;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int pc = tid + 256 * i;
       const int ch = pc >> 2, pl = (pc >> 1) & 1, half = pc & 1;
       f16x8 v;
@@ -362,51 +379,56 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
   }
 }
 
-template <int MODE>
+template <int MODE, int AC = 128>
 int launch(const AttnArgs& a, hipStream_t stream) {
-  constexpr int smem = (MODE == 0 ? 1 : 2) * X_BYTES + (MODE == 2 ? 2 : 1) * Z_BYTES + 256;
+  constexpr int smem = (MODE == 0 ? 1 : 2) * (AC / 16) * 32 * XP + (MODE == 2 ? 2 : 1) * 2 * AC * ZP + 256;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<MODE, AC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL(attn_f16x3_kernel<MODE>, dim3(AS / 128, a.B), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((attn_f16x3_kernel<MODE, AC>), dim3(AS / 128, a.B), dim3(256), smem, stream, a);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-// Forward: o[B,1024,128] = softmax(alpha q k^T) v, lse[B,1024] = log sum_j exp(alpha q_i k_j).
-// qt / kt: "T" packs of q / k (mulan_linear_pack_f16x3_batched(x, K = 128, N = 1024, transpose = 1)); vn: "N" pack of v
-// (K = 1024, N = 128, transpose = 0); *max: the per-image maxima the packs were scaled with ([B][16]).
+// Forward: o[B,1024,C] = softmax(alpha q k^T) v, lse[B,1024] = log sum_j exp(alpha q_i k_j); C = 128 or 256.
+// qt / kt: "T" packs of q / k (mulan_linear_pack_f16x3_batched(x, K = C, N = 1024, transpose = 1)); vn: "N" pack of v
+// (K = 1024, N = C, transpose = 0); *max: the per-image maxima the packs were scaled with ([B][16]).
 MULAN_API int mulan_attention_fwd_f16x3(const void* qt, const void* kt, const void* vn, const unsigned* qmax,
                                         const unsigned* kmax, const unsigned* vmax, float* o, float* lse, int B, int S,
                                         int C, float alpha, hipStream_t stream) {
-  if (S != AS || C != AC || B <= 0 || !qt || !kt || !vn || !qmax || !kmax || !vmax || !o || !lse) return (int)hipErrorInvalidValue;
+  if (S != AS || (C != 128 && C != 256) || B <= 0 || B > 65535 || !qt || !kt || !vn || !qmax || !kmax || !vmax || !o || !lse)
+    return (int)hipErrorInvalidValue;
   AttnArgs a{};
   a.qt = static_cast<const unsigned char*>(qt); a.kt = static_cast<const unsigned char*>(kt);
   a.vn = static_cast<const unsigned char*>(vn);
   a.qmax = qmax; a.kmax = kmax; a.vmax = vmax;
   a.out = o; a.lse_out = lse; a.alpha = alpha; a.B = B;
-  return launch<0>(a, stream);
+  return C == 128 ? launch<0, 128>(a, stream) : launch<0, 256>(a, stream);
 }
 
-// Both packs of x [B,1024,128] for the attention kernels in one pass (xt and / or xn; each 4 B per element), equal bit
-// for bit to mulan_linear_pack_f16x3_batched(x, K = 128, N = 1024, transpose = 1) and (K = 1024, N = 128, transpose = 0).
+// Both packs of x [B,1024,C] (C = 128 or 256) for the attention kernels in one pass (xt and / or xn; each 4 B per element),
+// equal bit for bit to mulan_linear_pack_f16x3_batched(x, K = C, N = 1024, transpose = 1) and (K = 1024, N = C, transpose = 0).
 MULAN_API int mulan_attention_pack_f16x3(const float* x, const unsigned* xmax, void* xt, void* xn, int B, int S, int C,
                                          hipStream_t stream) {
-  if (S != AS || C != AC || B <= 0 || B > 65535 || !x || !xmax || (!xt && !xn)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_pack_kernel, dim3(AS / 16, B), dim3(256), 0, stream, x, xmax,
-                     static_cast<unsigned char*>(xt), static_cast<unsigned char*>(xn));
+  if (S != AS || (C != 128 && C != 256) || B <= 0 || B > 65535 || !x || !xmax || (!xt && !xn)) return (int)hipErrorInvalidValue;
+  if (C == 128)
+    hipLaunchKernelGGL(attn_pack_kernel<128>, dim3(AS / 16, B), dim3(256), 0, stream, x, xmax,
+                       static_cast<unsigned char*>(xt), static_cast<unsigned char*>(xn));
+  else
+    hipLaunchKernelGGL(attn_pack_kernel<256>, dim3(AS / 16, B), dim3(256), 0, stream, x, xmax,
+                       static_cast<unsigned char*>(xt), static_cast<unsigned char*>(xn));
   MULAN_CHECK_LAUNCH();
 }
 
 // delta[B,1024] = rowsum(do * o): input of mulan_attention_bwd_f16x3 (and its maxima, mulan_absmax_rows(delta, B rows))
 MULAN_API int mulan_attention_delta(const float* dout, const float* o, float* delta, int B, int S, int C,
                                     hipStream_t stream) {
-  if (S != AS || C != AC || B <= 0) return (int)hipErrorInvalidValue;
+  if (S != AS || C != 128 || B <= 0) return (int)hipErrorInvalidValue;
   const size_t rows = (size_t)B * S;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, dout, o, delta, rows);
   MULAN_CHECK_LAUNCH();
@@ -420,7 +442,7 @@ MULAN_API int mulan_attention_bwd_f16x3(const void* qt, const void* qn, const vo
                                         const unsigned* vmax, const unsigned* domax, const unsigned* dmax,
                                         const float* lse, const float* delta, float* dq, float* dk, float* dv, int B,
                                         int S, int C, float alpha, hipStream_t stream) {
-  if (S != AS || C != AC || B <= 0 || !qt || !qn || !kt || !kn || !vt || !dot || !don || !qmax || !kmax || !vmax ||
+  if (S != AS || C != 128 || B <= 0 || !qt || !qn || !kt || !kn || !vt || !dot || !don || !qmax || !kmax || !vmax ||
       !domax || !dmax || !lse || !delta || !dq || !dk || !dv)
     return (int)hipErrorInvalidValue;
   AttnArgs a{};

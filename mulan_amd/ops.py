@@ -1252,8 +1252,32 @@ def _attn_fused_ok(q):
     return CONV_MODE == "f16x3" and ATTN_F16X3 and ATTN_FUSED and S == HW and C == 128
 
 
+def _attn_fused_fwd_only_ok(q, k, v):
+    """C = 256 (the ImageNet-32 width): only the forward kernel exists in fused form -- used wherever no gradient is
+    taken through the attention (the variational-bound evaluators, the ancestral sampler)"""
+    B, S, C = q.shape
+    return (CONV_MODE == "f16x3" and ATTN_F16X3 and ATTN_FUSED and S == HW and C == 256 and B <= 65535 and
+            not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)))
+
+
+def fused_attention_forward(q, k, v):
+    """softmax((q / sqrt(C)) k^T) v by the fused forward kernel alone (no tape): C = 128 or 256"""
+    q, k, v = _c(q), _c(k), _c(v)
+    B, S, C = q.shape
+    qm, km, vm = cached_absmax(q), cached_absmax(k), cached_absmax(v)
+    qt, _ = _attn_packs(q, qm, True, False)
+    kt, _ = _attn_packs(k, km, True, False)
+    _, vn = _attn_packs(v, vm, False, True)
+    o = torch.empty_like(q)
+    lse = torch.empty((B, S), device=q.device, dtype=torch.float32)
+    _timed("attn_f16x3_kernel<fwd>", 4.0 * B * S * S * C,
+           lambda: call("mulan_attention_fwd_f16x3", ptr(qt), ptr(kt), ptr(vn), ptr(qm), ptr(km), ptr(vm), ptr(o), ptr(lse),
+                        B, S, C, 1.0 / math.sqrt(C), stream()))
+    return o
+
+
 def _attn_packs(x, xmax, want_t=True, want_n=True):
-    """("T" pack, "N" pack) of x [B, 1024, 128] for the fused attention kernels, one pass over x"""
+    """("T" pack, "N" pack) of x [B, 1024, C] (C = 128 / 256) for the fused attention kernels, one pass over x"""
     B, S, C = x.shape
     xt = torch.empty(B * S * C * 4, device=x.device, dtype=torch.uint8) if want_t else None
     xn = torch.empty(B * S * C * 4, device=x.device, dtype=torch.uint8) if want_n else None
@@ -1372,6 +1396,8 @@ class AttentionFn(torch.autograd.Function):
 def attention(q, k, v):
     if _attn_fused_ok(q):
         return FusedAttentionFn.apply(q, k, v)
+    if _attn_fused_fwd_only_ok(q, k, v):
+        return fused_attention_forward(q, k, v)
     return AttentionFn.apply(q, k, v)
 
 
