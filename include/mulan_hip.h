@@ -141,6 +141,14 @@ size_t mulan_linear_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int
 int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
                                     float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
                                     int share_chip, mulan_stream_t stream);
+/* The same weight gradient with the layer's input in fp32 (round 3): [x1 | x2] ([B,1024,C1], [B,1024,C2]; x2 / C2 may be
+ * NULL / 0) is read as it is and split while staged -- the kernel is memory bound, the split is free --, so the
+ * forward call need not hand planes on (xs = NULL above: 134 MB less written per nin_shortcut at E = 128).  xmax: the
+ * maxima of the concat = elementwise max of x1max and x2max.  Bit-identical to the planes form.  C1, C2, N % 128 == 0. */
+size_t mulan_linear_wgrad_f16x3_x32_workspace(int B, int H, int W, int C, int N, int share_chip);
+int mulan_linear_wgrad_f16x3_x32(const float* x1, const float* x2, int C1, int C2, const unsigned* xmax, const void* dys,
+                                 const unsigned* dymax, float* dw, float* workspace, int B, int H, int W, int N,
+                                 int accumulate, int share_chip, mulan_stream_t stream);
 /* The attention products (lax.dot_general in dot_product_attention, model_vdm.py:775-796, and their autodiff) on the
  * same kernels, one operand per image:  y[b] = x[b] @ W[b] (+ res) with W[b] packed by the batched pack (w: batch
  * operands [K, N], or [N, K] with transpose = 1; wmax [batch][16] = mulan_absmax_rows(w, batch rows)) at

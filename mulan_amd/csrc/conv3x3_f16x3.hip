@@ -791,6 +791,9 @@ struct WgradArgsP {
   float* slab;
   int B, H, C, N, S;
   unsigned long long* stamps;                          // dev-only (mulan_set_debug_buffer)
+  // XF32 instantiation (one-tap kernel only): x arrives in fp32 as the virtual concat [x1 | x2] ([B][HW][C1], [B][HW][C - C1])
+  // and is split while it is staged; xmax holds the maxima of the concat (elementwise max of the two tensors' maxima)
+  const float* x1f; const float* x2f; int C1;
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -805,8 +808,14 @@ __device__ __forceinline__ int clamped_exp(unsigned maxbits) {
 // TAPS = 3: one kernel row of a 3x3 convolution per block (blockIdx.y = kh).  TAPS = 1: a 1x1 "convolution", i.e. the
 // weight gradient x^T dy of a per-pixel dense layer (nin_shortcut) from the planes its forward kernel handed on: the
 // same block with only the centre tap.
-template <int TAPS>
+// XF32 (TAPS = 1): the x operand is read in fp32 and split in the staging path instead of arriving as planes.  The
+// dense weight gradient is memory bound (48 MFMAs per wave and row pair against 68 KB of operands), so the split
+// arithmetic is free there, and the layer's forward kernel no longer has to write the planes of its input (134 MB per
+// nin_shortcut at E = 128: 27 us of a 83 us launch, profiles/r03_linear_probe.log).  Same values as the planes the
+// forward kernel used to hand on (split2 of x * s with the concat's per-image scale): bit-identical dw.
+template <int TAPS, bool XF32 = false>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradArgsP p) {
+  static_assert(!XF32 || TAPS == 1, "fp32 x operand: one-tap kernel only");
   constexpr int NQ = 4 * TAPS;                   // stages per row pair: 4 k steps x TAPS
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -842,8 +851,24 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
   const __amdgpu_buffer_rsrc_t ds_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.dys), 0, p.B * nchn * 65536, kBufWord3);
   const int u = tid & 3, upl = u >> 1, uh = u & 1;
+  // fp32 x: float4 unit t = tid + 256 i (i < 8): pixel t >> 5 of the pair's 64, channel quad t & 31 of the 128-ci tile
+  const bool x_first = c0 < p.C1;
+  const int ldxf = x_first ? p.C1 : C - p.C1, cxf = x_first ? c0 : c0 - p.C1;
+  const __amdgpu_buffer_rsrc_t xf_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(x_first ? p.x1f : p.x2f), 0, XF32 ? (int)((size_t)p.B * 1024 * ldxf * 4) : 0, kBufWord3);
+  int b_stage = -1;
+  float sx_stage = 0.f;
   auto gload_x1 = [&](int pr, int i) {
     const int b = pr / pairs_per_img, h0 = (pr - b * pairs_per_img) * WG_ROWS;
+    if constexpr (XF32) {
+      if (i < 8) {
+        const int t = tid + 256 * i;
+        const int pix = t >> 5, q = t & 31;
+        const unsigned off = (unsigned)((((b * 1024 + h0 * kW + pix) * ldxf) + cxf + q * 4) * 4);
+        xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xf_rsrc, off, 0, 0);
+      }
+      return;
+    }
     const int t = (tid >> 2) + 64 * i;
     const int cc = t / X3PIX, pix = t - cc * X3PIX;
     const int prow = pix / kPW, pcol = pix - prow * kPW;
@@ -860,7 +885,37 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
     dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(ds_rsrc, off, 0, 0);
   };
   // branch free (the loop body must stay one basic block): the 128 units past the x tile land in a dummy area
+  // (XF32) the scale of the image the staged pair belongs to; set_stage_scale(pr) before the pair's first store
+  auto set_stage_scale = [&](int pr) {
+    if constexpr (XF32) {
+      const int b = pr / pairs_per_img;
+      if (b != b_stage) {
+        float inv;
+        scale_of(row_max16(p.xmax, b), sx_stage, inv);
+        b_stage = b;
+      }
+    }
+  };
   auto store_x = [&](unsigned char* buf, int i) {
+    if constexpr (XF32) {
+      if (i < 8) {
+        const int t = tid + 256 * i;
+        const int pix = t >> 5, q = t & 31;
+        const int cc = q >> 2, pixl = (pix >> 5) * kPW + (pix & 31) + 1;       // interior pixel of the haloed row layout
+        const f32x4 v = __builtin_bit_cast(f32x4, xreg[i]);
+        f16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          _Float16 h, l;
+          split2(v[e] * sx_stage, h, l);
+          hi[e] = h; lo[e] = l;
+        }
+        unsigned char* d = buf + (cc >> 1) * X3_HALF + pixl * 64 + (cc & 1) * 32 + (q & 3) * 8;
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + X3_PLANE) = lo;
+      }
+      return;
+    }
     const int t = (tid >> 2) + 64 * i;
     const int cc = t / X3PIX, pix = t - cc * X3PIX;
     const int dst = upl * X3_PLANE + (cc >> 1) * X3_HALF + pix * 64 + (cc & 1) * 32 + uh * 16;
@@ -889,6 +944,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
     for (int i = 0; i < XV; ++i) gload_x1(pair_begin, i);
 #pragma unroll
     for (int i = 0; i < DV; ++i) gload_d1(pair_begin, i);
+    set_stage_scale(pair_begin);
 #pragma unroll
     for (int i = 0; i < XV; ++i) store_x(smem, i);
 #pragma unroll
@@ -906,6 +962,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
     const unsigned char* bc = smem + cur * WG3_BUF;
     unsigned char* bn = smem + (cur ^ 1) * WG3_BUF;
     const int pr2 = min(pr + 2, last);                 // past the end: a harmless re-read of the last pair
+    set_stage_scale(min(pr + 1, last));                // (XF32) the pair in the staging registers is pair pr + 1
     const int b_now = pr / pairs_per_img;
     if (b_now != b_acc) {                              // crossed into the next image: move the accumulators to its units
       const int d = (clamped_exp(row_max16(p.xmax, b_acc)) - clamped_exp(row_max16(p.xmax, b_now))) +
@@ -1327,6 +1384,39 @@ MULAN_API int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xm
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
                B, H, C, N, S, g_mulan_debug_buffer};
   hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<1>, dim3(S, 1, (C / WG3_T) * (N / WG3_T)), dim3(256),
+                     WG3_SMEM + 64, stream, a);
+  const int E = C * N;
+  hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
+  MULAN_CHECK_LAUNCH();
+}
+
+// The same weight gradient with x in fp32 (round 3): dw[C1 + C2, N] (+)= [x1 | x2]^T dy, x1 [B, H*W, C1] and x2 [B, H*W, C2]
+// (x2 / C2 may be NULL / 0) read as they are and split while staged, dy as the planes the convolution that consumed the
+// same dy handed on.  xmax [B][16]: the maxima of the concat (elementwise max of the two tensors' maxima arrays), i.e. the
+// scale the layer's forward pass used: results equal mulan_linear_wgrad_f16x3_planes on the planes that pass would have
+// written, bit for bit -- which the forward kernel therefore need not write.  C1 and C2 multiples of 128.
+MULAN_API size_t mulan_linear_wgrad_f16x3_x32_workspace(int B, int H, int W, int C, int N, int share_chip) {
+  return mulan_linear_wgrad_f16x3_planes_workspace(B, H, W, C, N, share_chip);
+}
+
+MULAN_API int mulan_linear_wgrad_f16x3_x32(const float* x1, const float* x2, int C1, int C2, const unsigned* xmax,
+                                           const void* dys, const unsigned* dymax, float* dw, float* workspace, int B,
+                                           int H, int W, int N, int accumulate, int share_chip, hipStream_t stream) {
+  const int C = C1 + C2;
+  if (W != kW || H != 32 || B <= 0 || C1 <= 0 || C1 % WG3_T != 0 || C2 < 0 || C2 % WG3_T != 0 || N % WG3_T != 0 || !x1 ||
+      (C2 > 0 && !x2) || !dys || !xmax || !dymax || (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
+    return (int)hipErrorInvalidValue;
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<1, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int S = linear_wgrad_splits(B, H, C, N, share_chip);
+  WgradArgsP a{nullptr, static_cast<const unsigned char*>(dys), xmax, dymax, workspace, B, H, C, N, S, g_mulan_debug_buffer,
+               x1, x2, C1};
+  hipLaunchKernelGGL((conv3x3_wgrad_f16x3_planes_kernel<1, true>), dim3(S, 1, (C / WG3_T) * (N / WG3_T)), dim3(256),
                      WG3_SMEM + 64, stream, a);
   const int E = C * N;
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);

@@ -41,6 +41,8 @@ SIGNATURES = {
     "mulan_linear_f16x3": [P, P, P, P, I, I, P, P, P, P, P, P, P, I, I, I, I, P],
     "mulan_linear_wgrad_f16x3_planes_workspace": [I, I, I, I, I, I],
     "mulan_linear_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "mulan_linear_wgrad_f16x3_x32_workspace": [I, I, I, I, I, I],
+    "mulan_linear_wgrad_f16x3_x32": [P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P],
     "mulan_gemm_workspace": [I, I, I, I],
     "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P],
@@ -109,7 +111,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"mulan_rk_workspace_bytes": c_size_t, "mulan_global_norm_clip_workspace": c_size_t, "mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
              "mulan_conv3x3_pack_f16x3_bytes": c_size_t, "mulan_conv3x3_planes_bytes": c_size_t, "mulan_linear_pack_f16x3_bytes": c_size_t,
-             "mulan_linear_wgrad_f16x3_planes_workspace": c_size_t,
+             "mulan_linear_wgrad_f16x3_planes_workspace": c_size_t, "mulan_linear_wgrad_f16x3_x32_workspace": c_size_t,
              "mulan_conv3x3_wgrad_f16x3_planes_workspace": c_size_t, "mulan_conv3x3_wgrad_f16x3_workspace": c_size_t, "mulan_gemm_workspace": c_size_t, "mulan_version": c_char_p}
 
 

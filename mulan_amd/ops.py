@@ -671,6 +671,27 @@ def linear_wgrad_planes_raw(xs, xmax, dys, dymax, B, K, N, out=None):
     return dw
 
 
+def linear_wgrad_x32_raw(x1, x2, xmax, dys, dymax, B, N, out=None):
+    """dw[K1 + K2, N] = [x1 | x2]^T dy with x in fp32 (split while staged: the kernel is memory bound) and dy as the
+    planes handed on by the convolution that consumed the same dy; xmax = the maxima of the concat.  Bit-identical to
+    linear_wgrad_planes_raw on the planes the forward kernel would have written -- which it then need not write."""
+    K1 = x1.shape[-1]
+    K2 = 0 if x2 is None else x2.shape[-1]
+    share = _share_chip()
+    nbytes = lib.load().mulan_linear_wgrad_f16x3_x32_workspace(B, H, W, K1 + K2, N, share)
+    ws = torch.empty(nbytes // 4, device=x1.device, dtype=torch.float32)
+    dw = out if out is not None else torch.empty((K1 + K2, N), device=x1.device, dtype=torch.float32)
+    _timed("linear_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * (K1 + K2) * N,
+           lambda: call("mulan_linear_wgrad_f16x3_x32", ptr(x1), ptr(x2), K1, K2, ptr(xmax), ptr(dys), ptr(dymax), ptr(dw),
+                        ptr(ws), B, H, W, N, 0, share, stream()))
+    return dw
+
+
+# the dense weight gradient reads the layer's fp32 input and splits it in its staging path (round 3) instead of taking
+# planes the forward kernel wrote as a by-product; A/B switch: 0 = the round-2 plane hand-over
+LINEAR_WGRAD_X32 = _os.environ.get("MULAN_LINEAR_WGRAD_X32", "1") == "1"
+
+
 class LinearFn(torch.autograd.Function):
     """y[M,N] = x[M,K] @ w[K,N] + bias + res   (flax nn.Dense: y = x @ kernel + bias)"""
 
@@ -818,7 +839,11 @@ class Linear2Fn(torch.autograd.Function):
         ctx.xs = None
         if ctx.fast:      # one pass over both inputs, no intermediate
             wp, ctx.wmax = linear_pack(w, False)
-            if ctx.needs_input_grad[2] and (K1 + K2) % 128 == 0 and N % 128 == 0:
+            ctx.x32 = None
+            if ctx.needs_input_grad[2] and LINEAR_WGRAD_X32 and K1 % 128 == 0 and K2 % 128 == 0 and N % 128 == 0:
+                y = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias))[0].view(M, N)
+                ctx.x32 = torch.maximum(cached_absmax(x1), cached_absmax(x2))      # maxima of the concat: [B, 16]
+            elif ctx.needs_input_grad[2] and (K1 + K2) % 128 == 0 and N % 128 == 0:
                 y, _, ctx.xs, ctx.xsmax = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias), planes=True)
                 y = y.view(M, N)
             else:
@@ -853,7 +878,16 @@ class Linear2Fn(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             dw = _fresh(gvw) if gvw is not None else torch.empty_like(w)
             pl = getattr(dy, "_planes", None)
-            if ctx.xs is not None and pl is not None and pl[2] == dy._version and pl[0].numel() == M * N * 4:
+            x32 = getattr(ctx, "x32", None)
+            if x32 is not None and pl is not None and pl[2] == dy._version and pl[0].numel() == M * N * 4:
+                B_ = M // HW
+                x1v, x2v = a1.view(B_, HW, K1), a2.view(B_, HW, K2)
+                if _side_ok(gvw):
+                    _on_side(lambda: linear_wgrad_x32_raw(x1v, x2v, x32, pl[0], pl[1], B_, N, out=dw),
+                             (x1v, x2v, x32, pl[0], pl[1]))
+                else:
+                    linear_wgrad_x32_raw(x1v, x2v, x32, pl[0], pl[1], B_, N, out=dw)
+            elif ctx.xs is not None and pl is not None and pl[2] == dy._version and pl[0].numel() == M * N * 4:
                 if _side_ok(gvw):
                     xs, xsmax = ctx.xs, ctx.xsmax
                     _on_side(lambda: linear_wgrad_planes_raw(xs, xsmax, pl[0], pl[1], M // HW, K1 + K2, N, out=dw),

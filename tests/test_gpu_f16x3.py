@@ -434,7 +434,12 @@ def test_f16x3_dense_weight_gradient_from_planes(ops, B, K1, K2, N):
         dymax = ops.absmax_rows(dyd)
         wc = dev(rng.integers(-1, 2, (3, 3, N, N)).astype(np.float64))           # any 3x3 conv whose dgrad hands dy's planes on
         _, dys = ops.conv3x3_dgrad_raw(dyd, wc, dymax=dymax, planes=True)
-        dw = ops.linear_wgrad_planes_raw(xs, xsmax, dys, dymax, B, K, N).cpu().double().numpy()
+        dw_dev = ops.linear_wgrad_planes_raw(xs, xsmax, dys, dymax, B, K, N)
+        dw = dw_dev.cpu().double().numpy()
+        # round 3: the same gradient with x read in fp32 and split in the kernel's staging path (the forward kernel then
+        # writes no planes): the very same operand values, hence the same bits
+        dw32 = ops.linear_wgrad_x32_raw(x1d, x2d, xsmax, dys, dymax, B, N)
+        assert torch.equal(dw32, dw_dev)
         f32 = lambda a: a.astype(np.float32).astype(np.float64)
         ref = np.einsum("bpk,bpn->kn", f32(x), f32(dy))
         if ints:
