@@ -259,7 +259,16 @@ int mulan_groupnorm_bwd_fused_planes(const float* dy, const unsigned* dymax, con
                                      unsigned long long seed, unsigned long long offset,
                                      const unsigned long long* seed_dev, unsigned* dxmax, float* dxsum_part,
                                      float* dgamma, float* dbeta, float* dxsum, float* dxsum2, unsigned* tickets,
-                                     mulan_stream_t stream);
+                                     const unsigned* keepbits, mulan_stream_t stream);
+/* keepbits (optional): the dropout keep-bits as the forward pass drew them -- written by
+ * mulan_groupnorm_fwd_planes_keepbits (mulan_groupnorm_fwd_planes + one more output of B * C / 32 * 1024 unsigned) --, so
+ * that the backward kernel does not repeat the 10 Philox rounds per float4 (same bits either way: nn.Dropout's mask of
+ * model_vdm.py:644 is a function of (seed, element) only). */
+int mulan_groupnorm_fwd_planes_keepbits(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                        const float* beta, void* yplanes, float* mean, float* rstd, int B, int hw, int G,
+                                        float eps, int act, float keep, unsigned long long seed, unsigned long long offset,
+                                        const unsigned long long* seed_dev, unsigned* ymax, unsigned* keepbits,
+                                        mulan_stream_t stream);
 /* add1 / add2 (optional): gradients arriving through a skip path of x1 / x2 (the ResnetBlock residual, nin_shortcut),
  * added while dx is written, so that no separate accumulation pass exists.  By-products of the written gradients (the
  * dy of the convolution in front): dx1max / dx2max (optional, [B][16], mulan_absmax_rows format) and dxsum_part

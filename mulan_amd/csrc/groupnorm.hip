@@ -25,6 +25,9 @@ struct GnArgs {
   const unsigned long long* seed_dev;         // optional: dropout seed = seed ^ seed_dev[0] (stream-ordered: graph replay)
   unsigned char* yplanes;                     // optional: y as the split fp16 planes of the f16x3 kernels instead of fp32
                                               // ([B][Ct/16][HW][plane][16], scaled by the bound below); y is not written
+  unsigned* maskbits;                         // optional output (dropout on): the keep-bits as drawn, for the backward
+                                              // kernel: [B][Ct/32][256 threads][4 words] (thread t = prow * 8 + quad of
+                                              // this kernel; bit 4 i + e: element e of pixel prow + 32 i)
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
       const unsigned bits = drop_bits4(thr, p.seed, p.offset + idx4) << ((i & 7) * 4);
       mb[i >> 3] = (i & 7) ? (mb[i >> 3] | bits) : bits;
     }
+    if (p.maskbits)
+      *reinterpret_cast<uint4*>(p.maskbits + (((size_t)b * gridDim.y + blockIdx.y) * 256 + tid) * 4) =
+          make_uint4(mb[0], mb[1], mb[2], mb[3]);
   }
 #pragma clang loop unroll(full)
   for (int i = 0; i < NP; ++i) {
@@ -233,6 +239,9 @@ struct GnBwdArgs {
   // the input-gradient convolution / weight-gradient kernel in front ([B][C1/16][HW][plane][16]) INSTEAD of as fp32,
   // scaled by an a-priori bound (below) that dx1max receives; dymax: [B][16] maxima of dy (the bound needs max|dy[b]|)
   unsigned char* dx1planes; const unsigned* dymax;
+  // optional (single-pass kernel): the keep-bits the forward kernel stored (GnArgs::maskbits) instead of re-drawing them
+  // (10 Philox rounds per float4: ~45 % of this kernel's arithmetic in the dropout layers)
+  const unsigned* maskbits;
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -372,11 +381,21 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     rm = wave_max(rm); gm = wave_max(gm); dm = wave_max(dm);
     bound = ((sqrtf((float)(HW * cpg)) + 2.f) * (p.act ? 1.1f : 1.f)) * rm * gm * (dm / p.keep);
   }
-  // the forward pass's dropout mask, re-drawn while the two slabs are in flight (see gn_fwd_kernel)
+  // the forward pass's dropout mask: as stored by the forward kernel, or re-drawn while the two slabs are in flight
+  // (see gn_fwd_kernel).  Stored form: the forward thread (prow & 31, quad) holds pixels (prow & 31) + 32 j at bit 4 j;
+  // this thread's pixel prow + 64 i is its j = (prow >> 5) + 2 i -- every second nibble, from bit 4 (prow >> 5) on.
   unsigned mb[NPB / 8];
   const bool dropping = p.keep < 1.f;
   const float inv_keep = 1.f / p.keep;
-  if (dropping) {
+  if (dropping && p.maskbits) {
+    const uint4 w = *reinterpret_cast<const uint4*>(p.maskbits + (((size_t)b * gridDim.y + blockIdx.y) * 256 + (prow & 31) * 8 + quad) * 4);
+    const unsigned sh = (unsigned)(prow >> 5) * 4u;
+    const unsigned ws[4] = {w.x >> sh, w.y >> sh, w.z >> sh, w.w >> sh};
+    mb[0] = mb[1] = 0u;
+#pragma unroll
+    for (int i = 0; i < NPB; ++i)       // nibble 2 i of the shifted words -> nibble i of this thread's 16
+      mb[i >> 3] |= ((ws[i >> 2] >> ((2 * i & 7) * 4)) & 15u) << ((i & 7) * 4);
+  } else if (dropping) {
     const uint32_t thr = (uint32_t)((double)p.keep * 4294967296.0);
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
@@ -599,7 +618,7 @@ MULAN_API int mulan_groupnorm_fwd_dyn(const float* x1, const float* x2, int C1, 
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   if (ymax && Ct / 32 > 16) return (int)hipErrorInvalidValue;
-  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev, nullptr};
+  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev, nullptr, nullptr};
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
@@ -619,6 +638,25 @@ MULAN_API int mulan_groupnorm_fwd_planes(const float* x1, const float* x2, int C
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || Ct / 32 > 16) return (int)hipErrorInvalidValue;
   GnArgs a{x1, x2, C1, C2, gamma, beta, nullptr, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev,
            static_cast<unsigned char*>(yplanes)};
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+// mulan_groupnorm_fwd_planes that also stores the dropout keep-bits it drew (keepbits: B * (C1 + C2) / 32 * 1024 unsigned,
+// see GnArgs::maskbits), for mulan_groupnorm_bwd_fused_planes: the backward kernel then skips its 10 Philox rounds per
+// float4.  keep must be < 1.
+MULAN_API int mulan_groupnorm_fwd_planes_keepbits(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                                  const float* beta, void* yplanes, float* mean, float* rstd, int B, int hw,
+                                                  int G, float eps, int act, float keep, unsigned long long seed,
+                                                  unsigned long long offset, const unsigned long long* seed_dev,
+                                                  unsigned* ymax, unsigned* keepbits, hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !yplanes || !ymax || !keepbits || !(keep > 0.f) || !(keep < 1.f))
+    return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || Ct / 32 > 16) return (int)hipErrorInvalidValue;
+  GnArgs a{x1, x2, C1, C2, gamma, beta, nullptr, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev,
+           static_cast<unsigned char*>(yplanes), keepbits};
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
@@ -685,13 +723,16 @@ MULAN_API int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const 
 // fp32, so that the convolution neither splits its input nor stores planes out of the MFMA kernel.  The planes are
 // scaled with an a-priori bound of |dx[b]| (see gn_bwd_kernel_1pass) formed from dymax ([B][16] maxima of dy, as the
 // convolution that produced dy leaves them), rstd and max|gamma|; dxmax [B][16] receives that bound in the maxima format.
+// keepbits (optional): the dropout keep-bits mulan_groupnorm_fwd_planes_keepbits stored in the forward pass (else the
+// kernel re-draws them from seed / offset: same bits).
 MULAN_API int mulan_groupnorm_bwd_fused_planes(const float* dy, const unsigned* dymax, const float* x, int C,
                                                const float* gamma, const float* beta, const float* mean,
                                                const float* rstd, void* dxplanes, float* dgamma_part, float* dbeta_part,
                                                int B, int hw, int G, int act, float keep, unsigned long long seed,
                                                unsigned long long offset, const unsigned long long* seed_dev,
                                                unsigned* dxmax, float* dxsum_part, float* dgamma, float* dbeta,
-                                               float* dxsum, float* dxsum2, unsigned* tickets, hipStream_t stream) {
+                                               float* dxsum, float* dxsum2, unsigned* tickets,
+                                               const unsigned* keepbits, hipStream_t stream) {
   if (hw != HW || B <= 0 || G <= 0 || C % G != 0 || !tickets || !dgamma || !dbeta || !dgamma_part || !dbeta_part ||
       !dxplanes || !dymax || !dxmax || !(keep > 0.f) || (dxsum && !dxsum_part) || (dxsum2 && !dxsum) || C / 32 > 16 ||
       C % 32 != 0 || (size_t)B * HW * C * 4 >= 0x80000000ull)
@@ -700,7 +741,7 @@ MULAN_API int mulan_groupnorm_bwd_fused_planes(const float* dy, const unsigned* 
   if (cpg % 4 != 0 || 32 % cpg != 0) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x, nullptr, C, 0, gamma, beta, mean, rstd, nullptr, nullptr, dgamma_part, dbeta_part,
               B, G, act, keep, seed, offset, 0, dxmax, nullptr, nullptr, nullptr, dxsum_part, seed_dev, tickets, dgamma,
-              dbeta, dxsum, dxsum2, static_cast<unsigned char*>(dxplanes), dymax};
+              dbeta, dxsum, dxsum2, static_cast<unsigned char*>(dxplanes), dymax, keep < 1.f ? keepbits : nullptr};
   hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, C / 32), dim3(512), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -1021,7 +1021,8 @@ def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False):
         sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
         call("mulan_groupnorm_bwd_fused_planes", ptr(dy), ptr(dymax_in[0]), ptr(x1), C1, ptr(gamma), ptr(beta), ptr(mean),
              ptr(rstd), ptr(dxp), ptr(parts[0]), ptr(parts[1]), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(bound),
-             ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2), ptr(_gn_tickets(dy.device)), stream())
+             ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2), ptr(_gn_tickets(dy.device)),
+             ptr(getattr(ctx, "keepbits", None)), stream())
         dx1 = _planes_only_grad(x1.shape, dy.device, dxp, bound)
         if sink is not None:
             dx1._biasdone = (sink, sink2, dx1._version)
@@ -1120,6 +1121,8 @@ GN_CONV_PLANES = _os.environ.get("MULAN_GN_CONV_PLANES", "1") == "1"    # A/B sw
 # conv1 of a ResnetBlock) goes as split planes too -- the input-gradient convolution then runs on the plane-fed
 # instantiation of the kernel (no split, no plane stores out of the MFMA kernel).  A/B switch: 0 = fp32 hand-over.
 GRAD_PLANES = _os.environ.get("MULAN_GRAD_PLANES", "1") == "1"
+# the dropout keep-bits of norm2 are stored by the forward kernel and re-used by the backward kernel (A/B: 0 = re-drawn)
+KEEP_BITS = _os.environ.get("MULAN_KEEP_BITS", "1") == "1"
 
 
 def gn_conv_ok(C1, C2, N, groups):
@@ -1156,8 +1159,18 @@ class GnConv3x3Fn(torch.autograd.Function):
         mean = torch.empty((B, groups), device=dev, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         sv, sd = _seed_args(seed)
-        call("mulan_groupnorm_fwd_planes", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(ys), ptr(mean), ptr(rstd),
-             B, HW, groups, float(eps), int(act), float(keep), sv, int(offset), ptr(sd), ptr(bound), stream())
+        # dropout layer whose backward will write planes (x1_grad_planes): keep the 4 keep-bits per float4 as drawn (2 MB at
+        # B = 128, C = 128), so that the backward kernel does not repeat the Philox rounds
+        keepbits = None
+        if KEEP_BITS and float(keep) < 1.0 and ctx.x1_grad_planes and any(ctx.needs_input_grad[:5]):
+            keepbits = torch.empty(B * (Ct // 32) * 1024, device=dev, dtype=torch.int32)
+            call("mulan_groupnorm_fwd_planes_keepbits", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(ys), ptr(mean),
+                 ptr(rstd), B, HW, groups, float(eps), int(act), float(keep), sv, int(offset), ptr(sd), ptr(bound),
+                 ptr(keepbits), stream())
+        else:
+            call("mulan_groupnorm_fwd_planes", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(ys), ptr(mean), ptr(rstd),
+                 B, HW, groups, float(eps), int(act), float(keep), sv, int(offset), ptr(sd), ptr(bound), stream())
+        ctx.keepbits = keepbits
         wp, wmax = _pack_weights(w, Ct, N, 0)
         y = torch.empty((B, HW, N), device=dev, dtype=torch.float32)
         ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
@@ -1208,7 +1221,7 @@ class GnConv3x3Fn(torch.autograd.Function):
                     needs_input_grad=(True, need[4], need[5], need[6], need[7]), want_dx_max=planes_out)
         dh, dw, dbias, dcb, dres = _conv3x3_backward(conv, dy)
         gn = _Ctx(saved_tensors=(x1, x2, gamma, beta, mean, rstd), meta=ctx.meta, gv=ctx.gv_gn,
-                  bias_sink=ctx.bias_sink)
+                  bias_sink=ctx.bias_sink, keepbits=ctx.keepbits)
         dx1, dx2, dgamma, dbeta = _gn_backward(gn, dh, ds1, ds2, planes_out=planes_out)
         return (dx1, dx2, dgamma, dbeta, dw, dbias, dcb, dres) + nones
 

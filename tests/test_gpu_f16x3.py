@@ -788,6 +788,7 @@ def test_gn_backward_planes_bound_and_precision(ops):
                  ops.ptr(rstd), B, 1024, 32, 1e-6, 1, keep, 11, 64, None, None, ops.stream())
         dymax = ops.absmax_rows(dy)
         tick = torch.zeros(16, device="cuda", dtype=torch.int32)
+        kb = torch.zeros(B * (C // 32) * 1024, device="cuda", dtype=torch.int32)
 
         def run(planes):
             dx = torch.empty_like(x)
@@ -800,7 +801,7 @@ def test_gn_backward_planes_bound_and_precision(ops):
                 ops.call("mulan_groupnorm_bwd_fused_planes", ops.ptr(dy), ops.ptr(dymax), ops.ptr(x), C, ops.ptr(gamma),
                          ops.ptr(beta), ops.ptr(mean), ops.ptr(rstd), ops.ptr(dxp), ops.ptr(parts[0]), ops.ptr(parts[1]), B,
                          1024, 32, 1, keep, 11, 64, None, ops.ptr(m), ops.ptr(csum), ops.ptr(dg), ops.ptr(db), ops.ptr(sink),
-                         None, ops.ptr(tick), ops.stream())
+                         None, ops.ptr(tick), ops.ptr(kb) if planes == "kept" else None, ops.stream())
             else:
                 ops.call("mulan_groupnorm_bwd_fused", ops.ptr(dy), ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta),
                          ops.ptr(mean), ops.ptr(rstd), ops.ptr(dx), None, ops.ptr(parts[0]), ops.ptr(parts[1]), B, 1024, 32, 1,
@@ -810,6 +811,22 @@ def test_gn_backward_planes_bound_and_precision(ops):
 
         dx, _, m_ref, csum_ref, dg_ref, db_ref, sink_ref = run(False)
         _, dxp, bound, csum, dg, db, sink = run(True)
+        if keep < 1.0:
+            # the keep-bits as the forward kernel stores them (mulan_groupnorm_fwd_planes_keepbits) instead of the re-draw:
+            # the same bits, hence the same planes and sums; and the planes that kernel writes equal the plain entry point's
+            ys0, ys1 = (torch.empty(B * 1024 * C * 4, device="cuda", dtype=torch.uint8) for _ in range(2))
+            bd = torch.empty(B, 16, device="cuda", dtype=torch.int32)
+            mm, rr = torch.empty(B, 32, device="cuda"), torch.empty(B, 32, device="cuda")
+            ops.call("mulan_groupnorm_fwd_planes", ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta), ops.ptr(ys0), ops.ptr(mm),
+                     ops.ptr(rr), B, 1024, 32, 1e-6, 1, keep, 11, 64, None, ops.ptr(bd), ops.stream())
+            ops.call("mulan_groupnorm_fwd_planes_keepbits", ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta), ops.ptr(ys1),
+                     ops.ptr(mm), ops.ptr(rr), B, 1024, 32, 1e-6, 1, keep, 11, 64, None, ops.ptr(bd), ops.ptr(kb), ops.stream())
+            assert torch.equal(ys0, ys1)
+            frac = float(sum(bin(int(v) & 0xffffffff).count("1") for v in kb[:4096].cpu().tolist())) / (4096 * 32)
+            assert abs(frac - keep) < 0.01, frac
+            _, dxp_k, bound_k, csum_k, dg_k, db_k, sink_k = run("kept")
+            for a_, r_ in ((dxp_k, dxp), (bound_k, bound), (csum_k, csum), (dg_k, dg), (db_k, db), (sink_k, sink)):
+                assert torch.equal(a_, r_)
         assert int(tick.abs().sum()) == 0
         for a, r in ((csum, csum_ref), (dg, dg_ref), (db, db_ref), (sink, sink_ref)):
             assert torch.equal(a, r)
