@@ -560,12 +560,21 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+#ifdef MULAN_GN_TICKET_FENCE
+      // memory-model form of the hand-off (release on the ticket, acquire in the last block): measured as an A/B
+      // against the sc1 write-through / sc1 load recipe the kernel ships with (profiles/r03_gn_ticket_fence.log)
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + blockIdx.y, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
       const unsigned t = __hip_atomic_fetch_add(p.tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       s_last = (t == (unsigned)p.B - 1u) ? 1u : 0u;
       if (s_last) __hip_atomic_store(p.tickets + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     __syncthreads();
     if (s_last) {
+#ifdef MULAN_GN_TICKET_FENCE
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
       const int ch = tid & 31, sl = tid >> 5;                  // 16 sample lanes x 32 channels
       float a0 = 0.f, a1 = 0.f, a2 = 0.f;
       const bool want_x = p.dxsum && c0 < p.C1;
