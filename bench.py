@@ -360,7 +360,8 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
         elapsed = float(t[0])
     res = {"elapsed": elapsed, "last_bpd": float(m["scalars"]["train_bpd"]), "prime": prime,
            "graph_used": bool(exp.hip_graph and exp._graphed is not None), "E": int(config.model.sm_n_embd),
-           "n_layer": int(config.model.sm_n_layer), "conv_mode": ops.CONV_MODE, "f32_mode": None}
+           "n_layer": int(config.model.sm_n_layer), "conv_mode": ops.CONV_MODE, "f32_mode": None,
+           "graph_error": exp.graph_capture_error}
     state, res["roof"] = conv_roofline(exp, state, batches[-1], a, rank, world, B, res["E"], elapsed / steps)
     # ---- the same step with the exact-fp32 MFMA convolution kernels (MULAN_CONV_MODE=f32), for reference
     if f32_reference and world == 1 and ops.CONV_MODE != "f32":
@@ -525,7 +526,7 @@ def main():
                                      {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(
                                          ops.CONV_MODE, PEAK_F32_MFMA_TFLOPS), 4),
         "last_train_bpd": round(head["last_bpd"], 4),
-        "hip_graph": head["graph_used"],
+        "hip_graph": head["graph_used"], "hip_graph_error": head["graph_error"],
         "oracle_pin": "unpinned: the reference has no golden vectors, JAX / Flax are not installable here and no "
                       "released checkpoint is in the image (tools/verify_checkpoint.py pins it in one command)",
         "roofline": roof, "f32_mfma_mode": head["f32_mode"], "cpu_baseline": cpu, "configs": extra,

@@ -211,6 +211,9 @@ class Experiment(abc.ABC):
         # shipped configurations.  MULAN_HIP_GRAPH=1 / 0 or config.training.hip_graph=True / False override.
         env = os.environ.get("MULAN_HIP_GRAPH", "")
         want = config.training.get("hip_graph", None)
+        # asked for explicitly (config or environment): a failed capture is an error; chosen by default: a warning and
+        # the eager step (a training run must not lose the replay without anybody noticing)
+        self.hip_graph_required = want is True or (env == "1" and want is not False)
         if env in ("0", "1"):
             want = env == "1" and want is not False
         elif want is None:
@@ -218,6 +221,7 @@ class Experiment(abc.ABC):
         self.hip_graph = bool(want) and torch.device(self.device).type == "cuda"
         self._graphed = None
         self._eager_steps = 0
+        self.graph_capture_error = None      # set when a default-on capture failed and the run fell back to eager steps
 
     # ---- schedules / optimiser ------------------------------------------------------------------
     def get_lr_schedule(self):
@@ -273,8 +277,13 @@ class Experiment(abc.ABC):
                     try:
                         self._graphed = g = GraphedStep(self, state, batch)
                     except Exception as e:           # noqa: BLE001  capture is an optimisation: fall back loudly, once
-                        log.warning("HIP-graph capture of the train step failed (%s: %s); running eagerly", type(e).__name__, e)
+                        if self.hip_graph_required:
+                            raise RuntimeError("HIP-graph capture of the train step failed although it was requested "
+                                               "(config.training.hip_graph / MULAN_HIP_GRAPH=1)") from e
+                        log.warning("HIP-graph capture of the train step failed (%s: %s); running eagerly from now on "
+                                    "(steps_per_sec will show it)", type(e).__name__, e)
                         self.hip_graph = False
+                        self.graph_capture_error = f"{type(e).__name__}: {e}"
                         g = None
                 else:
                     g = None
