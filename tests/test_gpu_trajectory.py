@@ -129,6 +129,7 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
     def rel_leaf(a, b, floor=1e-30):
         return float(np.abs(a - b).max() / (np.abs(b).max() + floor))
 
+    oracle_cache = {}
     for graph in (False, True):
         exp, config = _experiment(graph, vdm_type)
         M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), init), exp.state.params)
@@ -143,7 +144,14 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
         worst = dict(tf=0.0, grad=0.0, mom=0.0, bpd=0.0)
         for k in range(STEPS):
             (before, _, _, _), _ = _flax_state(exp)
-            want_bpd, want_g = oracle_value_and_grad(k, before)
+            # (the replayed step is bit-identical to the eager one: the oracle's float64 pass of a step is reused when
+            # the device holds the very same parameters)
+            hit = oracle_cache.get(k)
+            if hit is not None and all(np.array_equal(_leaf(hit[0], p), _leaf(before, p)) for p in paths):
+                want_bpd, want_g = hit[1], hit[2]
+            else:
+                want_bpd, want_g = oracle_value_and_grad(k, before)
+                oracle_cache[k] = (before, want_bpd, want_g)
             batch = {"images": batches[k].cuda(), "labels": torch.zeros(B, dtype=torch.int32).cuda(),
                      "conditioning": torch.zeros(B, dtype=torch.uint8).cuda()}
             assert exp.state.step == k
