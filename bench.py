@@ -413,7 +413,7 @@ def dense_eval_workload(images, T):
                      "conditioning": torch.zeros(T, dtype=torch.uint8, device=exp.device)}
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            bpd, _ = exp.loss_fn(exp.state.ema_params, tiled, i, rng=rng, is_train=False)
+            bpd, _ = exp.loss_fn(exp.state.ema_params, tiled, i, rng=rng, is_train=False, same_image=True)   # as the evaluator
             bpd = float(bpd)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)

@@ -105,7 +105,7 @@ def _dense_partial(experiment, config, n_timesteps, rank, world, max_images=0):
         tiled = {'images': images, 'labels': batch['labels'].expand(n_timesteps),
                  'conditioning': torch.zeros(n_timesteps, dtype=torch.uint8, device=experiment.device)}
         with torch.no_grad():
-            bpd, _ = experiment.loss_fn(experiment.orig_params, tiled, eval_step, rng=rng, is_train=False)
+            bpd, _ = experiment.loss_fn(experiment.orig_params, tiled, eval_step, rng=rng, is_train=False, same_image=True)
         total += float(bpd)
         count += 1
         if count % 100 == 0 and rank == 0:

@@ -446,9 +446,10 @@ class Experiment_VDM(Experiment):
             keys['enc'], keys['score'] = dropout_rng.split(2)
         return keys
 
-    def loss_fn(self, params, inputs, step, rng, is_train, rngs=None, noise=None):
+    def loss_fn(self, params, inputs, step, rng, is_train, rngs=None, noise=None, same_image=False):
         """Experiment_VDM.loss_fn (ldm/experiment_vdm.py:47-78).  rngs / noise (not in the reference): the already
-        derived keys / noise tensors of this step, used by the graph-captured train step (GraphedStep)."""
+        derived keys / noise tensors of this step, used by the graph-captured train step (GraphedStep).  same_image: all
+        rows of the batch are one image (the dense evaluator): see MulanVDM.apply."""
         if rngs is None:
             rng, sample_rng = rng.split()
             rngs = {'sample': sample_rng}
@@ -456,8 +457,9 @@ class Experiment_VDM(Experiment):
                 rng, dropout_rng = rng.split()
                 rngs['dropout'] = dropout_rng
         outputs = self.state.apply_fn(params, inputs['images'], inputs.get('labels'), inputs.get('conditioning'),
-                                      step=step, rngs=rngs, deterministic=not is_train, **({} if noise is None else
-                                                                                           {'noise': noise}))
+                                      step=step, rngs=rngs, deterministic=not is_train,
+                                      **({} if noise is None else {'noise': noise}),
+                                      **({'same_image': True} if (same_image and hasattr(self.model, "parameterization")) else {}))
         rescale_to_bpd = 1. / (float(np.prod(inputs['images'].shape[1:])) * math.log(2.))
         bpd_latent = outputs.loss_klz.mean() * rescale_to_bpd
         bpd_recon = outputs.loss_recon.mean() * rescale_to_bpd

@@ -351,7 +351,11 @@ class MulanVDM(_VDMBase):
         return {"score_model": score, "encoder_model": enc, "gamma": gamma}
 
     def apply(self, params, images, labels=None, conditioning=None, step=0, rngs=None, deterministic=True,
-              noise=None, return_aux=False):
+              noise=None, return_aux=False, same_image=False):
+        """same_image (not in the reference): the caller vouches that every row of `images` is the same image (the dense
+        variational-bound evaluator tiles one test image n_timesteps times, ldm/notebook_utils.py:181-186).  The encoder
+        U-Net sees neither t nor the noise, so in evaluation mode its logits are identical for all rows: it then runs on
+        one row and the logits are broadcast (7 % of the evaluator's FLOPs; same bits)."""
         cfg = self.config
         dev = images.device
         x = images.reshape(-1, D).contiguous()
@@ -368,7 +372,11 @@ class MulanVDM(_VDMBase):
             raise ValueError("training mode needs rngs['dropout']")
         k_enc, k_score = pair if pair is not None else (drop_key.split(2) if drop_key is not None else (None, None))
         if cfg.reparam_type == 'true':
-            logits = unet_encoder(params["encoder_model"], cfg, f, _Drop(k_enc, cfg.sm_pdrop))
+            if same_image and deterministic and B > 1:
+                logits = unet_encoder(params["encoder_model"], cfg, f[:1].contiguous(), _Drop(None, 0.0))
+                logits = logits.expand(B, logits.shape[1]).contiguous()
+            else:
+                logits = unet_encoder(params["encoder_model"], cfg, f, _Drop(k_enc, cfg.sm_pdrop))
             if cfg.topk_noise_type == 'gumbel':
                 emb, kl_z = ops.topk_embedding(logits, noise["gumbel"], cfg.latent_k, tau=-1.0)
             else:

@@ -75,6 +75,16 @@ def test_dense_and_sparse_eval_match_oracle(tmp_path):
     want = np.mean([_oracle_bpd(ref_params, ocfg, np.repeat(images[i:i + 1], T, axis=0), noise) for i in range(3)])
     assert abs(got - want) < 0.005, (got, want)
 
+    # the dense evaluator runs the encoder U-Net on one copy of the image and broadcasts its logits (same_image): the
+    # same bits as running it on all T copies
+    from mulan_amd.rng import PRNGKey
+    tiled = {"images": torch.tensor(np.repeat(images[1:2], T, axis=0)).cuda(), "labels": torch.zeros(T, dtype=torch.int32).cuda(),
+             "conditioning": torch.zeros(T, dtype=torch.uint8).cuda()}
+    with torch.no_grad():
+        b_all, _ = exp.loss_fn(exp.orig_params, tiled, 0, rng=PRNGKey(0), is_train=False)
+        b_one, _ = exp.loss_fn(exp.orig_params, tiled, 0, rng=PRNGKey(0), is_train=False, same_image=True)
+    assert float(b_all) == float(b_one)
+
     got_s = ev.eval_bpd_sparse_sampling(exp, config)              # two batches of two distinct images
     noise2 = _eval_noise(exp, 2)
     want_s = np.mean([_oracle_bpd(ref_params, ocfg, images[k:k + 2], noise2) for k in (0, 2)])
