@@ -89,6 +89,21 @@ int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp
 int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp, const unsigned* wmax,
                                       const float* bias, const float* cbias, int cbias_mode, const float* res, float* y,
                                       unsigned* ymax, int B, int H, int W, int C, int N, mulan_stream_t stream);
+/* GroupNorm (+ swish) normalised inside the convolution that consumes it (round 3; ResnetBlock norm1 + swish -> conv1,
+ * norm2 + swish -> conv2 wherever no dropout is drawn: ldm/model_vdm.py:622-623,632-633,643-650 under eval_step /
+ * sample / the likelihood evaluators).  mulan_groupnorm_stats reads x once and leaves mean / rstd [B, G] and the a-priori
+ * bound of |y| ([B][16], maxima format) -- what mulan_groupnorm_fwd_planes computes, same summation order -- and
+ * mulan_conv3x3_fwd_f16x3_gn_in normalises, activates and splits x1 (, x2: virtual channel concat, C2 == C1) while it
+ * fills its patches: the result is bit for bit that of mulan_groupnorm_fwd_planes + ..._planes_in, the normalised tensor
+ * never reaches HBM (yplanes_out, optional: store it as the weight-gradient operand after all).  C1 + C2 <= 512. */
+int mulan_groupnorm_stats(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                          float* mean, float* rstd, unsigned* bound, int B, int hw, int G, float eps,
+                          mulan_stream_t stream);
+int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                  const float* beta, const float* mean, const float* rstd, int G, int act,
+                                  const unsigned* bound, const void* wp, const unsigned* wmax, const float* bias,
+                                  const float* cbias, int cbias_mode, const float* res, float* y, unsigned* ymax,
+                                  void* yplanes_out, int B, int H, int W, int N, mulan_stream_t stream);
 
 size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,
@@ -143,12 +158,14 @@ int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const 
                                     int share_chip, mulan_stream_t stream);
 /* The same weight gradient with the layer's input in fp32 (round 3): [x1 | x2] ([B,1024,C1], [B,1024,C2]; x2 / C2 may be
  * NULL / 0) is read as it is and split while staged -- the kernel is memory bound, the split is free --, so the
- * forward call need not hand planes on (xs = NULL above: 134 MB less written per nin_shortcut at E = 128).  xmax: the
- * maxima of the concat = elementwise max of x1max and x2max.  Bit-identical to the planes form.  C1, C2, N % 128 == 0. */
+ * forward call need not hand planes on (xs = NULL above: 134 MB less written per nin_shortcut at E = 128).  xmax, xmax2:
+ * the maxima of x1 and x2 as mulan_linear_f16x3 took them (the concat is scaled with their elementwise max; xmax2 unused
+ * without x2).  Bit-identical to the planes form.  C1, C2, N % 128 == 0. */
 size_t mulan_linear_wgrad_f16x3_x32_workspace(int B, int H, int W, int C, int N, int share_chip);
-int mulan_linear_wgrad_f16x3_x32(const float* x1, const float* x2, int C1, int C2, const unsigned* xmax, const void* dys,
-                                 const unsigned* dymax, float* dw, float* workspace, int B, int H, int W, int N,
-                                 int accumulate, int share_chip, mulan_stream_t stream);
+int mulan_linear_wgrad_f16x3_x32(const float* x1, const float* x2, int C1, int C2, const unsigned* xmax,
+                                 const unsigned* xmax2, const void* dys, const unsigned* dymax, float* dw,
+                                 float* workspace, int B, int H, int W, int N, int accumulate, int share_chip,
+                                 mulan_stream_t stream);
 /* The attention products (lax.dot_general in dot_product_attention, model_vdm.py:775-796, and their autodiff) on the
  * same kernels, one operand per image:  y[b] = x[b] @ W[b] (+ res) with W[b] packed by the batched pack (w: batch
  * operands [K, N], or [N, K] with transpose = 1; wmax [batch][16] = mulan_absmax_rows(w, batch rows)) at

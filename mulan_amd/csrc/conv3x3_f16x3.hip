@@ -794,6 +794,7 @@ struct WgradArgsP {
   // XF32 instantiation (one-tap kernel only): x arrives in fp32 as the virtual concat [x1 | x2] ([B][HW][C1], [B][HW][C - C1])
   // and is split while it is staged; xmax holds the maxima of the concat (elementwise max of the two tensors' maxima)
   const float* x1f; const float* x2f; int C1;
+  const unsigned* xmax2;                               // (XF32) maxima of x2: the concat's are the elementwise max of xmax, xmax2
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -828,6 +829,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
   const int nchc = C / 16, nchn = N / 16;
   const int pairs_per_img = p.H / WG_ROWS;
   const int total_pairs = p.B * pairs_per_img;
+  auto xmax_of = [&](int b) {
+    unsigned m = row_max16(p.xmax, b);
+    if constexpr (XF32) { if (p.xmax2) m = max(m, row_max16(p.xmax2, b)); }
+    return m;
+  };
   const int pair_begin = (int)((long long)blockIdx.x * total_pairs / p.S);
   const int pair_end = (int)((long long)(blockIdx.x + 1) * total_pairs / p.S);
 
@@ -891,7 +897,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
       const int b = pr / pairs_per_img;
       if (b != b_stage) {
         float inv;
-        scale_of(row_max16(p.xmax, b), sx_stage, inv);
+        scale_of(xmax_of(b), sx_stage, inv);
         b_stage = b;
       }
     }
@@ -965,7 +971,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
     set_stage_scale(min(pr + 1, last));                // (XF32) the pair in the staging registers is pair pr + 1
     const int b_now = pr / pairs_per_img;
     if (b_now != b_acc) {                              // crossed into the next image: move the accumulators to its units
-      const int d = (clamped_exp(row_max16(p.xmax, b_acc)) - clamped_exp(row_max16(p.xmax, b_now))) +
+      const int d = (clamped_exp(xmax_of(b_acc)) - clamped_exp(xmax_of(b_now))) +
                     (clamped_exp(row_max16(p.dymax, b_acc)) - clamped_exp(row_max16(p.dymax, b_now)));
       // acc *= 2^d in place on the accumulator registers (kept in the "a" class so that the register allocation of
       // the main loop is not disturbed by this rare path); four registers per block so the moves interleave.
@@ -1062,7 +1068,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 
   if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
   float sdummy, inv_x, inv_g;
-  scale_of(row_max16(p.xmax, b_acc), sdummy, inv_x);
+  scale_of(xmax_of(b_acc), sdummy, inv_x);
   scale_of(row_max16(p.dymax, b_acc), sdummy, inv_g);
   float* slab = p.slab + (size_t)blockIdx.x * 9 * C * N;
   const int ntaps = TAPS == 3 ? 9 : 1;
@@ -1275,6 +1281,28 @@ MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsig
   return mulan_launch_conv3x3_f16x3_v3(a, stream);
 }
 
+// y = conv3x3(act(GroupNorm([x1 | x2]))) + bias + cbias + res with the normalisation done inside the convolution's patch
+// fill (ResnetBlock norm1 + swish -> conv1, norm2 + swish -> conv2 where no dropout is drawn: ldm/model_vdm.py:622-656 in
+// the evaluators and the sampler): x1 (, x2: equal widths) are the fp32 inputs of the GroupNorm, mean / rstd / bound what
+// mulan_groupnorm_stats left.  Same result, bit for bit, as mulan_groupnorm_fwd_planes + mulan_conv3x3_fwd_f16x3_planes_in;
+// the normalised tensor is not written unless yplanes_out (optional, mulan_conv3x3_planes_bytes(B, 32, 32, C1 + C2)
+// bytes) asks for it as the weight-gradient kernel's operand.
+MULAN_API int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                            const float* beta, const float* mean, const float* rstd, int G, int act,
+                                            const unsigned* bound, const void* wp, const unsigned* wmax, const float* bias,
+                                            const float* cbias, int cbias_mode, const float* res, float* y, unsigned* ymax,
+                                            void* yplanes_out, int B, int H, int W, int N, hipStream_t stream) {
+  const int C = C1 + (x2 ? C2 : 0);
+  if (W != kW || B <= 0 || C <= 0 || N <= 0 || G <= 0 || !x1 || !gamma || !beta || !mean || !rstd || !bound || !wmax ||
+      (x2 && C2 != C1) || C % G != 0 || (C / G) % 4 != 0 || C > 512 || !mulan_conv3x3_f16x3_v3_eligible(H, C, N) ||
+      (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts))
+    return (int)hipErrorInvalidValue;
+  ConvArgsH a{x1, bound, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
+              cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(yplanes_out), ymax, nullptr,
+              x2, mean, rstd, gamma, beta, act, G};
+  return mulan_launch_conv3x3_f16x3_v3(a, stream);
+}
+
 MULAN_API size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N) {
   if (W != kW || H % WG_ROWS != 0) return 0;
   return (size_t)wgrad_splits_h(B, H, C, N) * 9 * C * N * sizeof(float);
@@ -1392,19 +1420,19 @@ MULAN_API int mulan_linear_wgrad_f16x3_planes(const void* xs, const unsigned* xm
 
 // The same weight gradient with x in fp32 (round 3): dw[C1 + C2, N] (+)= [x1 | x2]^T dy, x1 [B, H*W, C1] and x2 [B, H*W, C2]
 // (x2 / C2 may be NULL / 0) read as they are and split while staged, dy as the planes the convolution that consumed the
-// same dy handed on.  xmax [B][16]: the maxima of the concat (elementwise max of the two tensors' maxima arrays), i.e. the
-// scale the layer's forward pass used: results equal mulan_linear_wgrad_f16x3_planes on the planes that pass would have
+// same dy handed on.  xmax, xmax2 [B][16]: the maxima of x1 and of x2 (the kernel takes their elementwise max: the maxima
+// of the concat), i.e. the scale the layer's forward pass used: results equal mulan_linear_wgrad_f16x3_planes on the planes that pass would have
 // written, bit for bit -- which the forward kernel therefore need not write.  C1 and C2 multiples of 128.
 MULAN_API size_t mulan_linear_wgrad_f16x3_x32_workspace(int B, int H, int W, int C, int N, int share_chip) {
   return mulan_linear_wgrad_f16x3_planes_workspace(B, H, W, C, N, share_chip);
 }
 
 MULAN_API int mulan_linear_wgrad_f16x3_x32(const float* x1, const float* x2, int C1, int C2, const unsigned* xmax,
-                                           const void* dys, const unsigned* dymax, float* dw, float* workspace, int B,
+                                           const unsigned* xmax2, const void* dys, const unsigned* dymax, float* dw, float* workspace, int B,
                                            int H, int W, int N, int accumulate, int share_chip, hipStream_t stream) {
   const int C = C1 + C2;
   if (W != kW || H != 32 || B <= 0 || C1 <= 0 || C1 % WG3_T != 0 || C2 < 0 || C2 % WG3_T != 0 || N % WG3_T != 0 || !x1 ||
-      (C2 > 0 && !x2) || !dys || !xmax || !dymax || (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
+      (C2 > 0 && (!x2 || !xmax2)) || !dys || !xmax || !dymax || (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
     return (int)hipErrorInvalidValue;
   static bool configured = false;
   if (!configured) {
@@ -1415,7 +1443,7 @@ MULAN_API int mulan_linear_wgrad_f16x3_x32(const float* x1, const float* x2, int
   }
   const int S = linear_wgrad_splits(B, H, C, N, share_chip);
   WgradArgsP a{nullptr, static_cast<const unsigned char*>(dys), xmax, dymax, workspace, B, H, C, N, S, g_mulan_debug_buffer,
-               x1, x2, C1};
+               x1, x2, C1, C2 > 0 ? xmax2 : nullptr};
   hipLaunchKernelGGL((conv3x3_wgrad_f16x3_planes_kernel<1, true>), dim3(S, 1, (C / WG3_T) * (N / WG3_T)), dim3(256),
                      WG3_SMEM + 64, stream, a);
   const int E = C * N;

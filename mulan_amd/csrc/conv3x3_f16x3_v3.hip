@@ -36,6 +36,9 @@ constexpr int P3_BUF = 2 * P3_PLANE;                // 21760
 constexpr int P3_DUMMY = 3 * P3_BUF;                // 512 B dummy target for the slots past the patch
 constexpr int SMEM3_B = 3 * P3_BUF + 512;           // 65792: two blocks per CU fit the 160 KB
 constexpr int PV3 = 6;                              // float4 patch slots per thread and chunk (1360 of 1536 used)
+constexpr int GN_ENT = 48;                          // GroupNorm-fed fill: table entry (scale x 4, beta x 4, mean) per channel quad
+constexpr int GN_MAXC = 512;
+constexpr int SMEM3_GN_B = SMEM3_B + GN_MAXC / 4 * GN_ENT;   // 71936
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -63,8 +66,14 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const
 // PIN: the input arrives as split planes (written by the GroupNorm in front, mulan_groupnorm_fwd_planes): the fill is a
 // 16-byte copy per slot -- no split arithmetic and, above all, no plane stores out of this kernel (they cost 5-13 % of
 // a launch: conv_ab ablation 16 / 32 of round 2).
-template <int ABL, bool PIN = false>
+// GNF (fp32 input only): the input is the fp32 tensor IN FRONT of a GroupNorm (+ SiLU); the fill normalises, activates,
+// clamps and splits each float4 with the arithmetic of gn_fwd_kernel's planes mode (same expressions, same bound and
+// scale: the patches hold bit for bit what mulan_groupnorm_fwd_planes would have handed over), from a per-block table
+// (scale = gamma rstd, beta, mean per channel quad of this image) in LDS.  GNF = 1: nothing else (forward-only paths: the
+// normalised tensor never reaches HBM); GNF = 2: the planes are also stored (xs) for a weight-gradient kernel.
+template <int ABL, bool PIN = false, int GNF = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
+  static_assert(!(PIN && GNF), "GroupNorm-fed fill reads fp32");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,6 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   const int n0 = blockIdx.y * BN;
   const int C = p.C, N = p.N;
   const int nchunks = C / CK, npairs = nchunks / 2;
+  const int ldx = (GNF && p.x2) ? C / 2 : C;          // channels per pixel of the tensor(s) behind x (, x2)
+  const int nch1 = ldx / CK;
   // every second block of a CU runs ahead (blocks i and i + 256 share a CU under breadth-first dispatch)
   if (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_setprio(1);
   float sx, inv_x, sw, inv_w;
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
 
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       PIN ? static_cast<void*>(const_cast<unsigned char*>(p.xplanes)) : static_cast<void*>(const_cast<float*>(p.x)), 0,
-      (int)((size_t)p.B * p.H * kW * C * 4), kBufWord3);
+      (int)((size_t)p.B * p.H * kW * ldx * 4), kBufWord3);
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(p.wp), 0, 9 * C * N * 4, kBufWord3);
   const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     Slot r;
     // PIN: unit q = (plane, 8-channel half) of the pixel's 64-byte plane record, copied as it is
     const unsigned g = PIN ? (unsigned)(((b * nchunks * p.H + hh) * kW + ww) * 64 + q * 16)
-                           : (unsigned)((((b * p.H + hh) * kW + ww) * C + q * 4) * 4);
+                           : (unsigned)((((b * p.H + hh) * kW + ww) * ldx + q * 4) * 4);
     r.goff = ok ? g : 0x80000000u;
     r.ldst = inb ? (PIN ? (q >> 1) * P3_PLANE + pix * 32 + (q & 1) * 16 : pix * 32 + q * 8) : P3_DUMMY + (t & 63) * 8;
     const bool interior = inb & ((unsigned)(prow - 1) < (unsigned)TR3) & ((unsigned)ww < (unsigned)kW);
@@ -122,7 +133,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     return r;
   };
   auto load_slot = [&](const Slot& sl, int cc) {
-    return __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, sl.goff, PIN ? cc * (p.H * kW * 64) : cc * CK * 4, 0);
+    if constexpr (GNF != 0) {
+      // flat loads from a wave-uniform base (tensor, chunk) + the slot's 32-bit offset: no buffer descriptors (two more of
+      // them push uniform values out of the scalar registers: waterfall loops around the weight loads).  Slots outside
+      // the image read offset 0 -- any valid address: the fill zeroes them.
+      const bool second = cc >= nch1;
+      const unsigned long long bb = reinterpret_cast<unsigned long long>(second ? p.x2 : p.x) + (size_t)(second ? cc - nch1 : cc) * (CK * 4);
+      typedef const char __attribute__((address_space(1)))* gchar_p;
+      typedef const i32x4 __attribute__((address_space(1)))* gvec_p;
+      gchar_p base = (gchar_p)(   // (scalar base + 32-bit lane offset: the saddr form of global_load)
+          ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bb >> 32)) << 32) |
+          (unsigned)__builtin_amdgcn_readfirstlane((int)bb));
+      return *(gvec_p)(base + (sl.goff & 0x7fffffffu));
+    } else {
+      return __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, sl.goff, PIN ? cc * (p.H * kW * 64) : cc * CK * 4, 0));
+    }
+  };
+  float gn_bound = 0.f;
+  if constexpr (GNF != 0) {
+    gn_bound = __uint_as_float(row_max16(p.xmax, b));
+    const int cpg = C / p.gn_groups;
+    for (int e = tid; e < C / 4; e += 256) {
+      const int c = e * 4, g = c / cpg;
+      const float mean = p.gn_mean[b * p.gn_groups + g], rstd = p.gn_rstd[b * p.gn_groups + g];
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gn_gamma + c);
+      float* te = reinterpret_cast<float*>(smem + SMEM3_B + e * GN_ENT);
+      *reinterpret_cast<f32x4*>(te) = f32x4{ga[0] * rstd, ga[1] * rstd, ga[2] * rstd, ga[3] * rstd};
+      *reinterpret_cast<f32x4*>(te + 4) = *reinterpret_cast<const f32x4*>(p.gn_beta + c);
+      te[8] = mean;
+    }
+    __syncthreads();
+  }
+  // (GNF) table entry of channel quad q of chunk cc.  Read where it is used: fetched a few MFMAs ahead (9 more live
+  // registers) the main loop spills
+  struct GnEntry { f32x4 sc, be; float mean; };
+  auto gn_entry = [&](int q, int cc) {
+    GnEntry g;
+    const float* te = reinterpret_cast<const float*>(smem + SMEM3_B + (cc * 4 + q) * GN_ENT);
+    g.sc = *reinterpret_cast<const f32x4*>(te);
+    g.be = *reinterpret_cast<const f32x4*>(te + 4);
+    g.mean = te[8];
+    return g;
   };
   // split one float4 and store it into patch buffer `pbuf` (byte offset in LDS) and into the plane tensor
   auto store_slot = [&](int pbuf, const Slot& sl, i32x4 raw, int cc) {
@@ -130,8 +181,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
       *reinterpret_cast<i32x4*>(smem + (sl.ldst >= P3_DUMMY ? sl.ldst & ~15 : pbuf + sl.ldst)) = raw;
       return;
     }
-    const f32x4 v = __builtin_bit_cast(f32x4, raw);
+    f32x4 v = __builtin_bit_cast(f32x4, raw);
     f16x4 hi, lo;
+    if constexpr (GNF != 0) {
+      // two-wide arithmetic as in gn_fwd_kernel (v_pk_add / v_pk_fma / v_pk_mul, v_cvt_pk_f16_f32): half the issue slots
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+      const GnEntry gn = gn_entry((sl.ldst >> 3) & 3, cc);   // ldst = pix * 32 + q * 8 (dummy slots too)
+      const f32x4 sc = gn.sc, be = gn.be;
+      const float mean = gn.mean;
+      const bool ok = sl.goff != 0x80000000u;          // the convolution pads the NORMALISED tensor with zeros
+      const float bnd = ok ? gn_bound : 0.f;           // (clamping to +-0 zeroes the slot)
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        f32x2 u = __builtin_elementwise_fma(f32x2{v[e], v[e + 1]} - mean, f32x2{sc[e], sc[e + 1]}, f32x2{be[e], be[e + 1]});
+        if (p.gn_act) {
+          const f32x2 t = u * -1.4426950408889634f;
+          const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.f;
+          u = u * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        }
+        const f32x2 vs = f32x2{__builtin_amdgcn_fmed3f(u[0], -bnd, bnd), __builtin_amdgcn_fmed3f(u[1], -bnd, bnd)} * sx;
+        const f16x2v h = __builtin_convertvector(vs, f16x2v);
+        const f16x2v l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x2), f16x2v);
+        hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
+      }
+    } else
     if (ABL & 48) {         // timing only (16 / 32): realistic operand values without the split arithmetic
 #pragma unroll
       for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)(v[e] * sx); lo[e] = (_Float16)(v[e] * (sx * 0.0004f)); }
@@ -146,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     unsigned char* d = smem + (sl.ldst >= P3_DUMMY ? sl.ldst : pbuf + sl.ldst);
     *reinterpret_cast<f16x4*>(d) = hi;
     *reinterpret_cast<f16x4*>(d + (sl.ldst >= P3_DUMMY ? 0 : P3_PLANE)) = lo;
-    if (ABL & 16) return;   // timing only: no plane stores either (32: the plane stores stay)
+    if ((ABL & 16) || GNF == 1) return;   // 16: timing only, no plane stores either (32: the plane stores stay)
     const unsigned eo = sl.emit != 0xffffffffu ? sl.emit + (unsigned)cc * 65536u : 0xffffffffu;
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, hi), xs_rsrc, eo, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo == 0xffffffffu ? eo : eo + 32, 0, 0);
@@ -240,7 +314,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
       int sel_s = sel;
       asm volatile("" : "+v"(sel_s));
       const int xaddr_n = xlane + (sel_s ? x_unit_off(nA, nB, 2 * sn + 1) : x_unit_off(nA, nB, 2 * sn));
-      const int uAn = tile_index(jn, 2 * sn), uBn = tile_index(jn, 2 * sn + 1);
+      // (wave-uniform by construction; said explicitly, because with the GroupNorm-fed fill the compiler otherwise forms
+      // them in vector registers and wraps every weight load in a waterfall loop -- branches inside the loop body)
+      const int uAn = __builtin_amdgcn_readfirstlane(tile_index(jn, 2 * sn));
+      const int uBn = __builtin_amdgcn_readfirstlane(tile_index(jn, 2 * sn + 1));
       // patch traffic of this step (table above): steps 0-2 fill chunk 2 j + 2 into buffer C, steps 5-7 chunk 2 j + 3
       // into buffer A (free after the step-4 barrier)
       const bool fill0 = s <= 2, fill1 = s >= 5 && s <= 7;
@@ -371,6 +448,23 @@ bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N) { return H % TR3 == 0 
 
 int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream) {
   const dim3 grid(a.B * (a.H / TR3), a.N / BN);
+  if (a.gn_mean) {   // GroupNorm-fed forward convolution: with (xs) / without the planes as a by-product
+#define MULAN_V3_GN_LAUNCH(GNF)                                                                                       \
+  {                                                                                                                   \
+    static bool configured = false;                                                                                   \
+    if (!configured) {                                                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, false, GNF>),       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_GN_B);                     \
+      if (e != hipSuccess) return (int)e;                                                                             \
+      configured = true;                                                                                              \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, false, GNF>), grid, dim3(256), SMEM3_GN_B, stream, a);             \
+  }
+    if (a.C > GN_MAXC) return (int)hipErrorInvalidValue;
+    if (a.xs) MULAN_V3_GN_LAUNCH(2) else MULAN_V3_GN_LAUNCH(1)
+#undef MULAN_V3_GN_LAUNCH
+    return (int)hipGetLastError();
+  }
   if (a.xplanes) {   // plane-fed forward convolution
     static bool configured_pin = false;
     if (!configured_pin) {

@@ -53,7 +53,17 @@ struct ConvArgsH {
   unsigned char* xs;            // optional by-product: the split planes of x, [B][C/16][H*W][plane][16] fp16
   unsigned* ymax;               // optional by-product: [B][16] partial maxima of |y| (mulan_absmax_rows format)
   const unsigned char* xplanes; // optional: the input as split planes (format of xs, scaled by xmax) instead of x
+  // GroupNorm-fed instantiation (conv3x3_f16x3_v3.hip, GNF): x is the fp32 INPUT of the GroupNorm (+ SiLU) in front of the
+  // convolution, x2 (optional) the second half of a virtual channel concat [x | x2] of equal widths; the patch fill
+  // normalises with gn_mean / gn_rstd [B, gn_groups] and gn_gamma / gn_beta [C]; xmax is the bound mulan_groupnorm_stats left
+  const float* x2; const float* gn_mean; const float* gn_rstd; const float* gn_gamma; const float* gn_beta;
+  int gn_act, gn_groups;
 };
+
+// sigmoid on the hardware exp2 and reciprocal: the expression of groupnorm.hip's sigmoid_fast, bit for bit
+__device__ __forceinline__ float sigmoid_hw(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));

@@ -28,6 +28,8 @@ struct GnArgs {
   unsigned* maskbits;                         // optional output (dropout on): the keep-bits as drawn, for the backward
                                               // kernel: [B][Ct/32][256 threads][4 words] (thread t = prow * 8 + quad of
                                               // this kernel; bit 4 i + e: element e of pixel prow + 32 i)
+  int stats_only;                             // 1: mean / rstd and the bound (into ymax) only, nothing is normalised: the
+                                              // consumer (mulan_conv3x3_fwd_f16x3_gn_in) applies them while it fills its patches
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   // 1 / keep, hence |y| <= (sqrt(n) max|gamma| + max|beta|) / keep for every image of the launch.  Every block takes
   // the two maxima over all Ct channels itself (same value in all blocks; the loads hide behind the slab's).
   float bound = 0.f;
-  if (p.yplanes) {
+  if (p.yplanes || p.stats_only) {
     float gm = 0.f, bm = 0.f;
     for (int cc = tid; cc < Ct; cc += 256) { gm = fmaxf(gm, fabsf(p.gamma[cc])); bm = fmaxf(bm, fabsf(p.beta[cc])); }
 #pragma unroll
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
   unsigned char* pdst = p.yplanes ? p.yplanes + ((size_t)(b * (Ct >> 4) + (c >> 4)) * HW) * 64 + (c & 15) * 2 : nullptr;
   const f32x2 sc_lo = lo2(ga) * rstd, sc_hi = hi2(ga) * rstd;
 #pragma clang loop unroll(full)
-  for (int i = 0; i < NP; ++i) {
+  for (int i = 0; i < (p.stats_only ? 0 : NP); ++i) {
     const int px = prow + 32 * i;
     f32x4 o;
     {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void gn_fwd_kernel(GnArgs p) {
       for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
     }
   }
-  if (p.yplanes) amax = __float_as_uint(bound);     // what the planes were scaled with: the consumers' "maximum"
+  if (p.yplanes || p.stats_only) amax = __float_as_uint(bound);   // what the planes are scaled with: the consumers' "maximum"
   if (p.ymax) {   // this block's slab is partial maximum number blockIdx.y of image b (unused entries zeroed)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
@@ -666,6 +668,23 @@ MULAN_API int mulan_groupnorm_fwd_planes_keepbits(const float* x1, const float* 
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || Ct / 32 > 16) return (int)hipErrorInvalidValue;
   GnArgs a{x1, x2, C1, C2, gamma, beta, nullptr, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev,
            static_cast<unsigned char*>(yplanes), keepbits};
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+// Statistics pass of a GroupNorm whose normalisation happens inside its consumer (mulan_conv3x3_fwd_f16x3_gn_in: the
+// convolution normalises, activates and splits the fp32 tensor while it fills its LDS patches, so the normalised tensor
+// never reaches HBM -- forward-only paths: evaluators, sampler).  mean / rstd [B, G] and bound [B][16] (the a-priori bound
+// of |y| in the maxima format) are exactly what mulan_groupnorm_fwd_planes computes (same summation order); x is read
+// once, nothing else is written.  No dropout (keep = 1).
+MULAN_API int mulan_groupnorm_stats(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                                    float* mean, float* rstd, unsigned* bound, int B, int hw, int G, float eps,
+                                    hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !bound || !mean || !rstd) return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || Ct / 32 > 16) return (int)hipErrorInvalidValue;
+  GnArgs a{x1, x2, C1, C2, gamma, beta, nullptr, mean, rstd, B, G, eps, 0, 1.f, 0ull, 0ull, bound, nullptr, nullptr, nullptr, 1};
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(B, Ct / 32), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -42,7 +42,7 @@ SIGNATURES = {
     "mulan_linear_wgrad_f16x3_planes_workspace": [I, I, I, I, I, I],
     "mulan_linear_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "mulan_linear_wgrad_f16x3_x32_workspace": [I, I, I, I, I, I],
-    "mulan_linear_wgrad_f16x3_x32": [P, P, I, I, P, P, P, P, P, I, I, I, I, I, I, P],
+    "mulan_linear_wgrad_f16x3_x32": [P, P, I, I, P, P, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_gemm": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, LL, LL, LL, LL, F, F, P, P],
     "mulan_gemm_workspace": [I, I, I, I],
     "mulan_groupnorm_fwd": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P],
@@ -50,6 +50,8 @@ SIGNATURES = {
     "mulan_groupnorm_fwd_dyn": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P, P],
     "mulan_groupnorm_fwd_planes": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P, P],
     "mulan_conv3x3_fwd_f16x3_planes_in": [P, P, P, P, P, P, I, P, P, P, I, I, I, I, I, P],
+    "mulan_groupnorm_stats": [P, P, I, I, P, P, P, P, P, I, I, I, F, P],
+    "mulan_conv3x3_fwd_f16x3_gn_in": [P, P, I, I, P, P, P, P, I, I, P, P, P, P, P, I, P, P, P, P, I, I, I, I, P],
     "mulan_groupnorm_bwd_dyn": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, P, I, P, P, P, P, P, P],
     "mulan_groupnorm_bwd_fused": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, P, P, P, P, P, P, P, P, P, P, P, P],
     "mulan_groupnorm_bwd_fused_planes": [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, U, U, P, P, P, P, P, P, P, P, P, P],

@@ -671,9 +671,10 @@ def linear_wgrad_planes_raw(xs, xmax, dys, dymax, B, K, N, out=None):
     return dw
 
 
-def linear_wgrad_x32_raw(x1, x2, xmax, dys, dymax, B, N, out=None):
+def linear_wgrad_x32_raw(x1, x2, xmax, xmax2, dys, dymax, B, N, out=None):
     """dw[K1 + K2, N] = [x1 | x2]^T dy with x in fp32 (split while staged: the kernel is memory bound) and dy as the
-    planes handed on by the convolution that consumed the same dy; xmax = the maxima of the concat.  Bit-identical to
+    planes handed on by the convolution that consumed the same dy; xmax / xmax2 = the maxima of x1 / x2 (the kernel
+    scales the concat with their elementwise max, as the forward kernel did: no separate launch for it).  Bit-identical to
     linear_wgrad_planes_raw on the planes the forward kernel would have written -- which it then need not write."""
     K1 = x1.shape[-1]
     K2 = 0 if x2 is None else x2.shape[-1]
@@ -682,7 +683,7 @@ def linear_wgrad_x32_raw(x1, x2, xmax, dys, dymax, B, N, out=None):
     ws = torch.empty(nbytes // 4, device=x1.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((K1 + K2, N), device=x1.device, dtype=torch.float32)
     _timed("linear_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * (K1 + K2) * N,
-           lambda: call("mulan_linear_wgrad_f16x3_x32", ptr(x1), ptr(x2), K1, K2, ptr(xmax), ptr(dys), ptr(dymax), ptr(dw),
+           lambda: call("mulan_linear_wgrad_f16x3_x32", ptr(x1), ptr(x2), K1, K2, ptr(xmax), ptr(xmax2), ptr(dys), ptr(dymax), ptr(dw),
                         ptr(ws), B, H, W, N, 0, share, stream()))
     return dw
 
@@ -842,7 +843,7 @@ class Linear2Fn(torch.autograd.Function):
             ctx.x32 = None
             if ctx.needs_input_grad[2] and LINEAR_WGRAD_X32 and K1 % 128 == 0 and K2 % 128 == 0 and N % 128 == 0:
                 y = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias))[0].view(M, N)
-                ctx.x32 = torch.maximum(cached_absmax(x1), cached_absmax(x2))      # maxima of the concat: [B, 16]
+                ctx.x32 = (cached_absmax(x1), cached_absmax(x2))      # the maxima the forward kernel just used: [B, 16] each
             elif ctx.needs_input_grad[2] and (K1 + K2) % 128 == 0 and N % 128 == 0:
                 y, _, ctx.xs, ctx.xsmax = linear_f16x3_raw(x1, x2, wp, ctx.wmax, N, 0, bias=_c(bias), planes=True)
                 y = y.view(M, N)
@@ -883,10 +884,10 @@ class Linear2Fn(torch.autograd.Function):
                 B_ = M // HW
                 x1v, x2v = a1.view(B_, HW, K1), a2.view(B_, HW, K2)
                 if _side_ok(gvw):
-                    _on_side(lambda: linear_wgrad_x32_raw(x1v, x2v, x32, pl[0], pl[1], B_, N, out=dw),
-                             (x1v, x2v, x32, pl[0], pl[1]))
+                    _on_side(lambda: linear_wgrad_x32_raw(x1v, x2v, x32[0], x32[1], pl[0], pl[1], B_, N, out=dw),
+                             (x1v, x2v, x32[0], x32[1], pl[0], pl[1]))
                 else:
-                    linear_wgrad_x32_raw(x1v, x2v, x32, pl[0], pl[1], B_, N, out=dw)
+                    linear_wgrad_x32_raw(x1v, x2v, x32[0], x32[1], pl[0], pl[1], B_, N, out=dw)
             elif ctx.xs is not None and pl is not None and pl[2] == dy._version and pl[0].numel() == M * N * 4:
                 if _side_ok(gvw):
                     xs, xsmax = ctx.xs, ctx.xsmax
@@ -1123,6 +1124,17 @@ GN_CONV_PLANES = _os.environ.get("MULAN_GN_CONV_PLANES", "1") == "1"    # A/B sw
 GRAD_PLANES = _os.environ.get("MULAN_GRAD_PLANES", "1") == "1"
 # the dropout keep-bits of norm2 are stored by the forward kernel and re-used by the backward kernel (A/B: 0 = re-drawn)
 KEEP_BITS = _os.environ.get("MULAN_KEEP_BITS", "1") == "1"
+# GroupNorm normalised inside the convolution's patch fill (mulan_groupnorm_stats + mulan_conv3x3_fwd_f16x3_gn_in) where no
+# dropout is drawn.  GN_FILL: wherever the convolution's weight needs no gradient (evaluators, sampler, the ODE
+# evaluator's input-only differentiation) and the convolution has one 128-wide block of output channels: the normalised
+# tensor never reaches HBM (sampler step -6.3 %, ODE function evaluation -3.5 % at E = 128).  With N = 256 every input
+# element is normalised by two blocks and the fill's arithmetic costs more than the GroupNorm pass it saves (dense
+# evaluation at E = 256: +4.5 %), so those layers keep the plane hand-over; GN_FILL_MAX_N is that limit.
+# GN_FILL_TRAIN (A/B switch, off: the train step is 1.2 % slower with it): also in training, the convolution
+# then stores the planes for its weight gradient.
+GN_FILL = _os.environ.get("MULAN_GN_FILL", "1") == "1"
+GN_FILL_MAX_N = int(_os.environ.get("MULAN_GN_FILL_MAX_N", "128"))
+GN_FILL_TRAIN = _os.environ.get("MULAN_GN_FILL_TRAIN", "0") == "1"
 
 
 def gn_conv_ok(C1, C2, N, groups):
@@ -1154,10 +1166,15 @@ class GnConv3x3Fn(torch.autograd.Function):
         C2 = 0 if x2 is None else x2.shape[-1]
         Ct, N = C1 + C2, w.shape[-1]
         dev = x1.device
-        ys = torch.empty(B * HW * Ct * 4, device=dev, dtype=torch.uint8)
         bound = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32)
         mean = torch.empty((B, groups), device=dev, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        fill = (float(keep) >= 1.0 and (C2 == 0 or C2 == C1) and Ct <= 512 and N <= GN_FILL_MAX_N and
+                (GN_FILL_TRAIN if ctx.needs_input_grad[4] else GN_FILL))
+        if fill:
+            return GnConv3x3Fn._forward_fill(ctx, x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, act, skip, bound,
+                                             mean, rstd)
+        ys = torch.empty(B * HW * Ct * 4, device=dev, dtype=torch.uint8)
         sv, sd = _seed_args(seed)
         # dropout layer whose backward will write planes (x1_grad_planes): keep the 4 keep-bits per float4 as drawn (2 MB at
         # B = 128, C = 128), so that the backward kernel does not repeat the Philox rounds
@@ -1179,10 +1196,41 @@ class GnConv3x3Fn(torch.autograd.Function):
         _timed("conv3x3_f16x3_kernel<planes_in>", 2.0 * B * HW * 9 * Ct * N,
                lambda: call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c),
                             ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), B, H, W, Ct, N, stream()))
+        return GnConv3x3Fn._finish_forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, mean, rstd, ys, bound, wmax, y, ymax,
+                                           (groups, int(act), float(keep), seed, int(offset)), skip, mode)
+
+    @staticmethod
+    def _forward_fill(ctx, x1, x2, gamma, beta, w, bias, cbias, res, groups, eps, act, skip, bound, mean, rstd):
+        """statistics pass + the convolution that normalises inside its patch fill (no dropout): bit for bit the result of
+        the two-kernel path above"""
+        B, C1 = x1.shape[0], x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Ct, N, dev = C1 + C2, w.shape[-1], x1.device
+        call("mulan_groupnorm_stats", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(bound), B,
+             HW, groups, float(eps), stream())
+        want_planes = bool(ctx.needs_input_grad[4])
+        ys = torch.empty(B * HW * Ct * 4 if want_planes else 0, device=dev, dtype=torch.uint8)
+        ctx.keepbits = None
+        wp, wmax = _pack_weights(w, Ct, N, 0)
+        y = torch.empty((B, HW, N), device=dev, dtype=torch.float32)
+        ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
+        mode = 0 if cbias is None else (1 if cbias.dim() == 2 else 2)
+        bias_c, cb_c, res_c = _c(bias), _c(cbias), _c(res)
+        _timed("conv3x3_f16x3_kernel<gn_in>", 2.0 * B * HW * 9 * Ct * N,
+               lambda: call("mulan_conv3x3_fwd_f16x3_gn_in", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean),
+                            ptr(rstd), groups, int(act), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c), ptr(cb_c), mode,
+                            ptr(res_c), ptr(y), ptr(ymax), ptr(ys) if want_planes else None, B, H, W, N, stream()))
+        return GnConv3x3Fn._finish_forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, mean, rstd, ys, bound, wmax, y, ymax,
+                                           (groups, int(act), 1.0, 0, 0), skip, mode)
+
+    @staticmethod
+    def _finish_forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, mean, rstd, ys, bound, wmax, y, ymax, meta, skip, mode):
+        B, C1 = x1.shape[0], x1.shape[-1]
+        Ct, N = C1 + (0 if x2 is None else x2.shape[-1]), w.shape[-1]
         if ymax is not None:
             y._absmax = (ymax, y._version)
         ctx.save_for_backward(x1, x2, gamma, beta, mean, rstd, ys, w, bound)
-        ctx.meta = (groups, int(act), float(keep), seed, int(offset))
+        ctx.meta = meta
         ctx.wmax = wmax
         ctx.has = (bias is not None, None if cbias is None else cbias.dim(), res is not None)
         ctx.gv_gn = (_gv(gamma), _gv(beta))

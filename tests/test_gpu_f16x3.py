@@ -438,7 +438,7 @@ def test_f16x3_dense_weight_gradient_from_planes(ops, B, K1, K2, N):
         dw = dw_dev.cpu().double().numpy()
         # round 3: the same gradient with x read in fp32 and split in the kernel's staging path (the forward kernel then
         # writes no planes): the very same operand values, hence the same bits
-        dw32 = ops.linear_wgrad_x32_raw(x1d, x2d, xsmax, dys, dymax, B, N)
+        dw32 = ops.linear_wgrad_x32_raw(x1d, x2d, ops.absmax_rows(x1d), ops.absmax_rows(x2d) if K2 else None, dys, dymax, B, N)
         assert torch.equal(dw32, dw_dev)
         f32 = lambda a: a.astype(np.float32).astype(np.float64)
         ref = np.einsum("bpk,bpn->kn", f32(x), f32(dy))
@@ -727,6 +727,89 @@ def test_gn_conv_plane_hand_over_matches_the_two_op_path(ops, monkeypatch, B, C1
                                          (x1, x2, gamma, beta, w, bias, cb, res)) if t is not None]
     for a, r, nm in zip(got, ref, labels):
         assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-30, (nm, float((a - r).abs().max()), float(r.abs().max()))
+
+
+@pytest.mark.parametrize("B,C1,C2,N,act,cbdim,with_res", [(3, 128, 0, 128, True, 2, False), (2, 128, 128, 128, True, 2, True),
+                                                          (5, 128, 0, 256, False, None, True), (2, 256, 256, 256, True, 2, False),
+                                                          (2, 256, 0, 256, True, 3, False), (130, 128, 128, 128, True, 2, True)])
+def test_gn_normalised_inside_the_convolution_is_bit_identical(ops, monkeypatch, B, C1, C2, N, act, cbdim, with_res):
+    """mulan_groupnorm_stats + mulan_conv3x3_fwd_f16x3_gn_in (the GroupNorm normalised, activated and split inside the
+    convolution's patch fill: forward-only paths) against mulan_groupnorm_fwd_planes + ..._planes_in: the same bits --
+    output, output maxima, and the input gradient a likelihood evaluator takes through the node (kernel without
+    gradient); with MULAN_GN_FILL_TRAIN also the train-step form (the convolution stores the planes for its weight
+    gradient): every gradient identical.  Heavy-tailed input with an offset, so that the clamp, the zero padding of the
+    NORMALISED tensor and (x - mean) are all exercised; B = 130 runs two blocks per CU."""
+    torch.manual_seed(B + C1 + C2 + N)
+    Ct = C1 + C2
+    x1 = (torch.randn(B, 1024, C1, device="cuda") ** 3 + 0.7).requires_grad_(True)
+    x2 = (torch.randn(B, 1024, C2, device="cuda") * 2 - 0.4).requires_grad_(True) if C2 else None
+    gamma, beta = torch.randn(Ct, device="cuda").requires_grad_(True), (torch.randn(Ct, device="cuda") * 0.3).requires_grad_(True)
+    w = (torch.randn(3, 3, Ct, N, device="cuda") * 0.03).requires_grad_(True)
+    bias = torch.randn(N, device="cuda").requires_grad_(True)
+    cb = None if cbdim is None else (torch.randn(B, N, device="cuda") if cbdim == 2 else torch.randn(B, 1024, N, device="cuda"))
+    res = torch.randn(B, 1024, N, device="cuda") if with_res else None
+    gy = torch.randn(B, 1024, N, device="cuda")
+    leaves = [t for t in (x1, x2, gamma, beta, w, bias) if t is not None]
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    def run(fill, train):
+        monkeypatch.setattr(ops, "GN_FILL", fill)
+        monkeypatch.setattr(ops, "GN_FILL_MAX_N", 512)           # (the product path keeps N = 256 on the plane hand-over: speed only)
+        monkeypatch.setattr(ops, "GN_FILL_TRAIN", fill and train)
+        for t in leaves:
+            t.grad = None
+            t.requires_grad_(train or t is x1 or t is x2)
+        names.clear()
+        y = ops.gn_conv3x3(x1, x2, gamma, beta, w, bias, cbias=cb, res=res, act=act, keep=1.0)
+        ymax = ops.cached_absmax(y).clone()
+        (y * gy).sum().backward()
+        return [y.detach().clone(), ymax] + [t.grad.clone() for t in leaves if t.grad is not None], list(names)
+
+    for train in (False, True):
+        ref, ref_names = run(False, train)
+        got, got_names = run(True, train)
+        assert "mulan_groupnorm_fwd_planes" in ref_names and "mulan_groupnorm_stats" not in ref_names
+        assert "mulan_groupnorm_stats" in got_names and "mulan_conv3x3_fwd_f16x3_gn_in" in got_names
+        assert "mulan_groupnorm_fwd_planes" not in got_names and "mulan_conv3x3_fwd_f16x3_planes_in" not in got_names
+        assert len(ref) == len(got) == (2 + len(leaves) if train else 2 + (2 if C2 else 1))
+        for i, (a_, r_) in enumerate(zip(got, ref)):
+            assert torch.equal(a_, r_), (train, i, float((a_.float() - r_.float()).abs().max()))
+
+
+def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkeypatch):
+    """MuLAN forward under no_grad (evaluators / sampler): the ResnetBlock GroupNorms are normalised inside their
+    convolutions (no mulan_groupnorm_fwd_planes launch is left for the dropout-free eval pass, no plane tensor written);
+    the three losses are bit for bit those of the plane hand-over."""
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg = M.VDMConfig(vocab_size=256, sample_softmax=False, antithetic_time_sampling=True, with_fourier_features=True,
+                      with_attention=False, gamma_type='poly_fixedend', gamma_min=-13.3, gamma_max=5.0, sm_n_timesteps=0,
+                      sm_n_embd=128, sm_n_layer=2, sm_pdrop=0.1, forward_n_layer=1, latent_size=50, latent_k=15,
+                      encoder='unet', latent_type='topk', z_conditioning=True, reparam_type='true', unet_type='vdm',
+                      condition='input')
+    vdm = M.make_vdm("mulan_velocity", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(3)))
+    x = torch.randint(0, 256, (6, 32, 32, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    def run(fill):
+        monkeypatch.setattr(ops, "GN_FILL", fill)
+        names.clear()
+        with torch.no_grad():
+            out = vdm.apply(params, x, None, None, step=0, rngs={"sample": PRNGKey(5)}, deterministic=True)
+        return [out.loss_recon.clone(), out.loss_klz.clone(), out.loss_diff.clone()], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert "mulan_conv3x3_fwd_f16x3_gn_in" not in ref_names and ref_names.count("mulan_groupnorm_fwd_planes") > 0
+    assert got_names.count("mulan_conv3x3_fwd_f16x3_gn_in") == ref_names.count("mulan_groupnorm_fwd_planes")
+    assert "mulan_groupnorm_fwd_planes" not in got_names
+    for a_, r_ in zip(got, ref):
+        assert torch.equal(a_, r_)
 
 
 def test_gn_planes_bound_and_precision(ops):

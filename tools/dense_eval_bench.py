@@ -39,7 +39,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
-            bpd, _ = exp.loss_fn(exp.state.ema_params, tiled, i, rng=rng, is_train=False)
+            bpd, _ = exp.loss_fn(exp.state.ema_params, tiled, i, rng=rng, is_train=False, same_image=True)   # as the evaluator
         bpds.append(float(bpd))
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
