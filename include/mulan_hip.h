@@ -78,6 +78,12 @@ int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t row_len, m
  * convolution that receives it */
 int mulan_add_absmax_rows(const float* a, const float* b, float* c, unsigned* out, int rows, size_t row_len,
                           mulan_stream_t stream);
+/* ... and with the column sums of c as a second by-product: each row is a [row_len / ncols, ncols] matrix (pixels x
+ * channels), colpart [rows][16][ncols] receives 16 partial column sums per row; the sum of the rows * 16 vectors
+ * (mulan_colsum) is the bias gradient of the convolution whose output gradient c is (autodiff of the bias add of
+ * model_vdm.py:633-656 for a block output with two consumers), without a second pass over c.  256 % (ncols / 4) == 0. */
+int mulan_add_absmax_rows_colsum(const float* a, const float* b, float* c, unsigned* out, float* colpart, int rows,
+                                 size_t row_len, int ncols, mulan_stream_t stream);
 size_t mulan_conv3x3_pack_f16x3_bytes(int C, int N);
 int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int C, int N, int flip,
                              mulan_stream_t stream);

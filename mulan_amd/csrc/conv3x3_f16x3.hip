@@ -528,10 +528,16 @@ __global__ __launch_bounds__(256) void absmax_rows_kernel(const float* __restric
 
 // c = a + b with the maxima of c as above: the sum autograd would form for a tensor with two consumers (the U-Net skip
 // connections) and the maxima pass of the convolution that takes c as its dy, in one pass over the data
+// colpart (optional, [rows][kMaxParts][ncols]): the column sums of c's rows seen as [row_len / ncols, ncols] matrices,
+// one partial per block -- the bias gradient of the convolution that receives c as its output gradient is the column
+// sum of these rows * 16 small vectors instead of a second pass over c.  (ncols / 4) divides 256: a thread's float4s
+// all belong to one column quad.
 __global__ __launch_bounds__(256) void add_absmax_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               float* __restrict__ c, unsigned* __restrict__ out,
-                                                              size_t row_len4) {
+                                                              size_t row_len4, float* __restrict__ colpart, int ncols) {
   __shared__ unsigned red[4];
+  __shared__ f32x4 cred[256];
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
   const size_t base = (size_t)blockIdx.x * row_len4;
   const f32x4* ra = reinterpret_cast<const f32x4*>(a) + base;
   const f32x4* rb = reinterpret_cast<const f32x4*>(b) + base;
@@ -541,14 +547,24 @@ __global__ __launch_bounds__(256) void add_absmax_rows_kernel(const float* __res
   for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < row_len4; i += stride) {
     const f32x4 v = ra[i] + rb[i];
     rc[i] = v;
+    cs += v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
   }
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  if (colpart) cred[threadIdx.x] = cs;
   __syncthreads();
   if (threadIdx.x == 0) out[(size_t)blockIdx.x * kMaxParts + blockIdx.y] = max(max(red[0], red[1]), max(red[2], red[3]));
+  if (colpart) {     // threads t, t + q, t + 2 q, ... (q = ncols / 4 column quads) hold the same columns: fixed order
+    const int q = ncols >> 2;
+    if ((int)threadIdx.x < q) {
+      f32x4 t = cred[threadIdx.x];
+      for (int j = threadIdx.x + q; j < 256; j += q) t += cred[j];
+      reinterpret_cast<f32x4*>(colpart)[((size_t)blockIdx.x * kMaxParts + blockIdx.y) * q + threadIdx.x] = t;
+    }
+  }
 }
 
 // wp[t][cc][o][plane][k] = split2( s_w * Wl[t][cc*16 + k][o] ),  Wl = w (flip = 0) or the tap-flipped,
@@ -1204,7 +1220,22 @@ MULAN_API int mulan_absmax_rows(const float* x, unsigned* out, int rows, size_t 
 MULAN_API int mulan_add_absmax_rows(const float* a, const float* b, float* c, unsigned* out, int rows, size_t row_len,
                                     hipStream_t stream) {
   if (rows <= 0 || row_len == 0 || row_len % 4 != 0 || !a || !b || !c || !out) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(add_absmax_rows_kernel, dim3(rows, kMaxParts), dim3(256), 0, stream, a, b, c, out, row_len / 4);
+  hipLaunchKernelGGL(add_absmax_rows_kernel, dim3(rows, kMaxParts), dim3(256), 0, stream, a, b, c, out, row_len / 4,
+                     static_cast<float*>(nullptr), 0);
+  MULAN_CHECK_LAUNCH();
+}
+
+// The same with the column sums of c as a by-product: every row is a [row_len / ncols, ncols] matrix (pixels x channels);
+// colpart [rows][16][ncols] receives 16 partial column sums per row (the sum of all rows * 16 vectors is the column sum of
+// c: the bias gradient of the layer whose output gradient c is, without a second pass over c).  ncols % 4 == 0,
+// 256 % (ncols / 4) == 0, row_len % ncols == 0.
+MULAN_API int mulan_add_absmax_rows_colsum(const float* a, const float* b, float* c, unsigned* out, float* colpart,
+                                           int rows, size_t row_len, int ncols, hipStream_t stream) {
+  if (rows <= 0 || row_len == 0 || row_len % 4 != 0 || !a || !b || !c || !out || !colpart || ncols <= 0 || ncols % 4 != 0 ||
+      256 % (ncols / 4) != 0 || row_len % ncols != 0)
+    return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_absmax_rows_kernel, dim3(rows, kMaxParts), dim3(256), 0, stream, a, b, c, out, row_len / 4,
+                     colpart, ncols);
   MULAN_CHECK_LAUNCH();
 }
 

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mulan_conv3x3_wgrad_bf16x6": [P, P, P, P, I, I, I, I, I, I, P],
     "mulan_absmax_rows": [P, P, I, Z, P],
     "mulan_add_absmax_rows": [P, P, P, P, I, Z, P],
+    "mulan_add_absmax_rows_colsum": [P, P, P, P, P, I, Z, I, P],
     "mulan_conv3x3_pack_f16x3_bytes": [I, I],
     "mulan_conv3x3_pack_f16x3": [P, P, P, I, I, I, P],
     "mulan_conv3x3_fwd_f16x3": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],

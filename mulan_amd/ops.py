@@ -159,6 +159,9 @@ def view_keep_absmax(x, *shape):
     return v
 
 
+TEE_COLSUM = _os.environ.get("MULAN_TEE_COLSUM", "1") == "1"     # A/B switch: 0 = the bias gradient takes its own pass
+
+
 class TeeFn(torch.autograd.Function):
     """(x, x) for a tensor with two consumers (a U-Net skip connection): the backward pass forms the sum of the two
     gradients itself, in one kernel that also leaves the maxima of the sum for the convolution behind it (instead of
@@ -183,7 +186,16 @@ class TeeFn(torch.autograd.Function):
             return ga + gb
         out = torch.empty_like(ga)
         m = torch.empty((ga.shape[0], MAX_PARTS), device=ga.device, dtype=torch.int32)
-        call("mulan_add_absmax_rows", ptr(ga), ptr(gb), ptr(out), ptr(m), ga.shape[0], ga.numel() // ga.shape[0], stream())
+        N = ga.shape[-1]
+        if TEE_COLSUM and ga.dim() == 3 and N % 4 == 0 and 256 % (N // 4) == 0:
+            # the sum is the output gradient of the convolution that produced x: leave its column sums (16 partial vectors
+            # per image) for that convolution's bias gradient, which then needs no pass of its own over the tensor
+            parts = torch.empty((ga.shape[0] * MAX_PARTS, N), device=ga.device, dtype=torch.float32)
+            call("mulan_add_absmax_rows_colsum", ptr(ga), ptr(gb), ptr(out), ptr(m), ptr(parts), ga.shape[0],
+                 ga.numel() // ga.shape[0], N, stream())
+            out._colsum_parts = (parts, out._version)
+        else:
+            call("mulan_add_absmax_rows", ptr(ga), ptr(gb), ptr(out), ptr(m), ga.shape[0], ga.numel() // ga.shape[0], stream())
         out._absmax = (m, out._version)
         return out
 
@@ -563,11 +575,20 @@ def _conv3x3_backward(ctx, dy):
                                            dymax=dymax)
         dbias = dcb = None
         per_sample = None
-        if (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):
+        parts = getattr(dy, "_colsum_parts", None)         # left by TeeFn.backward's add: 16 partial column sums per image
+        if parts is not None and not (parts[1] == dy._version and parts[0].shape[1] == N):
+            parts = None
+        if parts is not None and has_bias and ctx.needs_input_grad[2] and not (cb_dim == 2 and ctx.needs_input_grad[3]):
+            dbias = colsum_raw(parts[0], 1, parts[0].shape[0], N, out=_fresh(gvb).view(1, N) if gvb is not None else None).view(N)
+            try:
+                dy._biasgrad = (dbias.view(N), dy._version, None)
+            except (AttributeError, RuntimeError):
+                pass
+        elif (has_bias and ctx.needs_input_grad[2]) or (cb_dim == 2 and ctx.needs_input_grad[3]):
             cs = getattr(dy, "_colsum", None)              # left by the GroupNorm backward that produced dy
             per_sample = cs[0] if (cs is not None and cs[1] == dy._version and cs[0].shape == (B, N)) \
                 else colsum_raw(dy, B, HW, N)              # [B,N]
-        if has_bias and ctx.needs_input_grad[2]:
+        if dbias is None and has_bias and ctx.needs_input_grad[2]:
             done = getattr(dy, "_biasdone", None)          # the GroupNorm backward already summed it into the sink
             twin = None
             if (done is not None and done[2] == dy._version and gvb is not None and

@@ -323,6 +323,53 @@ def test_param_packer_matches_per_layer_packs(ops):
     assert not (packer.packed.data_ptr() <= wp.data_ptr() < packer.packed.data_ptr() + packer.packed.numel())
 
 
+@pytest.mark.parametrize("B,N", [(3, 128), (2, 256), (5, 512)])
+def test_tee_backward_leaves_the_bias_gradient_of_the_producer(ops, monkeypatch, B, N):
+    """TeeFn.backward (sum of the two gradients of a block output with two consumers, mulan_add_absmax_rows_colsum) leaves 16
+    partial column sums per image; the convolution that produced the tensor takes its bias gradient from them (one small
+    launch) instead of a pass over the summed gradient: same bias gradient as the two-pass route to fp32 rounding, all
+    other gradients identical, and the partials add up to the column sums in float64."""
+    torch.manual_seed(N + B)
+    x = torch.randn(B, 1024, 128, device="cuda", requires_grad=True)
+    w = (torch.randn(3, 3, 128, N, device="cuda") * 0.05).requires_grad_(True)
+    bias = torch.randn(N, device="cuda", requires_grad=True)
+    res = torch.randn(B, 1024, N, device="cuda", requires_grad=True)
+    g1, g2 = torch.randn(B, 1024, N, device="cuda"), torch.randn(B, 1024, N, device="cuda") * 3
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    def run(on):
+        monkeypatch.setattr(ops, "TEE_COLSUM", on)
+        for t in (x, w, bias, res):
+            t.grad = None
+        names.clear()
+        y = ops.conv3x3(x, w, bias, None, res)
+        a, b = ops.tee(y)
+        ((a * g1).sum() + (b * g2).sum()).backward()
+        return [t.grad.clone() for t in (x, w, bias, res)], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert "mulan_add_absmax_rows_colsum" in got_names and "mulan_add_absmax_rows" in ref_names
+    assert got_names.count("mulan_colsum") == 1 < ref_names.count("mulan_colsum")
+    for i in (0, 1, 3):
+        assert torch.equal(got[i], ref[i])
+    want = (g1 + g2).double().sum((0, 1))
+    scale = (g1 + g2).abs().double().sum((0, 1))
+    assert float(((got[2].double() - want).abs() / scale).max()) < 2e-7
+    assert float(((ref[2].double() - want).abs() / scale).max()) < 2e-7
+    # the entry point itself: partials in float64 against the column sums of the sum, maxima as mulan_absmax_rows
+    out = torch.empty_like(g1)
+    m = torch.empty(B, 16, device="cuda", dtype=torch.int32)
+    parts = torch.empty(B * 16, N, device="cuda")
+    ops.call("mulan_add_absmax_rows_colsum", ops.ptr(g1), ops.ptr(g2), ops.ptr(out), ops.ptr(m), ops.ptr(parts), B, 1024 * N, N,
+             ops.stream())
+    assert torch.equal(out, g1 + g2)
+    assert torch.equal(m.max(1).values, ops.absmax_rows(out).max(1).values)
+    assert float(((parts.double().sum(0) - want).abs() / scale).max()) < 2e-7
+
+
 def test_group_norm_skip_adds_the_skip_gradient_in_kernel(ops):
     """GroupNormSkipFn: gradients through the aliases s1 / s2 are added inside the backward kernel; the result, its
     maxima and its per-sample channel sums equal the two-step computation"""
