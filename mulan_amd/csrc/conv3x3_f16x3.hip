@@ -830,7 +830,9 @@ __device__ __forceinline__ int clamped_exp(unsigned maxbits) {
 // arithmetic is free there, and the layer's forward kernel no longer has to write the planes of its input (134 MB per
 // nin_shortcut at E = 128: 27 us of a 83 us launch, profiles/r03_linear_probe.log).  Same values as the planes the
 // forward kernel used to hand on (split2 of x * s with the concat's per-image scale): bit-identical dw.
-template <int TAPS, bool XF32 = false>
+// PROBE16 (dev, timing only, wrong numbers): every 32x32x16 MFMA replaced by two 16x16x32 ones on the same fragments --
+// the same operand traffic and matrix-core time on the shape the chip clocks higher under its power limit
+template <int TAPS, bool XF32 = false, bool PROBE16 = false>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradArgsP p) {
   static_assert(!XF32 || TAPS == 1, "fp32 x operand: one-tap kernel only");
   constexpr int NQ = 4 * TAPS;                   // stages per row pair: 4 k steps x TAPS
@@ -1065,17 +1067,27 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[ti][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]],
-                                                                   acc[ti][i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (PROBE16) {
+              f32x16& a16 = acc[ti][i][j];
+              f32x4 c0 = {a16[0], a16[1], a16[2], a16[3]}, c1 = {a16[4], a16[5], a16[6], a16[7]};
+              c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]], c0, 0, 0, 0);
+              c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]], c1, 0, 0, 0);
+              a16[0] = c0[0]; a16[1] = c0[1]; a16[2] = c0[2]; a16[3] = c0[3];
+              a16[4] = c1[0]; a16[5] = c1[1]; a16[6] = c1[2]; a16[7] = c1[3];
+            } else {
+              acc[ti][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][i][PA[term]], bfr[ks & 1][j][PB[term]],
+                                                                     acc[ti][i][j], 0, 0, 0);
+            }
+          }
       }
 #pragma unroll
-      for (int g = 0; g < 12; ++g) {
+      for (int g = 0; g < (PROBE16 ? 24 : 12); ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        if (TAPS == 1 || (g & 3) == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        if (TAPS == 1 || (g & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, PROBE16 ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, PROBE16 ? 2 : 4, 0);
+        if (TAPS == 1 || (g & (PROBE16 ? 7 : 3)) == (PROBE16 ? 3 : 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (TAPS == 1 || (g & (PROBE16 ? 7 : 3)) == (PROBE16 ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1384,6 +1396,12 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
   const int S = wgrad_splits_p(B, H, C, N, share_chip);
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
                B, H, C, N, S, g_mulan_debug_buffer};
+  if (g_mulan_tune[7] == 1) {   // dev: timing probe (wrong numbers)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<3, false, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+    hipLaunchKernelGGL((conv3x3_wgrad_f16x3_planes_kernel<3, false, true>), dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256),
+                       WG3_SMEM + 64, stream, a);
+  } else
   hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<3>, dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256), WG3_SMEM + 64,
                      stream, a);
   const int E = 9 * C * N;

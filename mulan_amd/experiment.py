@@ -205,10 +205,13 @@ class Experiment(abc.ABC):
         self._sample_dummy = None
         self._profile = None                 # profiling.Profile while config.training.profile is set (train_and_evaluate)
         # the lax.scan of the reference (ldm/experiment.py:89-91: `substeps` train steps per host dispatch) becomes a
-        # HIP-graph replay per step (GraphedStep).  Default: on for one rank; off with several ranks, where the eager
-        # step overlaps the bucketed gradient all-reduce with the backward pass (a replayed graph ends before the
-        # collectives, which would then run exposed behind it) and the host keeps up at the per-GPU batch sizes of the
-        # shipped configurations.  MULAN_HIP_GRAPH=1 / 0 or config.training.hip_graph=True / False override.
+        # HIP-graph replay per step (GraphedStep).  Default: on for one rank.  With several ranks the eager step overlaps
+        # the bucketed gradient all-reduce with the backward pass (a replayed graph ends before the collectives, which
+        # then run exposed behind it: ~2-3 ms for 285 MB over xGMI), so it stays eager WHERE THE HOST KEEPS UP: issuing
+        # the ~1100 launches of a step takes the host ~54 ms whatever the batch (measured, 32-block U-Nets), the GPU
+        # ~0.6 ms per image at E = 128 -- 128 images per GPU: 77.8 ms eager = replayed; 64 per GPU (BASELINE config #3
+        # on 8 GPUs): 54.3 ms eager against 43.5 replayed.  Hence: replay when local_batch * (E / 128)^2 < 96.
+        # MULAN_HIP_GRAPH=1 / 0 or config.training.hip_graph=True / False override.
         env = os.environ.get("MULAN_HIP_GRAPH", "")
         want = config.training.get("hip_graph", None)
         # asked for explicitly (config or environment): a failed capture is an error; chosen by default: a warning and
@@ -217,7 +220,9 @@ class Experiment(abc.ABC):
         if env in ("0", "1"):
             want = env == "1" and want is not False
         elif want is None:
-            want = self.world == 1
+            local = int(config.training.batch_size_train) // max(1, self.world)
+            width = float(config.model.get("sm_n_embd", 128)) / 128.0
+            want = self.world == 1 or local * width * width < 96
         self.hip_graph = bool(want) and torch.device(self.device).type == "cuda"
         self._graphed = None
         self._eager_steps = 0
