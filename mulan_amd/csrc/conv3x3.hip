@@ -604,6 +604,232 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, float* __rest
   out[e] = accumulate ? out[e] + s : s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Thin ends of the U-Nets: conv_out (E -> 3 for the score network, E -> 1 for the encoder, ldm/model_vdm.py:378-383,
+// model_mulan_epsilon.py:146-149), its input gradient (3 / 1 -> E) and its weight gradient.  On the MFMA kernels above
+// these pad the thin dimension to a 32-wide tile (113 / 52 / 184 us per launch at B = 128 for 0.9 GFLOP each); they are
+// reads / writes of one [B, 1024, E] tensor, so here they run on the vector ALUs in exact fp32 (v_fma_f32), lanes over
+// the channel quads of a pixel, a 3 x 3 window of float4s sliding along the image row: one pass over the tensor.
+constexpr int THIN_ROWS = 8;      // image rows per 256-thread block (two per wave)
+
+// y[b, p, n] = sum_{tap, c} x[b, p + tap, c] w[tap, c, n] + bias[n] + res[b, p, n]   for NT = N <= 4, C = 128 or 256
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_thin_n_fwd_kernel(ConvArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = p.C, G = C >> 2;                     // lanes per pixel (32 or 64)
+  const int ppw = 64 / G;                            // pixels a wave works on at a time (2 or 1)
+  const int c4 = lane % G, slot = lane / G;
+  const int rows_per_img = p.H / THIN_ROWS;
+  const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x % rows_per_img) * THIN_ROWS;
+  float wr[9][4][NT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wr[t][j][n] = p.w[((size_t)t * C + c4 * 4 + j) * NT + n];
+  const int cols = kW / ppw;                         // consecutive columns per slot
+  for (int r = wave; r < THIN_ROWS; r += 4) {
+    const int h = h0 + r;
+    const float* rowp[3];
+    bool rok[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + kh - 1;
+      rok[kh] = hh >= 0 && hh < p.H;
+      rowp[kh] = p.x + ((size_t)(b * p.H + (rok[kh] ? hh : h)) * kW) * C + c4 * 4;
+    }
+    const int col0 = slot * cols;
+    f32x4 win[3][3];                                 // [kh][kw]: columns col - 1, col, col + 1
+    auto ld = [&](int kh, int col) {
+      return (rok[kh] && col >= 0 && col < kW) ? *reinterpret_cast<const f32x4*>(rowp[kh] + (size_t)col * C)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) { win[kh][1] = ld(kh, col0 - 1); win[kh][2] = ld(kh, col0); }
+    for (int i = 0; i < cols; ++i) {
+      const int col = col0 + i;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) { win[kh][0] = win[kh][1]; win[kh][1] = win[kh][2]; win[kh][2] = ld(kh, col + 1); }
+      float acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_fmaf(win[kh][kw][j], wr[kh * 3 + kw][j][n], acc[n]);
+      for (int o = 1; o < G; o <<= 1)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] += __shfl_xor(acc[n], o, 64);
+      if (c4 == 0) {
+        const size_t px = (size_t)(b * p.H + h) * kW + col;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          float v = acc[n];
+          if (p.bias) v += p.bias[n];
+          if (p.res) v += p.res[px * NT + n];
+          p.y[px * NT + n] = v;
+        }
+      }
+    }
+  }
+}
+
+// y[b, p, n] = sum_{tap, c} x[b, p + tap, c] w[tap, c, n] + bias[n] + res[b, p, n]   for CT = C <= 4, N = 128 or 256:
+// the input gradient of conv_out (x = dy, w = the flipped kernel)
+template <int CT>
+__global__ __launch_bounds__(256) void conv3x3_thin_c_fwd_kernel(ConvArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = p.N, G = N >> 2;
+  const int ppw = 64 / G;
+  const int n4 = lane % G, slot = lane / G;
+  const int rows_per_img = p.H / THIN_ROWS;
+  const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x % rows_per_img) * THIN_ROWS;
+  f32x4 wr[9][CT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) wr[t][c] = *reinterpret_cast<const f32x4*>(p.w + ((size_t)t * CT + c) * N + n4 * 4);
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n4 * 4);
+  const int cols = kW / ppw;
+  for (int r = wave; r < THIN_ROWS; r += 4) {
+    const int h = h0 + r;
+    const float* rowp[3];
+    bool rok[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + kh - 1;
+      rok[kh] = hh >= 0 && hh < p.H;
+      rowp[kh] = p.x + ((size_t)(b * p.H + (rok[kh] ? hh : h)) * kW) * CT;
+    }
+    const int col0 = slot * cols;
+    float win[3][3][CT];
+    auto ld = [&](int kh, int col, float (&dst)[CT]) {
+      const bool ok = rok[kh] && col >= 0 && col < kW;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) dst[c] = ok ? rowp[kh][(size_t)col * CT + c] : 0.f;
+    };
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) { ld(kh, col0 - 1, win[kh][1]); ld(kh, col0, win[kh][2]); }
+    for (int i = 0; i < cols; ++i) {
+      const int col = col0 + i;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { win[kh][0][c] = win[kh][1][c]; win[kh][1][c] = win[kh][2][c]; }
+        ld(kh, col + 1, win[kh][2]);
+      }
+      f32x4 acc = bias4;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            const f32x4 w4 = wr[kh * 3 + kw][c];
+            const float xv = win[kh][kw][c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(xv, w4[e], acc[e]);
+          }
+      const size_t o = ((size_t)(b * p.H + h) * kW + col) * N + n4 * 4;
+      if (p.res) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(p.res + o);
+        acc[0] += rv[0]; acc[1] += rv[1]; acc[2] += rv[2]; acc[3] += rv[3];
+      }
+      *reinterpret_cast<f32x4*>(p.y + o) = acc;
+    }
+  }
+}
+
+// slab[block][tap][c][n] = sum over the block's rows of x[b, p + tap, c] dy[b, p, n]   for NT = N <= 4, C = 128 or 256
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_thin_n_wgrad_kernel(WgradArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float tsm[];          // [9][C][NT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = p.C, G = C >> 2;
+  const int ppw = 64 / G;
+  const int c4 = lane % G, slot = lane / G;
+  const int rows_per_img = p.H / THIN_ROWS;
+  const int b = blockIdx.x / rows_per_img, h0 = (blockIdx.x % rows_per_img) * THIN_ROWS;
+  float acc[9][4][NT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][j][n] = 0.f;
+  const int cols = kW / ppw;
+  for (int r = wave; r < THIN_ROWS; r += 4) {
+    const int h = h0 + r;
+    const float* rowp[3];
+    bool rok[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hh = h + kh - 1;
+      rok[kh] = hh >= 0 && hh < p.H;
+      rowp[kh] = p.x + ((size_t)(b * p.H + (rok[kh] ? hh : h)) * kW) * C + c4 * 4;
+    }
+    const float* dyrow = p.dy + ((size_t)(b * p.H + h) * kW) * NT;
+    const int col0 = slot * cols;
+    f32x4 win[3][3];
+    auto ld = [&](int kh, int col) {
+      return (rok[kh] && col >= 0 && col < kW) ? *reinterpret_cast<const f32x4*>(rowp[kh] + (size_t)col * C)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) { win[kh][1] = ld(kh, col0 - 1); win[kh][2] = ld(kh, col0); }
+    for (int i = 0; i < cols; ++i) {
+      const int col = col0 + i;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) { win[kh][0] = win[kh][1]; win[kh][1] = win[kh][2]; win[kh][2] = ld(kh, col + 1); }
+      float g[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) g[n] = dyrow[(size_t)col * NT + n];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[kh * 3 + kw][j][n] = __builtin_fmaf(win[kh][kw][j], g[n], acc[kh * 3 + kw][j][n]);
+    }
+  }
+  // the pixel slots of a wave, then the four waves in a fixed order through LDS
+  for (int o = G; o < 64; o <<= 1)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][j][n] += __shfl_xor(acc[t][j][n], o, 64);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && slot == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            float* d = tsm + ((size_t)t * C + c4 * 4 + j) * NT + n;
+            *d = w == 0 ? acc[t][j][n] : *d + acc[t][j][n];
+          }
+    }
+    __syncthreads();
+  }
+  const int E = 9 * C * NT;
+  float* slab = p.slab + (size_t)blockIdx.x * E;
+  for (int e = tid; e < E; e += 256) slab[e] = tsm[e];
+}
+
+bool thin_n_ok(int H, int C, int N) { return N >= 1 && N <= 4 && (C == 128 || C == 256) && H % THIN_ROWS == 0; }
+bool thin_c_ok(int H, int C, int N) { return C >= 1 && C <= 4 && (N == 128 || N == 256) && H % THIN_ROWS == 0; }
+
 int wgrad_splits(int B, int H, int C, int N) {
   const int tiles = ((C + WG_T - 1) / WG_T) * ((N + WG_T - 1) / WG_T);
   const int pairs = B * (H / WG_ROWS);
@@ -623,6 +849,27 @@ MULAN_API int mulan_conv3x3_fwd(const float* x, const float* w, const float* bia
                                 hipStream_t stream) {
   if (W != kW || H % TROWS != 0 || B <= 0 || C <= 0 || N <= 0) return (int)hipErrorInvalidValue;
   ConvArgs a{x, w, bias, cbias, res, y, B, H, C, N, cbias ? cbias_mode : 0, g_mulan_debug_buffer};
+  if (!cbias && g_mulan_tune[8] != 1) {   // thin ends (conv_out and its input gradient): vector-ALU kernels; tune[8] = 1: dev A/B
+    const dim3 tgrid(B * (H / THIN_ROWS));
+    if (thin_n_ok(H, C, N)) {
+      switch (N) {
+        case 1: hipLaunchKernelGGL(conv3x3_thin_n_fwd_kernel<1>, tgrid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(conv3x3_thin_n_fwd_kernel<2>, tgrid, dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(conv3x3_thin_n_fwd_kernel<3>, tgrid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(conv3x3_thin_n_fwd_kernel<4>, tgrid, dim3(256), 0, stream, a); break;
+      }
+      MULAN_CHECK_LAUNCH();
+    }
+    if (thin_c_ok(H, C, N) && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+      switch (C) {
+        case 1: hipLaunchKernelGGL(conv3x3_thin_c_fwd_kernel<1>, tgrid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(conv3x3_thin_c_fwd_kernel<2>, tgrid, dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(conv3x3_thin_c_fwd_kernel<3>, tgrid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(conv3x3_thin_c_fwd_kernel<4>, tgrid, dim3(256), 0, stream, a); break;
+      }
+      MULAN_CHECK_LAUNCH();
+    }
+  }
   const int mtiles = B * (H / TROWS);
   const auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   const bool vec = (C % 4 == 0) && (N % 4 == 0) && al(x) && al(w);
@@ -651,12 +898,26 @@ MULAN_API int mulan_conv3x3_wflip(const float* w, float* wT, int C, int N, hipSt
 
 MULAN_API size_t mulan_conv3x3_wgrad_workspace(int B, int H, int W, int C, int N) {
   if (W != kW || H % WG_ROWS != 0) return 0;
+  if (thin_n_ok(H, C, N) && g_mulan_tune[8] != 1) return (size_t)B * (H / THIN_ROWS) * 9 * C * N * sizeof(float);
   return (size_t)wgrad_splits(B, H, C, N) * 9 * C * N * sizeof(float);
 }
 
 MULAN_API int mulan_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* workspace, int B, int H, int W,
                                   int C, int N, int accumulate, hipStream_t stream) {
   if (W != kW || H % WG_ROWS != 0 || B <= 0) return (int)hipErrorInvalidValue;
+  if (thin_n_ok(H, C, N) && g_mulan_tune[8] != 1) {   // conv_out: vector-ALU kernel, one slab per block of 8 image rows
+    const int S = B * (H / THIN_ROWS), E = 9 * C * N;
+    WgradArgs a{x, dy, workspace, B, H, C, N, S};
+    const size_t lds = (size_t)E * sizeof(float);
+    switch (N) {
+      case 1: hipLaunchKernelGGL(conv3x3_thin_n_wgrad_kernel<1>, dim3(S), dim3(256), lds, stream, a); break;
+      case 2: hipLaunchKernelGGL(conv3x3_thin_n_wgrad_kernel<2>, dim3(S), dim3(256), lds, stream, a); break;
+      case 3: hipLaunchKernelGGL(conv3x3_thin_n_wgrad_kernel<3>, dim3(S), dim3(256), lds, stream, a); break;
+      default: hipLaunchKernelGGL(conv3x3_thin_n_wgrad_kernel<4>, dim3(S), dim3(256), lds, stream, a); break;
+    }
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
+    MULAN_CHECK_LAUNCH();
+  }
   const int S = wgrad_splits(B, H, C, N);
   WgradArgs a{x, dy, workspace, B, H, C, N, S};
   dim3 grid(S, (C + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T);

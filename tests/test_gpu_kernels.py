@@ -84,6 +84,40 @@ def test_conv3x3_grads_exact(ops, B, C, N):
     assert np.array_equal(dw.cpu().numpy().astype(np.float64), w.grad.numpy())
 
 
+@pytest.mark.parametrize("B,C,N", [(2, 128, 3), (1, 256, 1), (3, 128, 4), (1, 256, 2), (1, 3, 128), (2, 1, 256), (1, 4, 128)])
+def test_conv3x3_thin_ends_exact(ops, B, C, N):
+    """conv_out (E -> 3 / 1, ldm/model_vdm.py:378-383) and its gradients on the vector-ALU kernels (exact fp32 FMAs, one pass
+    over the wide tensor): integers exact with / without bias and residual, the same bits on random data as the MFMA
+    kernels' float64-checked results to fp32 rounding, and really the thin kernels (dev switch 8 = 1 selects the old ones)."""
+    rng = np.random.default_rng(11 * B + C + 7 * N)
+    x, w = ints(rng, (B, 32, 32, C)), ints(rng, (3, 3, C, N), -2, 3)
+    bias, res = ints(rng, (N,)), ints(rng, (B, 32, 32, N))
+    for bb, rr in ((bias, res), (None, None), (bias, None)):
+        ref = onp.conv3x3(x, w, bb) + (rr if rr is not None else 0)
+        y = ops.conv3x3_raw(dev(x).view(B, 1024, C), dev(w), dev(bb) if bb is not None else None, None,
+                            dev(rr).view(B, 1024, N) if rr is not None else None)
+        assert np.array_equal(y.cpu().numpy().reshape(ref.shape).astype(np.float64), ref)
+    xf = rng.standard_normal((B, 32, 32, C))
+    wf = rng.standard_normal((3, 3, C, N)) / math.sqrt(9 * C)
+    ref = onp.conv3x3(xf, wf)
+    y = ops.conv3x3_raw(dev(xf).view(B, 1024, C), dev(wf)).cpu().numpy().reshape(ref.shape)
+    assert rel_err(y, ref) < 2e-6
+    if N <= 4:       # the weight gradient of the thin-output layer
+        dy = ints(rng, (B, 32, 32, N), -2, 3)
+        xt, wt = torch.tensor(x, requires_grad=True), torch.tensor(w, requires_grad=True)
+        tr.conv3x3(xt, {"kernel": wt}).backward(torch.tensor(dy))
+        dw = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N))
+        assert np.array_equal(dw.cpu().numpy().astype(np.float64), wt.grad.numpy())
+        dx = ops.conv3x3_dgrad_raw(dev(dy).view(B, 1024, N), dev(w))
+        assert np.array_equal(dx.cpu().numpy().reshape(B, 32, 32, C).astype(np.float64), xt.grad.numpy())
+        ops.call("mulan_set_tuning", 8, 1)
+        try:
+            dw_old = ops.conv3x3_wgrad_raw(dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N))
+        finally:
+            ops.call("mulan_set_tuning", 8, 0)
+        assert torch.equal(dw_old, dw)
+
+
 def test_conv3x3_float_tolerance(ops):
     """random fp32 data: fp32 MFMA accumulation vs float64, rel 1e-5 of the output scale"""
     rng = np.random.default_rng(0)
