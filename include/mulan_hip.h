@@ -101,15 +101,20 @@ int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax,
  * bound of |y| ([B][16], maxima format) -- what mulan_groupnorm_fwd_planes computes, same summation order -- and
  * mulan_conv3x3_fwd_f16x3_gn_in normalises, activates and splits x1 (, x2: virtual channel concat, C2 == C1) while it
  * fills its patches: the result is bit for bit that of mulan_groupnorm_fwd_planes + ..._planes_in, the normalised tensor
- * never reaches HBM (yplanes_out, optional: store it as the weight-gradient operand after all).  C1 + C2 <= 512. */
+ * never reaches HBM (yplanes_out, optional: store it as the weight-gradient operand after all).  C1 + C2 <= 512.
+ * Statistics handed from convolution to convolution: ystats (optional output, [B][H / 8][N / 4][2]) receives this
+ * launch's partial sums of y and y^2 per image, 8-row tile and channel quad; given as xstats1 (, xstats2) to the next
+ * launch they replace the statistics pass -- every block forms mean / rstd / bound itself and mean, rstd, bound become
+ * outputs (same formulas, another summation order: agreement to fp32 rounding instead of bit for bit). */
 int mulan_groupnorm_stats(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
                           float* mean, float* rstd, unsigned* bound, int B, int hw, int G, float eps,
                           mulan_stream_t stream);
 int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, int C1, int C2, const float* gamma,
-                                  const float* beta, const float* mean, const float* rstd, int G, int act,
-                                  const unsigned* bound, const void* wp, const unsigned* wmax, const float* bias,
-                                  const float* cbias, int cbias_mode, const float* res, float* y, unsigned* ymax,
-                                  void* yplanes_out, int B, int H, int W, int N, mulan_stream_t stream);
+                                  const float* beta, float* mean, float* rstd, int G, int act, float eps,
+                                  unsigned* bound, const float* xstats1, const float* xstats2, const void* wp,
+                                  const unsigned* wmax, const float* bias, const float* cbias, int cbias_mode,
+                                  const float* res, float* y, unsigned* ymax, float* ystats, void* yplanes_out, int B,
+                                  int H, int W, int N, mulan_stream_t stream);
 
 size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,

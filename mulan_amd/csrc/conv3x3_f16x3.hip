@@ -1326,23 +1326,32 @@ MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsig
 
 // y = conv3x3(act(GroupNorm([x1 | x2]))) + bias + cbias + res with the normalisation done inside the convolution's patch
 // fill (ResnetBlock norm1 + swish -> conv1, norm2 + swish -> conv2 where no dropout is drawn: ldm/model_vdm.py:622-656 in
-// the evaluators and the sampler): x1 (, x2: equal widths) are the fp32 inputs of the GroupNorm, mean / rstd / bound what
-// mulan_groupnorm_stats left.  Same result, bit for bit, as mulan_groupnorm_fwd_planes + mulan_conv3x3_fwd_f16x3_planes_in;
-// the normalised tensor is not written unless yplanes_out (optional, mulan_conv3x3_planes_bytes(B, 32, 32, C1 + C2)
+// the evaluators and the sampler): x1 (, x2: equal widths) are the fp32 inputs of the GroupNorm.
+//  * xstats1 == NULL: mean / rstd / bound are what mulan_groupnorm_stats left; the result is, bit for bit, that of
+//    mulan_groupnorm_fwd_planes + mulan_conv3x3_fwd_f16x3_planes_in.
+//  * xstats1 (, xstats2) given: the partial sums the convolutions that PRODUCED x1 (, x2) left through their `ystats`
+//    ([B][H / 8][C1 / 4][2]: sum and sum of squares per image, 8-row tile and channel quad): every block forms mean / rstd
+//    and the bound itself -- no pass over x in front of the convolution at all -- and mean / rstd / bound are OUTPUTS (for
+//    a later backward pass).  Same formulas, another summation order: statistics agree to fp32 rounding.
+//  * ystats (optional, [B][H / 8][N / 4][2]): this launch's partial sums of y for the next GroupNorm.
+// The normalised tensor is not written unless yplanes_out (optional, mulan_conv3x3_planes_bytes(B, 32, 32, C1 + C2)
 // bytes) asks for it as the weight-gradient kernel's operand.
 MULAN_API int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, int C1, int C2, const float* gamma,
-                                            const float* beta, const float* mean, const float* rstd, int G, int act,
-                                            const unsigned* bound, const void* wp, const unsigned* wmax, const float* bias,
-                                            const float* cbias, int cbias_mode, const float* res, float* y, unsigned* ymax,
-                                            void* yplanes_out, int B, int H, int W, int N, hipStream_t stream) {
+                                            const float* beta, float* mean, float* rstd, int G, int act, float eps,
+                                            unsigned* bound, const float* xstats1, const float* xstats2, const void* wp,
+                                            const unsigned* wmax, const float* bias, const float* cbias, int cbias_mode,
+                                            const float* res, float* y, unsigned* ymax, float* ystats, void* yplanes_out,
+                                            int B, int H, int W, int N, hipStream_t stream) {
   const int C = C1 + (x2 ? C2 : 0);
   if (W != kW || B <= 0 || C <= 0 || N <= 0 || G <= 0 || !x1 || !gamma || !beta || !mean || !rstd || !bound || !wmax ||
       (x2 && C2 != C1) || C % G != 0 || (C / G) % 4 != 0 || C > 512 || !mulan_conv3x3_f16x3_v3_eligible(H, C, N) ||
-      (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts))
+      (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts) ||
+      (xstats1 && x2 && !xstats2) || (ystats && yplanes_out))
     return (int)hipErrorInvalidValue;
   ConvArgsH a{x1, bound, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
               cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(yplanes_out), ymax, nullptr,
-              x2, mean, rstd, gamma, beta, act, G};
+              x2, mean, rstd, gamma, beta, act, G,
+              ystats, xstats1, xstats2, xstats1 ? mean : nullptr, xstats1 ? rstd : nullptr, xstats1 ? bound : nullptr, eps};
   return mulan_launch_conv3x3_f16x3_v3(a, stream);
 }
 

@@ -38,7 +38,8 @@ constexpr int SMEM3_B = 3 * P3_BUF + 512;           // 65792: two blocks per CU 
 constexpr int PV3 = 6;                              // float4 patch slots per thread and chunk (1360 of 1536 used)
 constexpr int GN_ENT = 48;                          // GroupNorm-fed fill: table entry (scale x 4, beta x 4, mean) per channel quad
 constexpr int GN_MAXC = 512;
-constexpr int SMEM3_GN_B = SMEM3_B + GN_MAXC / 4 * GN_ENT;   // 71936
+constexpr int GN_SLOT = SMEM3_B + GN_MAXC / 4 * GN_ENT;      // 16 floats behind the table: [0] bound, [4..11] block reduction
+constexpr int SMEM3_GN_B = GN_SLOT + 64;                      // 72000
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -151,11 +152,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   };
   float gn_bound = 0.f;
   if constexpr (GNF != 0) {
-    gn_bound = __uint_as_float(row_max16(p.xmax, b));
     const int cpg = C / p.gn_groups;
+    float* gslot = reinterpret_cast<float*>(smem + GN_SLOT);
+    if (p.xstats) {
+      // the bound of gn_fwd_kernel's planes mode, formed here: (sqrt(n) max|gamma| + max|beta|) / keep with keep = 1
+      float gm = 0.f, bm = 0.f;
+      for (int cc = tid; cc < C; cc += 256) { gm = fmaxf(gm, fabsf(p.gn_gamma[cc])); bm = fmaxf(bm, fabsf(p.gn_beta[cc])); }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { gm = fmaxf(gm, __shfl_xor(gm, o, 64)); bm = fmaxf(bm, __shfl_xor(bm, o, 64)); }
+      if (lane == 0) { gslot[4 + wave] = gm; gslot[8 + wave] = bm; }
+      __syncthreads();
+      gm = fmaxf(fmaxf(gslot[4], gslot[5]), fmaxf(gslot[6], gslot[7]));
+      bm = fmaxf(fmaxf(gslot[8], gslot[9]), fmaxf(gslot[10], gslot[11]));
+      gn_bound = sqrtf((float)(p.H * kW * cpg)) * gm + bm;
+      if (tid == 0) gslot[0] = gn_bound;
+      scale_of(__float_as_uint(gn_bound), sx, inv_x);
+      if (p.xmax_out && blockIdx.y == 0 && h0 == 0 && tid < kMaxParts) p.xmax_out[b * kMaxParts + tid] = tid ? 0u : __float_as_uint(gn_bound);
+    } else {
+      gn_bound = __uint_as_float(row_max16(p.xmax, b));
+    }
+    const int qpg = cpg >> 2, nq1 = ldx >> 2, ntile = p.H / TR3;
+    const float inv_n = 1.f / (float)(p.H * kW * cpg);
     for (int e = tid; e < C / 4; e += 256) {
       const int c = e * 4, g = c / cpg;
-      const float mean = p.gn_mean[b * p.gn_groups + g], rstd = p.gn_rstd[b * p.gn_groups + g];
+      float mean, rstd;
+      if (p.xstats) {      // sums of the group's channel quads over the row tiles, in a fixed order
+        float s1 = 0.f, s2 = 0.f;
+        for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) {
+          const float* src = qq < nq1 ? p.xstats + ((size_t)b * ntile * nq1 + qq) * 2
+                                      : p.xstats2 + ((size_t)b * ntile * nq1 + (qq - nq1)) * 2;
+          for (int t = 0; t < ntile; ++t) { s1 += src[(size_t)t * nq1 * 2]; s2 += src[(size_t)t * nq1 * 2 + 1]; }
+        }
+        mean = s1 * inv_n;
+        rstd = rsqrtf(fmaxf(0.f, s2 * inv_n - mean * mean) + p.gn_eps);
+        if (p.gn_mean_out && blockIdx.y == 0 && h0 == 0 && (e % qpg) == 0) {
+          p.gn_mean_out[b * p.gn_groups + g] = mean;
+          p.gn_rstd_out[b * p.gn_groups + g] = rstd;
+        }
+      } else {
+        mean = p.gn_mean[b * p.gn_groups + g];
+        rstd = p.gn_rstd[b * p.gn_groups + g];
+      }
       const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gn_gamma + c);
       float* te = reinterpret_cast<float*>(smem + SMEM3_B + e * GN_ENT);
       *reinterpret_cast<f32x4*>(te) = f32x4{ga[0] * rstd, ga[1] * rstd, ga[2] * rstd, ga[3] * rstd};
@@ -373,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   if (tl && tl_blk < 32) p.stamps[tl_blk] = __builtin_amdgcn_s_memtime() - cyc0;   // core cycles spent in the main loop
 
   // ---- epilogue: straight from the accumulator layout (lane: pixel l15 of the tile, couts 4 grp .. 4 grp + 3)
-  scale_of(row_max16(p.xmax, b), sx, inv_x);         // (re-derived here: nothing of it lives across the main loop)
+  if (GNF != 0 && p.xstats) scale_of(__float_as_uint(*reinterpret_cast<const float*>(smem + GN_SLOT)), sx, inv_x);
+  else scale_of(row_max16(p.xmax, b), sx, inv_x);    // (re-derived here: nothing of it lives across the main loop)
   scale_of(row_max16(p.wmax, 0), sw, inv_w);
   const float* __restrict__ res = p.res;
   const float* __restrict__ cbp = p.cbias;
@@ -390,6 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
   }
   unsigned omax = 0;
+  float ys1[2] = {0.f, 0.f}, ys2[2] = {0.f, 0.f};    // (GNF = 1, ystats) sums of y and y^2 over this lane's pixels, per cout tile
   // one straight-line body per (residual, per-pixel FiLM bias) combination: the loads of all tiles can be in flight together
   auto finish = [&](auto has_res, auto has_cb2) {
 #pragma unroll
@@ -420,6 +459,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
           o[e] = (acc[pt][ct][e] * inv_x) * inv_w + add[ct][e];
           omax = max(omax, __float_as_uint(o[e]) & 0x7fffffffu);
         }
+        if constexpr (GNF == 1) {
+          ys1[ct] += (o[0] + o[1]) + (o[2] + o[3]);
+          ys2[ct] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+        }
         *reinterpret_cast<f32x4*>(yout + pixbase + ct * 16) = o;
       }
     }
@@ -428,6 +471,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   using F = std::false_type;
   if (res) { if (p.cbias_mode == 2) finish(T{}, T{}); else finish(T{}, F{}); }
   else { if (p.cbias_mode == 2) finish(F{}, T{}); else finish(F{}, F{}); }
+  if constexpr (GNF == 1) {
+    if (p.ystats) {   // this lane's 4 couts of a tile are one channel quad: sum over the 16 pixel lanes, one writer per quad
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { ys1[ct] += __shfl_xor(ys1[ct], o, 64); ys2[ct] += __shfl_xor(ys2[ct], o, 64); }
+        if (l15 == 0) {
+          const int quad = (nb + ct * 16) >> 2;
+          float* d = p.ystats + (((size_t)b * tiles_per_img + h0 / TR3) * (N >> 2) + quad) * 2;
+          d[0] = ys1[ct]; d[1] = ys2[ct];
+        }
+      }
+    }
+  }
   if (p.ymax) {   // this block is partial maximum number (row tile, cout block) of image b; unused entries zeroed
     const int part = (h0 / TR3) * gridDim.y + blockIdx.y, nparts = tiles_per_img * gridDim.y;
 #pragma unroll

@@ -58,6 +58,13 @@ struct ConvArgsH {
   // normalises with gn_mean / gn_rstd [B, gn_groups] and gn_gamma / gn_beta [C]; xmax is the bound mulan_groupnorm_stats left
   const float* x2; const float* gn_mean; const float* gn_rstd; const float* gn_gamma; const float* gn_beta;
   int gn_act, gn_groups;
+  // statistics handed from convolution to convolution (forward-only chains): ystats (optional output) receives this
+  // launch's partial sums of y and y^2 per (image, 8-row tile, channel quad): [B][H / 8][N / 4][2]; xstats / xstats2
+  // (optional inputs, same layout for x / x2) replace gn_mean / gn_rstd as the source of the statistics -- the block
+  // forms mean / rstd (and the bound) itself, and block (row tile 0, cout block 0) writes them to gn_mean_out /
+  // gn_rstd_out / xmax_out for a later backward pass
+  float* ystats; const float* xstats; const float* xstats2; float* gn_mean_out; float* gn_rstd_out; unsigned* xmax_out;
+  float gn_eps;
 };
 
 // sigmoid on the hardware exp2 and reciprocal: the expression of groupnorm.hip's sigmoid_fast, bit for bit

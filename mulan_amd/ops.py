@@ -171,9 +171,10 @@ class TeeFn(torch.autograd.Function):
     def forward(ctx, x):
         a, b = x.view_as(x), x.view_as(x)
         for v in (a, b):
-            c = getattr(x, "_absmax", None)
-            if c is not None and c[1] == x._version:
-                v._absmax = (c[0], v._version)
+            for tag in ("_absmax", "_gnstats"):     # what the producer left on x stays valid for the aliases
+                c = getattr(x, tag, None)
+                if c is not None and c[1] == x._version:
+                    setattr(v, tag, (c[0], v._version))
         return a, b
 
     @staticmethod
@@ -1148,7 +1149,7 @@ KEEP_BITS = _os.environ.get("MULAN_KEEP_BITS", "1") == "1"
 # GroupNorm normalised inside the convolution's patch fill (mulan_groupnorm_stats + mulan_conv3x3_fwd_f16x3_gn_in) where no
 # dropout is drawn.  GN_FILL: wherever the convolution's weight needs no gradient (evaluators, sampler, the ODE
 # evaluator's input-only differentiation) and the convolution has one 128-wide block of output channels: the normalised
-# tensor never reaches HBM (sampler step -6.3 %, ODE function evaluation -3.5 % at E = 128).  With N = 256 every input
+# tensor never reaches HBM (with the statistics hand-over below: sampler step -15 %, ODE function evaluation -7.5 % at E = 128).  With N = 256 every input
 # element is normalised by two blocks and the fill's arithmetic costs more than the GroupNorm pass it saves (dense
 # evaluation at E = 256: +4.5 %), so those layers keep the plane hand-over; GN_FILL_MAX_N is that limit.
 # GN_FILL_TRAIN (A/B switch, off: the train step is 1.2 % slower with it): also in training, the convolution
@@ -1156,6 +1157,18 @@ KEEP_BITS = _os.environ.get("MULAN_KEEP_BITS", "1") == "1"
 GN_FILL = _os.environ.get("MULAN_GN_FILL", "1") == "1"
 GN_FILL_MAX_N = int(_os.environ.get("MULAN_GN_FILL_MAX_N", "128"))
 GN_FILL_TRAIN = _os.environ.get("MULAN_GN_FILL_TRAIN", "0") == "1"
+# ... and the statistics handed from convolution to convolution: a GroupNorm-fed convolution leaves the partial sums of
+# its output (per image, 8-row tile, channel quad) on the tensor, the next one forms mean / rstd from them in its prologue:
+# no pass over the tensor between two convolutions of a forward-only chain.  A/B switch: 0 = mulan_groupnorm_stats in
+# front of every convolution (bit-identical to the plane hand-over; with the hand-over the statistics agree to rounding).
+GN_FILL_STATS = _os.environ.get("MULAN_GN_FILL_STATS", "1") == "1"
+
+
+def _gn_stats_of(x, C):
+    c = getattr(x, "_gnstats", None) if x is not None else None
+    if c is not None and c[1] == x._version and c[0].shape == (x.shape[0], H // 8, C // 4, 2):
+        return c[0]
+    return None
 
 
 def gn_conv_ok(C1, C2, N, groups):
@@ -1227,9 +1240,13 @@ class GnConv3x3Fn(torch.autograd.Function):
         B, C1 = x1.shape[0], x1.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
         Ct, N, dev = C1 + C2, w.shape[-1], x1.device
-        call("mulan_groupnorm_stats", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(bound), B,
-             HW, groups, float(eps), stream())
         want_planes = bool(ctx.needs_input_grad[4])
+        st1 = _gn_stats_of(x1, C1) if GN_FILL_STATS and not want_planes else None
+        st2 = _gn_stats_of(x2, C2) if (st1 is not None and x2 is not None) else None
+        if st1 is None or (x2 is not None and st2 is None):
+            st1 = st2 = None
+            call("mulan_groupnorm_stats", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(bound), B,
+                 HW, groups, float(eps), stream())
         ys = torch.empty(B * HW * Ct * 4 if want_planes else 0, device=dev, dtype=torch.uint8)
         ctx.keepbits = None
         wp, wmax = _pack_weights(w, Ct, N, 0)
@@ -1237,10 +1254,15 @@ class GnConv3x3Fn(torch.autograd.Function):
         ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
         mode = 0 if cbias is None else (1 if cbias.dim() == 2 else 2)
         bias_c, cb_c, res_c = _c(bias), _c(cbias), _c(res)
+        ystats = (torch.empty((B, H // 8, N // 4, 2), device=dev, dtype=torch.float32)
+                  if GN_FILL_STATS and not want_planes else None)
         _timed("conv3x3_f16x3_kernel<gn_in>", 2.0 * B * HW * 9 * Ct * N,
                lambda: call("mulan_conv3x3_fwd_f16x3_gn_in", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean),
-                            ptr(rstd), groups, int(act), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c), ptr(cb_c), mode,
-                            ptr(res_c), ptr(y), ptr(ymax), ptr(ys) if want_planes else None, B, H, W, N, stream()))
+                            ptr(rstd), groups, int(act), float(eps), ptr(bound), ptr(st1), ptr(st2), ptr(wp), ptr(wmax),
+                            ptr(bias_c), ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), ptr(ystats),
+                            ptr(ys) if want_planes else None, B, H, W, N, stream()))
+        if ystats is not None:
+            y._gnstats = (ystats, y._version)
         return GnConv3x3Fn._finish_forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, mean, rstd, ys, bound, wmax, y, ymax,
                                            (groups, int(act), 1.0, 0, 0), skip, mode)
 

@@ -804,6 +804,7 @@ def test_gn_normalised_inside_the_convolution_is_bit_identical(ops, monkeypatch,
     def run(fill, train):
         monkeypatch.setattr(ops, "GN_FILL", fill)
         monkeypatch.setattr(ops, "GN_FILL_MAX_N", 512)           # (the product path keeps N = 256 on the plane hand-over: speed only)
+        monkeypatch.setattr(ops, "GN_FILL_STATS", False)         # (statistics from mulan_groupnorm_stats: the bit-identical form)
         monkeypatch.setattr(ops, "GN_FILL_TRAIN", fill and train)
         for t in leaves:
             t.grad = None
@@ -825,6 +826,49 @@ def test_gn_normalised_inside_the_convolution_is_bit_identical(ops, monkeypatch,
             assert torch.equal(a_, r_), (train, i, float((a_.float() - r_.float()).abs().max()))
 
 
+@pytest.mark.parametrize("B,E", [(3, 128), (130, 128), (2, 256)])
+def test_gn_statistics_handed_from_convolution_to_convolution(ops, monkeypatch, B, E):
+    """A forward-only chain conv -> GroupNorm -> conv -> ... (ResnetBlocks under the evaluators / the sampler): each
+    GroupNorm-fed convolution leaves the partial sums of its output, the next one forms mean / rstd / bound from them in
+    its prologue -- one mulan_groupnorm_stats launch for the chain's first tensor, none after it, concat inputs included.
+    Same formulas in another summation order: every tensor of the chain, the saved statistics and the input gradient a
+    likelihood evaluator takes through it agree with the statistics-kernel route to fp32 rounding."""
+    torch.manual_seed(B + E)
+    x0 = (torch.randn(B, 1024, E, device="cuda") * 2 + 0.3).requires_grad_(True)
+    skip = torch.randn(B, 1024, E, device="cuda")
+    mk = lambda *s_, sc=1.0: torch.randn(*s_, device="cuda") * sc
+    layers = [(mk(E), mk(E, sc=0.3), mk(3, 3, E, E, sc=0.03), mk(E), mk(B, E)) for _ in range(3)]
+    g2, b2, w2 = mk(2 * E), mk(2 * E, sc=0.3), mk(3, 3, 2 * E, E, sc=0.02)
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+    monkeypatch.setattr(ops, "GN_FILL_MAX_N", 512)
+
+    def run(hand_over):
+        monkeypatch.setattr(ops, "GN_FILL_STATS", hand_over)
+        names.clear()
+        x0.grad = None
+        outs = []
+        h = x0
+        for i, (g, b_, w, bias, cb) in enumerate(layers):
+            h = ops.gn_conv3x3(h, None, g, b_, w, bias, cbias=cb if i % 2 == 0 else None, res=h if i % 2 else None)
+            outs.append(h)
+        a, b2_ = ops.tee(h)                                        # block output with two consumers
+        sk, _ = ops.tee(outs[0])
+        h = ops.gn_conv3x3(a, sk, g2, b2, w2)                      # up block: GroupNorm over the concat [h | skip]
+        outs.append(h)
+        h2 = ops.gn_conv3x3(b2_, skip, g2, b2, w2)                 # a skip tensor nobody left statistics on: falls back
+        outs.append(h2)
+        (h * 0.5 + h2).sum().backward()
+        return [o.detach().clone() for o in outs] + [x0.grad.clone()], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert ref_names.count("mulan_groupnorm_stats") == 5 and got_names.count("mulan_groupnorm_stats") == 2
+    for i, (a_, r_) in enumerate(zip(got, ref)):
+        assert float((a_ - r_).abs().max()) <= 3e-6 * float(r_.abs().max()), (i, float((a_ - r_).abs().max()), float(r_.abs().max()))
+
+
 def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkeypatch):
     """MuLAN forward under no_grad (evaluators / sampler): the ResnetBlock GroupNorms are normalised inside their
     convolutions (no mulan_groupnorm_fwd_planes launch is left for the dropout-free eval pass, no plane tensor written);
@@ -843,8 +887,9 @@ def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkey
     real = ops.call
     monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
 
-    def run(fill):
+    def run(fill, hand_over=False):
         monkeypatch.setattr(ops, "GN_FILL", fill)
+        monkeypatch.setattr(ops, "GN_FILL_STATS", hand_over)
         names.clear()
         with torch.no_grad():
             out = vdm.apply(params, x, None, None, step=0, rngs={"sample": PRNGKey(5)}, deterministic=True)
@@ -852,6 +897,11 @@ def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkey
 
     ref, ref_names = run(False)
     got, got_names = run(True)
+    # the shipped form: statistics handed from convolution to convolution (fewer launches still; losses to fp32 rounding)
+    got2, got2_names = run(True, True)
+    assert got2_names.count("mulan_groupnorm_stats") < got_names.count("mulan_groupnorm_stats") // 2
+    for a_, r_ in zip(got2, ref):
+        assert float((a_ - r_).abs().max()) <= 2e-6 * float(r_.abs().max())
     assert "mulan_conv3x3_fwd_f16x3_gn_in" not in ref_names and ref_names.count("mulan_groupnorm_fwd_planes") > 0
     assert got_names.count("mulan_conv3x3_fwd_f16x3_gn_in") == ref_names.count("mulan_groupnorm_fwd_planes")
     assert "mulan_groupnorm_fwd_planes" not in got_names
