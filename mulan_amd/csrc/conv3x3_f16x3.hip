@@ -1140,6 +1140,13 @@ __global__ void slab_reduce_h_kernel(const float* __restrict__ slab, float* __re
   if (e >= E) return;
   float s = 0.f;
   int i = 0;
+  for (; i + 20 <= S; i += 20) {         // (S = 40 / 80 in the train step: 20 loads in flight, summed in index order)
+    float v[20];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) v[u] = slab[(size_t)(i + u) * E + e];
+#pragma unroll
+    for (int u = 0; u < 20; ++u) s += v[u];
+  }
   for (; i + 8 <= S; i += 8) {
     float v[8];
 #pragma unroll

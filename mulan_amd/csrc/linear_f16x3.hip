@@ -60,13 +60,19 @@ struct LinArgs {
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 constexpr int kBufWord3 = 0x00020000;          // raw buffer resource; out-of-range lanes are dropped
 
-__global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
-  constexpr int MT = 2, NT = 2;
+// NT = 2: a block is 128 rows x 128 columns (wave: 64 x 64).  NT = 4: 128 rows x 256 columns (wave: 64 x 128) for layers
+// with at least 256 output columns -- the rows are read, split and staged once for 256 columns instead of twice (E = 256:
+// the kernel is bound by that work, not by HBM; E = 128: the two-output input gradient of nin_shortcut reads dy once).
+// The weight fragments of k step t + 1 are fetched while step t is multiplied (a ring of two: 64 registers at NT = 4).
+template <int NT>
+__global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
+  constexpr int MT = 2;
+  constexpr int TNB = NT * 64;                   // columns per block
   __shared__ __attribute__((aligned(16))) unsigned char smem[LIN_SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int r0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  const int r0 = blockIdx.x * TM, n0 = blockIdx.y * TNB;
   const int K = p.K1 + p.K2, N = p.N1 + p.N2;
   const int nst = K / SK;
   const int b = r0 / p.rows_per_img;
@@ -120,41 +126,36 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
     }
   };
   // weight fragments of a stage: [k step j][n tile][plane]
-  const unsigned char* bbase = p.wp + (size_t)b * p.wp_img_stride + (size_t)(n0 + wn * 64 + li) * 64 + lh * 16;
+  const unsigned char* bbase = p.wp + (size_t)b * p.wp_img_stride + (size_t)(n0 + wn * (NT * 32) + li) * 64 + lh * 16;
   const size_t chunk_stride = (size_t)N * 64;
-  auto gload_b = [&](f16x8 (&bs)[2][NT][2], int s) {
+  // weight fragments of k step t (16 input channels): [n tile][plane]
+  auto gload_b = [&](f16x8 (&bs)[NT][2], int t) {
+    const unsigned char* q = bbase + (size_t)t * chunk_stride;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned char* t = bbase + (size_t)(2 * s + j) * chunk_stride;
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) bs[j][nt][pl] = *reinterpret_cast<const f16x8*>(t + nt * 2048 + pl * 32);
-    }
+      for (int pl = 0; pl < 2; ++pl) bs[nt][pl] = *reinterpret_cast<const f16x8*>(q + nt * 2048 + pl * 32);
   };
 
-  f16x8 bcur[2][NT][2], bnxt[2][NT][2];
+  f16x8 bring[2][NT][2];
   gload_a(0);
-  gload_b(bcur, 0);
+  gload_b(bring[0], 0);
   for (int s = 0; s < nst; ++s) {
     unsigned char* buf = smem + (s & 1) * STAGE_B;
     store_a(buf, s);
     __syncthreads();
     const bool more = s + 1 < nst;
-    if (more) {
-      gload_a(s + 1);
-      gload_b(bnxt, s + 1);
-    }
-    f16x8 af[2][MT][2];
+    if (more) gload_a(s + 1);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      const int t = 2 * s + j;
+      if (j == 0 || more) gload_b(bring[(j + 1) & 1], t + 1);    // the fragments of the next k step, while this one runs
+      f16x8 af[MT][2];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
-          af[j][mt][pl] = *reinterpret_cast<const f16x8*>(buf + (wm * 64 + mt * 32 + li) * ROWB + pl * 64 + j * 32 + lh * 16);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
+          af[mt][pl] = *reinterpret_cast<const f16x8*>(buf + (wm * 64 + mt * 32 + li) * ROWB + pl * 64 + j * 32 + lh * 16);
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
         constexpr int PA[3] = {1, 0, 0};
@@ -163,37 +164,33 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j][mt][PA[term]], bcur[j][nt][PB[term]], acc[mt][nt], 0,
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt][PA[term]], bring[j][nt][PB[term]], acc[mt][nt], 0,
                                                                  0, 0);
       }
-    if (more) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) bcur[j][nt][pl] = bnxt[j][nt][pl];
     }
   }
 
   // epilogue: transposed through LDS so every lane moves float4s; scales divided out here
   const float* __restrict__ res = p.res;
-  float* out; int ldo, col0;
-  if (n0 < p.N1) { out = p.y1; ldo = p.N1; col0 = n0; } else { out = p.y2; ldo = p.N2; col0 = n0 - p.N1; }
-  float* __restrict__ yout = out;
   constexpr int TS = 64 + 4;
   float* stage = reinterpret_cast<float*>(smem) + wave * 32 * TS;
   const int c4 = lane & 15, prl = lane >> 4;
-  const int nb = wn * 64 + c4 * 4;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + nb);
   __syncthreads();
+#pragma unroll
+  for (int nh = 0; nh < NT / 2; ++nh) {            // 64 columns of the wave's tile at a time (N1 % 128 == 0: one output each)
+  const int ncol = n0 + wn * (NT * 32) + nh * 64;  // first column of this half in [y1 | y2]
+  float* out; int ldo, col0;
+  if (ncol < p.N1) { out = p.y1; ldo = p.N1; col0 = ncol; } else { out = p.y2; ldo = p.N2; col0 = ncol - p.N1; }
+  float* __restrict__ yout = out;
+  const int nb = c4 * 4;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + ncol + nb);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = (acc[mt][nt][r] * inv_x) * inv_w;
+      for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = (acc[mt][nh * 2 + nt][r] * inv_x) * inv_w;
     const size_t rowbase = (size_t)(r0 + wm * 64 + mt * 32) * ldo + col0 + nb;
     f32x4 add[8];
 #pragma unroll
@@ -215,6 +212,7 @@ __global__ __launch_bounds__(256) void linear_f16x3_kernel(LinArgs p) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+  }
   }
 }
 
@@ -274,7 +272,10 @@ static int linear_f16x3_launch(const float* x1, const unsigned* x1max, const flo
   if (xs && (size_t)M * (K1 + K2) * 4 >= 0x80000000ull) return (int)hipErrorInvalidValue;
   LinArgs a{x1, K2 > 0 ? x2 : nullptr, x1max, x2max, static_cast<const unsigned char*>(wp), wmax, bias, res, y1, y2,
             M, K1, K2, N1, N2, rows_per_img, static_cast<unsigned char*>(xs), wp_img_stride, wmax_per_img};
-  hipLaunchKernelGGL(linear_f16x3_kernel, dim3(M / TM, (N1 + N2) / TN), dim3(256), 0, stream, a);
+  if ((N1 + N2) % 256 == 0 && g_mulan_tune[11] != 1)       // tune[11] = 1: dev A/B, 128-column blocks everywhere
+    hipLaunchKernelGGL(linear_f16x3_kernel<4>, dim3(M / TM, (N1 + N2) / 256), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(linear_f16x3_kernel<2>, dim3(M / TM, (N1 + N2) / TN), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
 
