@@ -266,14 +266,16 @@ int mulan_groupnorm_bwd(const float* dy, const float* x1, const float* x2, int C
  * 32-channel slab sums them in a fixed order): dgamma / dbeta [C1+C2] receive the totals, dxsum (optional) the sum over
  * samples of dxsum_part's x1 columns [C1] = the bias gradient of the convolution whose output gradient dx1 is, dxsum2
  * (optional) a second copy of it (a shortcut layer's bias that sees the same gradient).  tickets: [16] unsigned, zero
- * before the first launch on a stream (each launch leaves them zero). */
+ * before the first launch on a stream (each launch leaves them zero).  add1b (optional, round 3): a second outside
+ * gradient of x1, dx1 = (dx1 + add1) + add1b -- the gradient a block output receives through its U-Net skip connection
+ * (autodiff of model_vdm.py:351-372), added here instead of by a kernel of its own. */
 int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const float* x2, int C1, int C2, const float* gamma,
                               const float* beta, const float* mean, const float* rstd, float* dx1, float* dx2,
                               float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
                               unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
                               unsigned* dx1max, unsigned* dx2max, const float* add1, const float* add2,
-                              float* dxsum_part, float* dgamma, float* dbeta, float* dxsum, float* dxsum2,
-                              unsigned* tickets, mulan_stream_t stream);
+                              const float* add1b, float* dxsum_part, float* dgamma, float* dbeta, float* dxsum,
+                              float* dxsum2, unsigned* tickets, mulan_stream_t stream);
 /* _fused_planes (round 3; autodiff of ldm/model_vdm.py:643-650, the gradient norm2 hands to conv1): single input, no
  * skip-path gradient; dx is written ONLY as the split fp16 operand planes of the f16x3 kernels of the convolution in
  * front ([B][C/16][1024][plane][16], mulan_conv3x3_planes_bytes bytes) -- its input-gradient convolution

@@ -244,6 +244,9 @@ struct GnBwdArgs {
   // optional (single-pass kernel): the keep-bits the forward kernel stored (GnArgs::maskbits) instead of re-drawing them
   // (10 Philox rounds per float4: ~45 % of this kernel's arithmetic in the dropout layers)
   const unsigned* maskbits;
+  // optional (single-pass kernel): a second gradient that reaches x1 from outside -- dx1 = (dx1 + add1) + add1b: the
+  // gradient a block output receives through its U-Net skip connection, added here instead of by a kernel of its own
+  const float* add1b;
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -355,6 +358,8 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
   dxp += (size_t)b * HW * ld + cs + quad * 4;
   const float* addp = c0 < p.C1 ? p.add1 : p.add2;
   if (addp) addp += (size_t)b * HW * ld + cs + quad * 4;
+  const float* addq = c0 < p.C1 ? p.add1b : nullptr;
+  if (addq) addq += (size_t)b * HW * ld + cs + quad * 4;
   const int c = c0 + quad * 4, g = c / cpg;
   const float mean = p.mean[b * p.G + g], rstd = p.rstd[b * p.G + g];
   const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
@@ -505,6 +510,10 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
     }
     if (addp) {
       const f32x4 ad = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(addp + (size_t)px * ld));
+      o[0] += ad[0]; o[1] += ad[1]; o[2] += ad[2]; o[3] += ad[3];
+    }
+    if (addq) {
+      const f32x4 ad = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(addq + (size_t)px * ld));
       o[0] += ad[0]; o[1] += ad[1]; o[2] += ad[2]; o[3] += ad[3];
     }
     *reinterpret_cast<f32x4*>(dp) = o;
@@ -724,13 +733,15 @@ MULAN_API int mulan_groupnorm_bwd_dyn(const float* dy, const float* x1, const fl
 // sum over samples of dxsum_part's x1 columns -- the bias gradient of the convolution whose output gradient dx1 is --
 // and dxsum2 (optional) a second copy of it (the bias of a shortcut layer that sees the same gradient).
 // tickets: [16] unsigned, zero before the first launch on a stream (every launch leaves them zero again).
+// add1b (optional, like x1): a second outside gradient of x1, dx1 = (dx1 + add1) + add1b (the skip-connection gradient of a
+// U-Net block output whose other consumer is this GroupNorm).
 MULAN_API int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const float* x2, int C1, int C2,
                                         const float* gamma, const float* beta, const float* mean, const float* rstd,
                                         float* dx1, float* dx2, float* dgamma_part, float* dbeta_part, int B, int hw,
                                         int G, int act, float keep, unsigned long long seed, unsigned long long offset,
                                         const unsigned long long* seed_dev, unsigned* dx1max, unsigned* dx2max,
-                                        const float* add1, const float* add2, float* dxsum_part, float* dgamma,
-                                        float* dbeta, float* dxsum, float* dxsum2, unsigned* tickets,
+                                        const float* add1, const float* add2, const float* add1b, float* dxsum_part,
+                                        float* dgamma, float* dbeta, float* dxsum, float* dxsum2, unsigned* tickets,
                                         hipStream_t stream) {
   const int Ct = C1 + C2;
   if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !tickets || !dgamma || !dbeta || !dgamma_part || !dbeta_part ||
@@ -740,7 +751,7 @@ MULAN_API int mulan_groupnorm_bwd_fused(const float* dy, const float* x1, const 
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
   GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
               B, G, act, keep, seed, offset, 0, dx1max, dx2max, add1, add2, dxsum_part, seed_dev, tickets, dgamma, dbeta,
-              dxsum, dxsum2, nullptr, nullptr};
+              dxsum, dxsum2, nullptr, nullptr, nullptr, add1b};
   hipLaunchKernelGGL(gn_bwd_kernel_1pass, dim3(B, Ct / 32), dim3(512), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -207,8 +207,8 @@ def _unet_stem(p, z, t, conditioning, E, n_layers, per_pixel, with_attention, dr
     if per_pixel:
         cond = cond.view(z.shape[0], HW, -1)
     h = ops.conv3x3(ops.fourier_features(z), p["conv_in"]["kernel"], p["conv_in"]["bias"])
-    # every level output feeds the next block and (in the U-Nets with an up path) a skip connection: ops.tee hands
-    # out one alias per consumer so that the two gradients are summed by mulan_add_absmax_rows
+    # every level output feeds the next block and (in the U-Nets with an up path) a skip connection: ops.tee /
+    # ops.tee_take arrange for the two gradients to be summed inside the next block's GroupNorm backward kernel
     h, skip = ops.tee(h) if with_skips else (h, h)
     hs = [skip]
     for i in range(n_layers):
@@ -231,7 +231,7 @@ def score_unet(p, cfg, z, g_t, conditioning, drop, time=False):
     t = g_t if (time and not per_pixel) else (g_t - cfg.gamma_min) / (cfg.gamma_max - cfg.gamma_min)
     h, hs, cond = _unet_stem(p, z, t, conditioning, E, L, per_pixel, cfg.with_attention, drop)
     for i in range(L + 1):
-        h = resnet_block(p[f"up.block_{i}"], h, hs.pop(), cond, drop)
+        h = resnet_block(p[f"up.block_{i}"], h, ops.tee_take(hs.pop()), cond, drop)
         if cfg.with_attention:
             h = attn_block(p[f"up.attn_{i}"], h)
     assert not hs

@@ -201,11 +201,63 @@ class TeeFn(torch.autograd.Function):
         return out
 
 
+# The gradient sum of a block output with two consumers inside the GroupNorm backward kernel of the first consumer
+# (mulan_groupnorm_bwd_fused, add1b) instead of in a kernel of its own (TeeFn): the skip-connection gradient, which the
+# backward pass produces first, waits in a box until that kernel runs.  A/B switch: 0 = TeeFn.
+TEE_MAILBOX = _os.environ.get("MULAN_TEE_MAILBOX", "1") == "1"
+
+
+class _GradBox:
+    """where the gradient that reaches a tensor through its second consumer waits for the first consumer's backward"""
+    __slots__ = ("grad", "claimed")
+
+    def __init__(self):
+        self.grad = None
+        self.claimed = False
+
+
+class MailFn(torch.autograd.Function):
+    """alias of x for its second consumer (tee_take): the gradient goes into the box instead of to x"""
+
+    @staticmethod
+    def forward(ctx, x, box):
+        ctx.box = box
+        y = x.view_as(x)
+        for tag in ("_absmax", "_gnstats"):
+            c = getattr(x, tag, None)
+            if c is not None and c[1] == x._version:
+                setattr(y, tag, (c[0], y._version))
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        if g is not None:
+            box = ctx.box
+            box.grad = _c(g) if box.grad is None else box.grad + g       # (a second arrival: not in the U-Nets)
+        return None, None
+
+
 def tee(x):
-    """two aliases of x for its two consumers; see TeeFn"""
+    """x for its two consumers (a block output that also feeds a U-Net skip connection): (a, b).  With TEE_MAILBOX both
+    are x itself, carrying a box: if the first consumer claims it (GnConv3x3Fn with skip=True: the next ResnetBlock),
+    tee_take(b) -- called where the second alias is consumed -- diverts b's gradient into the box and the first
+    consumer's GroupNorm backward adds it in-kernel.  Unclaimed (another kind of first consumer): autograd sums the two
+    gradients itself.  Without TEE_MAILBOX: two aliases whose gradients TeeFn.backward adds (mulan_add_absmax_rows)."""
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
+    if TEE_MAILBOX:
+        x._grad_box = _GradBox()
+        return x, x
     return TeeFn.apply(x)
+
+
+def tee_take(b):
+    """the second alias of tee(x), at the place where it is consumed (after the first consumer's forward)"""
+    box = getattr(b, "_grad_box", None)
+    if box is None or not box.claimed or not (torch.is_grad_enabled() and b.requires_grad):
+        return b
+    return MailFn.apply(b, box)
 
 
 class ParamPacker:
@@ -1017,7 +1069,7 @@ def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     return y, x1, x2
 
 
-def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False):
+def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False, add1b=None):
     """dx1, dx2 (+ the gradients add1 / add2 that reach x1 / x2 through a skip path), dgamma, dbeta.  The written dx1
     carries its maxima and per-sample channel sums for the convolution in front (whose dy it is).
     planes_out: the caller vouches that dx1 is consumed ONLY by the f16x3 kernels of the convolution that produced x1
@@ -1030,6 +1082,8 @@ def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False):
     C2 = 0 if x2 is None else x2.shape[-1]
     Ct = C1 + C2
     dymax_in = getattr(dy, "_absmax", None)
+    if add1b is not None and add1 is None:
+        add1, add1b = add1b, None
     if (planes_out and GN_FUSED_REDUCE and x2 is None and add1 is None and dymax_in is not None and
             dymax_in[1] == dy._version and C1 % 32 == 0 and C1 // 32 <= 16 and (C1 // groups) % 4 == 0 and
             32 % (C1 // groups) == 0 and B * HW * C1 * 4 < 2 ** 31):
@@ -1070,11 +1124,13 @@ def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False):
         sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
         call("mulan_groupnorm_bwd_fused", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
              ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(m1), ptr(m2),
-             ptr(_c(add1)), ptr(_c(add2)), ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2),
+             ptr(_c(add1)), ptr(_c(add2)), ptr(_c(add1b)), ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2),
              ptr(_gn_tickets(dy.device)), stream())
         if sink is not None:
             dx1._biasdone = (sink, sink2, dx1._version)
     else:
+        if add1b is not None:
+            add1 = add1 + add1b
         call("mulan_groupnorm_bwd_dyn", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
              ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), 0, ptr(m1), ptr(m2),
              ptr(_c(add1)), ptr(_c(add2)), ptr(csum), stream())
@@ -1195,6 +1251,13 @@ class GnConv3x3Fn(torch.autograd.Function):
         # ResnetBlock); if x1's producer accepts it (tag below), d x1 then travels as split planes only
         acc = getattr(x1, "_accepts_grad_planes", None)
         ctx.x1_grad_planes = bool(x1_grad_planes and not skip and x2 is None and acc is not None and acc == x1._version)
+        # x1 is a block output that also feeds a skip connection (tee): this op's GroupNorm backward will add the gradient
+        # that arrives through that connection (it is there first: the up path runs first in the backward pass)
+        box = getattr(x1, "_grad_box", None)
+        ctx.grad_box = None
+        if box is not None and skip and not box.claimed and ctx.needs_input_grad[0]:
+            box.claimed = True
+            ctx.grad_box = box
         x1, x2, w = _c(x1), _c(x2), _c(w)
         B, C1 = x1.shape[0], x1.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
@@ -1301,11 +1364,17 @@ class GnConv3x3Fn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, dy, ds1=None, ds2=None):
         nones = (None,) * 8
+        box = getattr(ctx, "grad_box", None)
+        add1b = None
+        if box is not None:
+            add1b, box.grad = box.grad, None
         if dy is None:     # only the skip path was used downstream
+            if add1b is not None:
+                ds1 = add1b if ds1 is None else ds1 + add1b
             return (ds1, ds2) + (None,) * 6 + nones
         x1, x2, gamma, beta, mean, rstd, ys, w, bound = ctx.saved_tensors
         need = ctx.needs_input_grad
-        planes_out = ctx.x1_grad_planes and GRAD_PLANES and ds1 is None
+        planes_out = ctx.x1_grad_planes and GRAD_PLANES and ds1 is None and add1b is None
         # (planes = False when the kernel needs no gradient -- the ODE evaluator differentiates with respect to the input
         # only: input gradient without plane output, no weight-gradient launch)
         conv = _Ctx(saved_tensors=(ys, w), planes=bool(need[4]), xmax=bound, wmax=ctx.wmax, has=ctx.has, gv=ctx.gv_conv,
@@ -1313,7 +1382,7 @@ class GnConv3x3Fn(torch.autograd.Function):
         dh, dw, dbias, dcb, dres = _conv3x3_backward(conv, dy)
         gn = _Ctx(saved_tensors=(x1, x2, gamma, beta, mean, rstd), meta=ctx.meta, gv=ctx.gv_gn,
                   bias_sink=ctx.bias_sink, keepbits=ctx.keepbits)
-        dx1, dx2, dgamma, dbeta = _gn_backward(gn, dh, ds1, ds2, planes_out=planes_out)
+        dx1, dx2, dgamma, dbeta = _gn_backward(gn, dh, ds1, ds2, planes_out=planes_out, add1b=add1b)
         return (dx1, dx2, dgamma, dbeta, dw, dbias, dcb, dres) + nones
 
 

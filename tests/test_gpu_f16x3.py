@@ -339,6 +339,8 @@ def test_tee_backward_leaves_the_bias_gradient_of_the_producer(ops, monkeypatch,
     real = ops.call
     monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
 
+    monkeypatch.setattr(ops, "TEE_MAILBOX", False)      # (TeeFn: the form without a GroupNorm behind the tensor)
+
     def run(on):
         monkeypatch.setattr(ops, "TEE_COLSUM", on)
         for t in (x, w, bias, res):
@@ -368,6 +370,53 @@ def test_tee_backward_leaves_the_bias_gradient_of_the_producer(ops, monkeypatch,
     assert torch.equal(out, g1 + g2)
     assert torch.equal(m.max(1).values, ops.absmax_rows(out).max(1).values)
     assert float(((parts.double().sum(0) - want).abs() / scale).max()) < 2e-7
+
+
+def test_skip_connection_gradient_is_added_inside_the_groupnorm_backward(ops, monkeypatch):
+    """A U-Net block output feeds the next block and a skip connection (ldm/model_vdm.py:351-372).  ops.tee / tee_take:
+    the gradient that arrives through the skip connection waits in a box and the next block's GroupNorm backward kernel
+    adds it (mulan_groupnorm_bwd_fused, add1b) -- no kernel of its own for the sum, and the maxima / bias-gradient
+    by-products of that kernel serve the convolution in front.  Against TeeFn (mulan_add_absmax_rows): the same sum in the
+    same order, so every gradient of a MuLAN train-mode pass is identical, bias gradients (summed in another order) to
+    fp32 rounding."""
+    from mulan_amd import model as M
+    from mulan_amd.rng import PRNGKey
+    cfg = M.VDMConfig(vocab_size=256, sample_softmax=False, antithetic_time_sampling=True, with_fourier_features=True,
+                      with_attention=False, gamma_type='poly_fixedend', gamma_min=-13.3, gamma_max=5.0, sm_n_timesteps=0,
+                      sm_n_embd=128, sm_n_layer=3, sm_pdrop=0.1, forward_n_layer=1, latent_size=50, latent_k=15,
+                      encoder='unet', latent_type='topk', z_conditioning=True, reparam_type='true', unet_type='vdm',
+                      condition='input')
+    vdm = M.make_vdm("mulan_epsilon", cfg)
+    params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(2)))
+    for _, leaf in M.tree_leaves(params):
+        leaf.normal_(0.0, 0.05)          # (zero-initialised layers would hide their inputs' gradients)
+        leaf.requires_grad_(True)
+    x = torch.randint(0, 256, (4, 32, 32, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).cuda()
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    def run(mailbox):
+        monkeypatch.setattr(ops, "TEE_MAILBOX", mailbox)
+        for _, leaf in M.tree_leaves(params):
+            leaf.grad = None
+        names.clear()
+        out = vdm.apply(params, x, None, None, step=0, rngs={"sample": PRNGKey(5), "dropout": PRNGKey(6)}, deterministic=False)
+        (out.loss_recon.mean() + out.loss_klz.mean() + out.loss_diff.mean()).backward()
+        return {n: leaf.grad.clone() for n, leaf in M.tree_leaves(params)}, list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    n_tee = ref_names.count("mulan_add_absmax_rows_colsum") + ref_names.count("mulan_add_absmax_rows")
+    assert n_tee == cfg.sm_n_layer + 1                               # one per skip connection
+    assert not any(n.startswith("mulan_add_absmax_rows") for n in got_names)
+    assert got_names.count("mulan_colsum") <= ref_names.count("mulan_colsum")   # (fewer in a train step: flat-buffer bias sinks)
+    assert len(got_names) <= len(ref_names) - n_tee
+    for n in ref:
+        if n[-1] == "bias":
+            assert float((got[n] - ref[n]).abs().max()) <= 2e-6 * float(ref[n].abs().max()) + 1e-12, n
+        else:
+            assert torch.equal(got[n], ref[n]), (n, float((got[n] - ref[n]).abs().max()))
 
 
 def test_group_norm_skip_adds_the_skip_gradient_in_kernel(ops):
@@ -985,7 +1034,7 @@ def test_gn_backward_planes_bound_and_precision(ops):
             else:
                 ops.call("mulan_groupnorm_bwd_fused", ops.ptr(dy), ops.ptr(x), None, C, 0, ops.ptr(gamma), ops.ptr(beta),
                          ops.ptr(mean), ops.ptr(rstd), ops.ptr(dx), None, ops.ptr(parts[0]), ops.ptr(parts[1]), B, 1024, 32, 1,
-                         keep, 11, 64, None, ops.ptr(m), None, None, None, ops.ptr(csum), ops.ptr(dg), ops.ptr(db),
+                         keep, 11, 64, None, ops.ptr(m), None, None, None, None, ops.ptr(csum), ops.ptr(dg), ops.ptr(db),
                          ops.ptr(sink), None, ops.ptr(tick), ops.stream())
             return dx, dxp, m, csum, dg, db, sink
 

@@ -66,7 +66,7 @@ def run():
     for n, keep, a1 in ((6, 0.9, None), (5, 1.0, add)):
         for _ in range(n):
             call("mulan_groupnorm_bwd_fused", ptr(dy), ptr(x1), None, 128, 0, ptr(g), ptr(b_), ptr(mean), ptr(rstd), ptr(dx),
-                 None, ptr(parts[0]), ptr(parts[1]), B, 1024, 32, 1, keep, 123, 0, None, ptr(m1), None, ptr(a1), None,
+                 None, ptr(parts[0]), ptr(parts[1]), B, 1024, 32, 1, keep, 123, 0, None, ptr(m1), None, ptr(a1), None, None,
                  ptr(cs), ptr(dg), ptr(db), ptr(sink), None, ptr(tick), stream())
         torch.cuda.synchronize()
     print("done", float(dw[0, 0, 0, 0]), float(dx[0, 0, 0]))
