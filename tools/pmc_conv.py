@@ -33,7 +33,7 @@ SHAPES = [  # name, kernel (fp32 input / plane-fed), C, N, residual, launches (d
     ("pin_dgrad_128_128", "pin_plain", 128, 128, False, 7),
     ("pin_dgrad_128_256", "pin_plain", 128, 256, False, 3),
 ]
-SYMBOL = {"fp32": "conv3x3_f16x3_v3_kernel<0, false>", "pin": "conv3x3_f16x3_v3_kernel<0, true>"}
+SYMBOL = {"fp32": "conv3x3_f16x3_v3_kernel<0, false, 0>", "pin": "conv3x3_f16x3_v3_kernel<0, true, 0>"}
 KIND_SYMBOL = {"fp32": "fp32", "pin": "pin", "pin_plain": "pin"}
 B = 128
 
@@ -87,7 +87,7 @@ def parse(d):
             rows += [r for r in csv.DictReader(fh) if "conv3x3_f16x3_v3_kernel" in r["Kernel_Name"]]
     if not rows:
         raise SystemExit(f"no conv3x3_f16x3_v3_kernel rows under {d}")
-    out = {"kernel": "conv3x3_f16x3_v3_kernel (<0, false>: fp32 input, splits and stores planes; <0, true>: plane-fed)",
+    out = {"kernel": "conv3x3_f16x3_v3_kernel (<0, false, 0>: fp32 input, splits and stores planes; <0, true, 0>: plane-fed)",
            "batch": B,
            "corrections": "FETCH_SIZE x 1024 x 2 (gfx950 counts the 128-B requests of 16-B-per-lane loads as 64 B); "
                           "WRITE_SIZE x 1024 exact for 16-B-per-lane stores; one counter group per rocprofv3 pass; "
