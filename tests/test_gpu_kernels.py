@@ -118,6 +118,24 @@ def test_conv3x3_thin_ends_exact(ops, B, C, N):
         assert torch.equal(dw_old, dw)
 
 
+def test_conv3x3_thin_ends_at_the_bench_batch(ops):
+    """the same kernels at the bench batch (B = 128: 8 row blocks per image x 128 images, 64-bit offsets): forward, input
+    gradient and weight gradient against the padded MFMA kernels (dev switch 8) on random data, fp32 rounding apart"""
+    torch.manual_seed(4)
+    B, C, N = 128, 128, 3
+    x, w = torch.randn(B, 1024, C, device="cuda"), torch.randn(3, 3, C, N, device="cuda") * 0.05
+    bias, res, dy = torch.randn(N, device="cuda"), torch.randn(B, 1024, N, device="cuda"), torch.randn(B, 1024, N, device="cuda")
+    out = {}
+    for old in (0, 1):
+        ops.call("mulan_set_tuning", 8, old)
+        try:
+            out[old] = (ops.conv3x3_raw(x, w, bias, None, res), ops.conv3x3_dgrad_raw(dy, w), ops.conv3x3_wgrad_raw(x, dy))
+        finally:
+            ops.call("mulan_set_tuning", 8, 0)
+    for a_, r_ in zip(out[0], out[1]):
+        assert float((a_ - r_).abs().max()) <= 3e-6 * float(r_.abs().max())
+
+
 def test_conv3x3_float_tolerance(ops):
     """random fp32 data: fp32 MFMA accumulation vs float64, rel 1e-5 of the output scale"""
     rng = np.random.default_rng(0)
