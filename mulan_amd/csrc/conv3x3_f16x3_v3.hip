@@ -80,9 +80,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, grp = lane >> 4, sel = lane >> 5, khalf = grp & 1;
   const int tiles_per_img = p.H / TR3;
-  const int b = blockIdx.x / tiles_per_img;
-  const int h0 = (blockIdx.x % tiles_per_img) * TR3;
-  const int n0 = blockIdx.y * BN;
+  // Block -> (pixel tile, cout block).  With two or more cout blocks every one of them reads the same patch: dispatched
+  // gridDim.x blocks apart (the plain 2-D order) the second read misses the caches once the input outgrows them
+  // (B = 1000 copies in the dense evaluator: 1 GB of planes per launch).  Paired (ids 8 apart: the same XCD under the
+  // round-robin dispatch, a few hundred ns apart) the re-read hits that XCD's L2.  g_pair: set by the launcher.
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.pair_cols) { const int per = 8 * (int)gridDim.y; bx = (lin / per) * 8 + (lin & 7); by = (lin % per) >> 3; }
+  const int b = bx / tiles_per_img;
+  const int h0 = (bx % tiles_per_img) * TR3;
+  const int n0 = by * BN;
   const int C = p.C, N = p.N;
   const int nchunks = C / CK, npairs = nchunks / 2;
   const int ldx = (GNF && p.x2) ? C / 2 : C;          // channels per pixel of the tensor(s) behind x (, x2)
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   const __amdgpu_buffer_rsrc_t wp_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(p.wp), 0, 9 * C * N * 4, kBufWord3);
   const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      p.xs + (size_t)b * nchunks * 65536, 0, (p.xs && blockIdx.y == 0) ? nchunks * 65536 : 0, kBufWord3);
+      p.xs + (size_t)b * nchunks * 65536, 0, (p.xs && by == 0) ? nchunks * 65536 : 0, kBufWord3);
 
   // ---- patch slots: slot = tid + 256 s -> (pixel of the 10 x 34 halo patch, channel quad q = tid & 3).  The slot
   // geometry is recomputed where it is used (from a laundered tid, so that it is not hoisted into 18 live registers).
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
       gn_bound = sqrtf((float)(p.H * kW * cpg)) * gm + bm;
       if (tid == 0) gslot[0] = gn_bound;
       scale_of(__float_as_uint(gn_bound), sx, inv_x);
-      if (p.xmax_out && blockIdx.y == 0 && h0 == 0 && tid < kMaxParts) p.xmax_out[b * kMaxParts + tid] = tid ? 0u : __float_as_uint(gn_bound);
+      if (p.xmax_out && by == 0 && h0 == 0 && tid < kMaxParts) p.xmax_out[b * kMaxParts + tid] = tid ? 0u : __float_as_uint(gn_bound);
     } else {
       gn_bound = __uint_as_float(row_max16(p.xmax, b));
     }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         }
         mean = s1 * inv_n;
         rstd = rsqrtf(fmaxf(0.f, s2 * inv_n - mean * mean) + p.gn_eps);
-        if (p.gn_mean_out && blockIdx.y == 0 && h0 == 0 && (e % qpg) == 0) {
+        if (p.gn_mean_out && by == 0 && h0 == 0 && (e % qpg) == 0) {
           p.gn_mean_out[b * p.gn_groups + g] = mean;
           p.gn_rstd_out[b * p.gn_groups + g] = rstd;
         }
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
   }
   if (p.ymax) {   // this block is partial maximum number (row tile, cout block) of image b; unused entries zeroed
-    const int part = (h0 / TR3) * gridDim.y + blockIdx.y, nparts = tiles_per_img * gridDim.y;
+    const int part = (h0 / TR3) * gridDim.y + by, nparts = tiles_per_img * gridDim.y;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
     __syncthreads();
@@ -503,8 +510,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
 
 bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N) { return H % TR3 == 0 && C % 32 == 0 && N % BN == 0; }
 
-int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream) {
+int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a_in, hipStream_t stream) {
+  f16x3::ConvArgsH a = a_in;
   const dim3 grid(a.B * (a.H / TR3), a.N / BN);
+  a.pair_cols = (grid.y > 1 && grid.x % 8 == 0 && g_mulan_tune[13] != 1) ? 1 : 0;    // tune[13] = 1: dev A/B, plain 2-D order
   if (a.gn_mean) {   // GroupNorm-fed forward convolution: with (xs) / without the planes as a by-product
 #define MULAN_V3_GN_LAUNCH(GNF)                                                                                       \
   {                                                                                                                   \

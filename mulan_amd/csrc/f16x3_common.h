@@ -65,6 +65,7 @@ struct ConvArgsH {
   // gn_rstd_out / xmax_out for a later backward pass
   float* ystats; const float* xstats; const float* xstats2; float* gn_mean_out; float* gn_rstd_out; unsigned* xmax_out;
   float gn_eps;
+  int pair_cols;                // (set by the launcher) the cout blocks of a pixel tile run on one XCD, see the kernel
 };
 
 // sigmoid on the hardware exp2 and reciprocal: the expression of groupnorm.hip's sigmoid_fast, bit for bit
