@@ -223,25 +223,6 @@ def _unet_stem(p, z, t, conditioning, E, n_layers, per_pixel, with_attention, dr
     return h, hs, cond
 
 
-# Forward-only calls on a large batch (the dense evaluator: T = 1000 copies of an image) run the score network on
-# sub-batches of this many images: every sample is independent (per-image operand scales, per-sample GroupNorm), so the
-# result is the same bits, and a sub-batch's activations (131 MB per layer at E = 256) stay in the 256 MB Infinity Cache
-# between the kernel that writes them and the one that reads them.  0 = off.
-import os as _os
-EVAL_CHUNK = int(_os.environ.get("MULAN_EVAL_CHUNK", "0"))
-
-
-def score_unet_chunked(p, cfg, z, g_t, conditioning, drop):
-    B = z.shape[0]
-    if EVAL_CHUNK <= 0 or B < 2 * EVAL_CHUNK or drop.on or torch.is_grad_enabled():
-        return score_unet(p, cfg, z, g_t, conditioning, drop)
-    n = -(-B // EVAL_CHUNK)
-    step = -(-B // n)
-    outs = [score_unet(p, cfg, z[i:i + step], g_t[i:i + step], conditioning[i:i + step], _Drop(None, 0.0))
-            for i in range(0, B, step)]
-    return torch.cat(outs, 0)
-
-
 def score_unet(p, cfg, z, g_t, conditioning, drop, time=False):
     """ScoreUNet.__call__ (ldm/model_vdm.py:314-388) / ldm_unet.UNet.__call__ (ldm/ldm_unet.py:69-142).
     z [B,1024,3]; g_t [B] (vdm) or [B,1024,3] (ldm); conditioning [B,K]."""
@@ -411,7 +392,7 @@ class MulanVDM(_VDMBase):
         else:
             cond = conditioning.reshape(B, 1).to(torch.float32)
         g_in = gt.view(B, HW, 3) if cfg.unet_type == 'ldm' else gbar
-        net = score_unet_chunked(params["score_model"], cfg, zt.view(B, HW, 3), g_in, cond, _Drop(k_score, cfg.sm_pdrop))
+        net = score_unet(params["score_model"], cfg, zt.view(B, HW, 3), g_in, cond, _Drop(k_score, cfg.sm_pdrop))
         net = net.reshape(B, D)
         T = cfg.sm_n_timesteps
         if self.parameterization == "velocity":

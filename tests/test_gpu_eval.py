@@ -85,17 +85,6 @@ def test_dense_and_sparse_eval_match_oracle(tmp_path):
         b_one, _ = exp.loss_fn(exp.orig_params, tiled, 0, rng=PRNGKey(0), is_train=False, same_image=True)
     assert float(b_all) == float(b_one)
 
-    # ... and the score network on sub-batches (model.EVAL_CHUNK: the activations of a sub-batch stay in the Infinity
-    # Cache between kernels) is the same bits: every sample is independent
-    from mulan_amd import model as M
-    M.EVAL_CHUNK = 3
-    try:
-        with torch.no_grad():
-            b_chunked, _ = exp.loss_fn(exp.orig_params, tiled, 0, rng=PRNGKey(0), is_train=False, same_image=True)
-    finally:
-        M.EVAL_CHUNK = 0
-    assert float(b_chunked) == float(b_one)
-
     got_s = ev.eval_bpd_sparse_sampling(exp, config)              # two batches of two distinct images
     noise2 = _eval_noise(exp, 2)
     want_s = np.mean([_oracle_bpd(ref_params, ocfg, images[k:k + 2], noise2) for k in (0, 2)])
