@@ -918,7 +918,8 @@ def test_gn_statistics_handed_from_convolution_to_convolution(ops, monkeypatch, 
         assert float((a_ - r_).abs().max()) <= 3e-6 * float(r_.abs().max()), (i, float((a_ - r_).abs().max()), float(r_.abs().max()))
 
 
-def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkeypatch):
+@pytest.mark.parametrize("vdm_type,unet_type", [("mulan_velocity", "vdm"), ("mulan_epsilon", "ldm")])
+def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkeypatch, vdm_type, unet_type):
     """MuLAN forward under no_grad (evaluators / sampler): the ResnetBlock GroupNorms are normalised inside their
     convolutions (no mulan_groupnorm_fwd_planes launch is left for the dropout-free eval pass, no plane tensor written);
     the three losses are bit for bit those of the plane hand-over."""
@@ -927,10 +928,12 @@ def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkey
     cfg = M.VDMConfig(vocab_size=256, sample_softmax=False, antithetic_time_sampling=True, with_fourier_features=True,
                       with_attention=False, gamma_type='poly_fixedend', gamma_min=-13.3, gamma_max=5.0, sm_n_timesteps=0,
                       sm_n_embd=128, sm_n_layer=2, sm_pdrop=0.1, forward_n_layer=1, latent_size=50, latent_k=15,
-                      encoder='unet', latent_type='topk', z_conditioning=True, reparam_type='true', unet_type='vdm',
+                      encoder='unet', latent_type='topk', z_conditioning=True, reparam_type='true', unet_type=unet_type,
                       condition='input')
-    vdm = M.make_vdm("mulan_velocity", cfg)
+    vdm = M.make_vdm(vdm_type, cfg)
     params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(3)))
+    for _, leaf in M.tree_leaves(params):
+        leaf.normal_(0.0, 0.05)          # (zero-initialised layers would switch whole branches off)
     x = torch.randint(0, 256, (6, 32, 32, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
     names = []
     real = ops.call
