@@ -600,3 +600,41 @@ def test_bench_self_launches_for_several_gpus(monkeypatch):
     assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert "torch.cuda" not in sys.modules or not __import__("torch").cuda.is_initialized()
+
+
+def test_load_flax_reads_bytes_it_did_not_write():
+    """tests/golden/tiny_state.flax was assembled byte by byte from the msgpack specification by
+    tests/golden/make_flax_fixture.py (struct.pack only: neither `checkpoint.save_flax` nor the msgpack library wrote
+    it), the way flax 0.7.0 serialises the reference's TrainState (ldm/experiment.py:210-214, notebook_utils.py:31-37):
+    ext-1 ndarrays, an ext-3 numpy scalar, a chunked array, the gamma network under its attribute names, one wrapping
+    'params' level, optax.chain(masked(adamw), masked(adamw)) with masked-out leaves as empty maps."""
+    import msgpack
+    from mulan_amd import checkpoint as ck
+    from tests.golden import make_flax_fixture as fx
+    path = os.path.join(ROOT, "tests", "golden", "tiny_state.flax")
+    raw = open(path, "rb").read()
+    assert raw == fx.build_bytes() and len(raw) < 2048
+    # the hand-assembled headers are the ones msgpack itself emits: decode (extension payloads kept opaque) and
+    # re-encode with the library -> the same bytes
+    generic = msgpack.unpackb(raw, raw=False, strict_map_key=False)
+    assert msgpack.packb(generic, use_bin_type=True) == raw
+    assert isinstance(generic["step"], msgpack.ExtType) and generic["step"].code == 3
+    assert generic["ema_params"]["score_model"]["norm_out"]["scale"]["__msgpack_chunked_array__"] is True
+    assert generic["opt_state"]["0"]["inner_state"]["0"]["mu"]["gamma"]["l1"]["bias"] == {}        # masked-out leaf
+    assert generic["opt_state"]["1"]["inner_state"]["0"]["mu"]["gamma"]["l1"]["kernel"] == {}
+    got = ck.load_flax(path)
+    want = fx.expected_tree()
+    assert got["step"] == 223 and isinstance(got["step"], int)
+
+    def same(a, b, where=""):
+        assert isinstance(a, dict) == isinstance(b, dict), where
+        if isinstance(b, dict):
+            assert sorted(a) == sorted(b), (where, sorted(a), sorted(b))
+            for k in b:
+                same(a[k], b[k], where + "/" + k)
+        else:
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), where
+    for key in ("params", "ema_params"):
+        same(got[key], want[key], key)
+    same(got["opt_state"]["mu"], want["opt_state"]["mu"], "mu")
+    same(got["opt_state"]["nu"], want["opt_state"]["nu"], "nu")
