@@ -5,6 +5,7 @@ Each Function's forward and backward are launches of hand-written HIP kernels th
 Shapes: images are [B, 1024, C] (NHWC with H = W = 32 flattened), matrices row-major, all fp32.
 """
 import math
+import weakref
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -208,12 +209,41 @@ TEE_MAILBOX = _os.environ.get("MULAN_TEE_MAILBOX", "1") == "1"
 
 
 class _GradBox:
-    """where the gradient that reaches a tensor through its second consumer waits for the first consumer's backward"""
-    __slots__ = ("grad", "claimed")
+    """where the gradient that reaches a tensor through its second consumer waits for the first consumer's backward.
+    The hand-over is only right if, in every backward pass, the deposit (MailFn.backward) comes before the claiming
+    consumer's backward takes the box's content: `deposits` / `takes` count both, and a deposit that finds more takes
+    than deposits has missed its consumer -- an error, not a silently dropped gradient."""
+    __slots__ = ("grad", "claimed", "deposits", "takes", "__weakref__")
 
     def __init__(self):
         self.grad = None
         self.claimed = False
+        self.deposits = 0
+        self.takes = 0
+
+    def take(self):
+        """the claiming consumer's backward: the waiting gradient (or None), the box empty again"""
+        g, self.grad = self.grad, None
+        self.takes += 1
+        _PENDING_BOXES.discard(self)
+        return g
+
+
+_PENDING_BOXES = weakref.WeakSet()      # boxes that hold a gradient nobody has taken yet
+
+
+def _check_no_gradient_left_waiting():
+    """at the next forward pass: a box still holding a gradient means the last backward pass ended without the claiming
+    consumer's backward (it was not on the differentiated path): that gradient never reached the tensor"""
+    left = [b for b in _PENDING_BOXES if b.grad is not None]
+    if left:
+        _PENDING_BOXES.clear()
+        for b in left:
+            b.grad = None
+        raise RuntimeError(
+            f"{len(left)} skip-connection gradient(s) were left waiting in their tee() mailbox when the backward pass ended: "
+            "the consumer that claimed the box (GnConv3x3Fn with skip=True) was not part of that backward pass, so the "
+            "gradient of the tee()'d tensor is incomplete.  Differentiate through both consumers, or set MULAN_TEE_MAILBOX=0.")
 
 
 class MailFn(torch.autograd.Function):
@@ -234,7 +264,15 @@ class MailFn(torch.autograd.Function):
     def backward(ctx, g):
         if g is not None:
             box = ctx.box
+            if box.takes > box.deposits:
+                raise RuntimeError(
+                    "tee() mailbox: the skip-connection gradient arrived AFTER the backward of the consumer that adds it "
+                    "in-kernel (GnConv3x3Fn with skip=True) had run, so it would be dropped.  The mailbox needs the second "
+                    "consumer's gradient first (true for the shipped U-Nets: the up path is differentiated before the "
+                    "down path); set MULAN_TEE_MAILBOX=0 for graphs with another order.")
+            box.deposits += 1
             box.grad = _c(g) if box.grad is None else box.grad + g       # (a second arrival: not in the U-Nets)
+            _PENDING_BOXES.add(box)
         return None, None
 
 
@@ -247,6 +285,7 @@ def tee(x):
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
     if TEE_MAILBOX:
+        _check_no_gradient_left_waiting()
         x._grad_box = _GradBox()
         return x, x
     return TeeFn.apply(x)
@@ -604,6 +643,11 @@ def _conv3x3_backward(ctx, dy):
             dx = conv3x3_dgrad_planes_raw(dys, dymax, w, wmax=ctx.wmax, want_max=want_max)
             dw = wgrad_from_planes(dys, dymax) if ctx.needs_input_grad[1] else None
         else:
+            if dy.numel() > 1 and all(s == 0 for s in dy.stride()):
+                # the NaN stand-in of _planes_only_grad without (valid) planes: autograd handed on another tensor object than
+                # the GroupNorm backward returned (a tensor hook, retain_grad or an accumulation on conv1's output)
+                raise RuntimeError("planes-only gradient arrived without its planes: hooks / retain_grad / a second consumer "
+                                   "on the output of a ResnetBlock's conv1 are not supported with MULAN_GRAD_PLANES=1")
             dy = _c(dy)
             dymax = cached_absmax(dy) if (CONV_MODE == "f16x3" and N % 4 == 0) else None   # shared by dgrad and wgrad
         if gp is not None:
@@ -1367,7 +1411,7 @@ class GnConv3x3Fn(torch.autograd.Function):
         box = getattr(ctx, "grad_box", None)
         add1b = None
         if box is not None:
-            add1b, box.grad = box.grad, None
+            add1b = box.take()
         if dy is None:     # only the skip path was used downstream
             if add1b is not None:
                 ds1 = add1b if ds1 is None else ds1 + add1b

@@ -419,6 +419,55 @@ def test_skip_connection_gradient_is_added_inside_the_groupnorm_backward(ops, mo
             assert torch.equal(got[n], ref[n]), (n, float((got[n] - ref[n]).abs().max()))
 
 
+def test_tee_mailbox_fails_loudly_when_its_order_invariant_breaks(ops, monkeypatch):
+    """the tee() mailbox is only right if the skip-path gradient is deposited before the claiming consumer's
+    backward takes it.  (1) the shipped order gives the two-consumer gradient; (2) the claiming consumer's backward first,
+    the skip path second (torch.autograd.grad on sub-graphs): RuntimeError instead of a dropped gradient; (3) a backward
+    pass through the skip path only leaves the gradient waiting: the next forward pass's tee() reports it."""
+    monkeypatch.setattr(ops, "TEE_MAILBOX", True)
+    torch.manual_seed(21)
+    B, C = 2, 128
+    g = torch.randn(C, device="cuda") * 0.2 + 1.0
+    b = torch.randn(C, device="cuda") * 0.1
+    w = torch.randn(3, 3, C, C, device="cuda") * 0.03
+
+    def graph():
+        x = torch.randn(B, 1024, C, device="cuda", requires_grad=True)
+        h = x * 1.5                                             # a block output with two consumers
+        a, skip = ops.tee(h)
+        y1, s1, _ = ops.gn_conv3x3(a, None, g, b, w, act=True, skip=True)     # first consumer: claims the box
+        y2 = ops.tee_take(skip) * 0.25                          # second consumer (the U-Net's up path)
+        return x, h, y1, s1, y2
+
+    # (1) the shipped order: one backward pass, the sum of both consumers' gradients reaches x
+    x, h, y1, s1, y2 = graph()
+    (y1.sum() + s1.sum() * 0.5 + y2.sum()).backward()
+    got = x.grad.clone()
+    monkeypatch.setattr(ops, "TEE_MAILBOX", False)
+    # (the same graph without the mailbox, on the same x)
+    x2 = x.detach().clone().requires_grad_(True)
+    h2 = x2 * 1.5
+    a2, skip2 = ops.tee(h2)
+    z1, t1, _ = ops.gn_conv3x3(a2, None, g, b, w, act=True, skip=True)
+    z2 = ops.tee_take(skip2) * 0.25
+    (z1.sum() + t1.sum() * 0.5 + z2.sum()).backward()
+    assert float((got - x2.grad).abs().max()) <= 1e-5 * float(x2.grad.abs().max())
+    monkeypatch.setattr(ops, "TEE_MAILBOX", True)
+
+    # (2) wrong order: the claiming consumer's backward runs before the skip-path gradient exists
+    x, h, y1, s1, y2 = graph()
+    torch.autograd.grad(y1.sum(), x, retain_graph=True)
+    with pytest.raises(RuntimeError, match="mailbox"):
+        torch.autograd.grad(y2.sum(), x, allow_unused=True)
+
+    # (3) only the skip path is differentiated: its gradient waits in the box for a consumer that never runs
+    x, h, y1, s1, y2 = graph()
+    torch.autograd.grad(y2.sum(), x, allow_unused=True)
+    with pytest.raises(RuntimeError, match="left waiting"):
+        graph()
+    graph()                                                     # (reported once; the next forward pass is clean)
+
+
 def test_group_norm_skip_adds_the_skip_gradient_in_kernel(ops):
     """GroupNormSkipFn: gradients through the aliases s1 / s2 are added inside the backward kernel; the result, its
     maxima and its per-sample channel sums equal the two-step computation"""
