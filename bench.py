@@ -386,47 +386,154 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
     return res
 
 
-def dense_eval_workload(images, T):
-    """BASELINE configs[4] per GPU: eval_bpd --bpd_eval_method=dense on the ImageNet-32 configuration -- every test
-    image is a batch of T copies through loss_fn(is_train=False) under one key (ldm/notebook_utils.py:176-191)"""
+def _max_over_ranks(seconds, world, dev):
     import torch
+    import torch.distributed as dist
+    if world > 1:
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        seconds = float(t[0])
+    return seconds
+
+
+def dense_eval_workload(images, T, rank=0, world=1):
+    """BASELINE configs[4]: eval_bpd --bpd_eval_method=dense on the ImageNet-32 configuration, the test images sharded
+    over the ranks by index -- the evaluator itself (mulan_amd.evaluators.eval_bpd_dense_sampling = ldm/notebook_utils.py:
+    176-191: every test image a batch of T copies through loss_fn(is_train=False) under one key, image i on rank i % world,
+    one all-reduce of (sum bpd, count) at the end).  `images` per rank after one warm-up image per rank; barrier +
+    synchronize on both sides, MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+    from mulan_amd import evaluators
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
-    from mulan_amd.rng import PRNGKey
     config = load_config_file(os.path.join(ROOT, "ldm", "configs", "imagenet32.py"))
     config.data.dataset = "synthetic"
     config.vdm_type = "mulan_velocity"
     config.model.velocity_from_epsilon = True
-    config.training.batch_size_train = 8
-    config.training.batch_size_eval = 8
+    config.training.batch_size_train = 8 * world
+    config.training.batch_size_eval = 8 * world
     exp = Experiment_VDM(config)
-    rng = PRNGKey(0)
-    packer = exp.state.param_packer("ema")
-    times = []
-    with torch.no_grad():
-        if packer is not None:
-            packer.refresh()                 # the weights are constant over the evaluation: prepared once
-        for i in range(images + 1):          # (the first image is the warm-up)
-            img = torch.randint(0, 256, (1, 32, 32, 3), dtype=torch.uint8, device=exp.device)
-            tiled = {"images": img.expand(T, 32, 32, 3).contiguous(),
-                     "labels": torch.zeros(T, dtype=torch.int32, device=exp.device),
-                     "conditioning": torch.zeros(T, dtype=torch.uint8, device=exp.device)}
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            bpd, _ = exp.loss_fn(exp.state.ema_params, tiled, i, rng=rng, is_train=False, same_image=True)   # as the evaluator
-            bpd = float(bpd)
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
-        if packer is not None:
-            packer.invalidate()
-    dt = sum(times[1:]) / images
+    exp.orig_params = exp.state.ema_params               # what Experiment_Colab evaluates (notebook_utils.py:36)
+    quiet = open(os.devnull, "w")
+    saved = sys.stdout
+
+    def run(n_images):
+        sys.stdout = quiet                                # (the evaluator prints its running mean like the reference)
+        try:
+            return evaluators.eval_bpd_dense_sampling(exp, config, n_timesteps=T, max_images=n_images * world)
+        finally:
+            sys.stdout = saved
+    run(1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    bpd = run(images)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = _max_over_ranks(time.perf_counter() - t0, world, exp.device)
+    dt = elapsed / images                                 # seconds per test image on one GPU
     del exp
     torch.cuda.empty_cache()
-    return {"workload": f"eval_bpd dense VLB, ldm/configs/imagenet32.py (E=256, velocity_from_epsilon), T={T} copies "
-                        f"per image, {images} images after one warm-up image, forward only, EMA weights",
+    return {"workload": f"eval_bpd dense VLB (evaluators.eval_bpd_dense_sampling), ldm/configs/imagenet32.py (E=256, "
+                        f"velocity_from_epsilon), T={T} copies per image, {images} images per rank after one warm-up "
+                        f"image, test images sharded over {world} rank(s) by index, one (sum, count) all-reduce, forward "
+                        "only, EMA weights",
             "metric": "dense-eval seconds per test image", "value": round(dt, 4), "unit": "s/image",
-            "higher_is_better": False, "forward_images_per_s": round(T / dt, 1),
-            "model_tflops": round(T / dt * FWD_GFLOP_BY_WIDTH[256] / 1e3, 1), "bpd_random_init": round(bpd, 4)}
+            "higher_is_better": False, "test_images_per_s_all_ranks": round(images * world / elapsed, 3),
+            "forward_images_per_s": round(T * world / dt, 1),
+            "model_tflops_per_gpu": round(T / dt * FWD_GFLOP_BY_WIDTH[256] / 1e3, 1), "bpd_random_init": round(float(bpd), 4)}
+
+
+def sampler_workload(B, T, steps):
+    """Experiment_VDM.sample_fn's inner loop (ldm/experiment_vdm.py:80-110) at the flagship
+    configuration -- `steps` timed reverse steps of VDM.sample out of a T-step schedule, then generate_x"""
+    import torch
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    from mulan_amd.rng import PRNGKey
+    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    config.data.dataset = "synthetic"
+    config.training.batch_size_train = B
+    config.training.batch_size_eval = B
+    exp = Experiment_VDM(config)
+    st, model = exp.state, exp.model
+    cond = torch.zeros(B, dtype=torch.uint8, device=exp.device)
+    key = PRNGKey(0)
+    packer = st.param_packer("ema")
+    with torch.no_grad():
+        if packer is not None:
+            packer.refresh()
+        coeffs = model.sample_coefficients(st.ema_params, model.deterministic_embedding(B, exp.device))
+        z = float(config.model.sigma_prior) * key.normal((B, 3072), exp.device)
+        for i in range(3):
+            z = model.sample(st.ema_params, i, T, z, cond, key, coeffs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + steps):
+            z = model.sample(st.ema_params, i, T, z, cond, key, coeffs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        x = model.generate_x(st.ema_params, z, coeffs, rng=key.fold_in(T))
+        torch.cuda.synchronize()
+        if packer is not None:
+            packer.invalidate()
+    ok = tuple(x.shape) == (B, 32, 32, 3) and bool(torch.isfinite(z).all())
+    E = int(config.model.sm_n_embd)
+    del exp
+    torch.cuda.empty_cache()
+    gf = SCORE_FWD_GFLOP_BY_WIDTH[E]
+    return {"workload": f"ancestral sampler (Experiment_VDM.sample_fn loop: VDM.sample + generate_x), cifar10-conditioned "
+                        f"(E={E}), batch {B}, {steps} timed reverse steps of a T={T} schedule, EMA weights, 1 GPU",
+            "metric": "sampled images per second at T=1000", "value": round(B / (dt * T), 3), "unit": "images/s",
+            "ms_per_reverse_step": round(dt * 1e3, 3), "reverse_steps_per_s": round(1.0 / dt, 2),
+            "image_steps_per_s": round(B / dt, 1), "seconds_per_grid_of_B_images": round(dt * T, 2),
+            "model_tflops": round(B / dt * gf / 1e3, 1),
+            "model_roofline_frac": round(B / dt * gf / 1e3 / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "finite": ok}
+
+
+def ode_workload(B):
+    """one exact-likelihood solve as eval_bpd --bpd_eval_method=ode runs it (ldm/notebook_utils.py:
+    264-373) -- a batch of B test images, truncated-normal dequantisation, Rademacher Hutchinson probe per function
+    evaluation, adaptive Dormand-Prince at rtol = atol = 1e-5, one importance sample (n_is = 1)"""
+    import torch
+    from mulan_amd import evaluators
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    from mulan_amd.rng import PRNGKey
+    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    config.data.dataset = "synthetic"
+    config.training.batch_size_train = B
+    config.training.batch_size_eval = B
+    exp = Experiment_VDM(config)
+    exp.orig_params = exp.state.ema_params
+    like = evaluators.get_ode_likelihood_fn(exp, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5, dequantization="tn")
+    img = torch.randint(0, 256, (B, 32, 32, 3), dtype=torch.uint8, device=exp.device)
+    like(PRNGKey(1), img, t_grid=[0.0, 0.01])            # warm-up: one Dormand-Prince step (7 function evaluations)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    log_p, log_q, aux, info = like(PRNGKey(2), img)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    offset = evaluators._get_bpd_offset("tn", 1)
+    bpd = float((-(log_p) + aux.double()).mean() / (3072 * math.log(2.0)) + offset)
+    E = int(config.model.sm_n_embd)
+    del exp
+    torch.cuda.empty_cache()
+    per = dt / info["nfev"]
+    gf = 3 * SCORE_FWD_GFLOP_BY_WIDTH[E] * 2.0 / 3.0       # forward + input-gradient pass (no weight gradients)
+    return {"workload": f"exact-likelihood ODE evaluator (evaluators.get_ode_likelihood_fn), cifar10-conditioned (E={E}), "
+                        f"batch {B}, dequantization tn, Rademacher probes, adaptive RK45 rtol=atol=1e-5, n_is=1, EMA "
+                        "weights at their random initialisation, 1 GPU",
+            "metric": "ODE function evaluations per second (batch)", "value": round(1.0 / per, 2), "unit": "nfe/s",
+            "nfev": int(info["nfev"]), "rk45_steps": int(info["steps"]), "rk45_rejected": int(info["rejected"]),
+            "ms_per_function_evaluation": round(per * 1e3, 3), "image_evaluations_per_s": round(B / per, 1),
+            "seconds_per_image_this_solve": round(dt / B, 4),
+            "seconds_per_image_at_nfev_300_n_is_20": round(300 * 20 * per / B, 3),
+            "model_tflops": round(B / per * gf / 1e3, 1), "bpd_random_init": round(bpd, 4),
+            "finite": bool(torch.isfinite(log_p).all())}
 
 
 def main():

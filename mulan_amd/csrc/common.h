@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MULAN_CHECK_LAUNCH() return (int)hipGetLastError()
 
 // developer tuning knobs (mulan_set_tuning): [0] conv fwd variant, [1] wgrad resident-block target
-extern int g_mulan_tune[16];
+extern int g_mulan_tune[32];
 extern unsigned long long* g_mulan_debug_buffer;   // dev-only stamp buffer (>= 64 u64), normally null
 
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];

@@ -178,7 +178,7 @@ MULAN_API int mulan_randn(float* out, size_t n, unsigned long long seed, unsigne
   MULAN_CHECK_LAUNCH();
 }
 
-int g_mulan_tune[16] = {0};
+int g_mulan_tune[32] = {0};
 unsigned long long* g_mulan_debug_buffer = nullptr;
 
 MULAN_API int mulan_set_debug_buffer(void* dev_ptr) {
@@ -187,7 +187,7 @@ MULAN_API int mulan_set_debug_buffer(void* dev_ptr) {
 }
 
 MULAN_API int mulan_set_tuning(int key, int value) {
-  if (key < 0 || key >= 16) return (int)hipErrorInvalidValue;
+  if (key < 0 || key >= 32) return (int)hipErrorInvalidValue;
   g_mulan_tune[key] = value;
   return 0;
 }

@@ -6,6 +6,7 @@ dense : per test image, a batch of `n_timesteps` copies -> antithetic t covers [
         is sharded by index across ranks and (sum bpd, count) is all-reduced once at the end.
 sparse: batches of batch_size_eval distinct images, same fixed key (notebook_utils.py:157-173).
 """
+import contextlib
 import os
 
 import numpy as np
@@ -84,6 +85,23 @@ class Experiment_Colab(Experiment_VDM):
         return {k: float(np.mean([m[k] for m in eval_metrics])) for k in eval_metrics[0]}
 
 
+@contextlib.contextmanager
+def _packed_weights(experiment):
+    """The evaluated weights are constant over an evaluation: their maxima and split fp16 operands are prepared once
+    (ParamPacker, two launches) instead of per layer and call."""
+    st = experiment.state
+    params = getattr(experiment, "orig_params", None)
+    which = "ema" if params is st.ema_params else ("params" if params is st.params else None)
+    packer = st.param_packer(which) if which else None
+    if packer is not None:
+        packer.refresh()
+    try:
+        yield
+    finally:
+        if packer is not None:
+            packer.invalidate()
+
+
 def _reduce_mean(total, count, device):
     if parallel.world_size() > 1:
         t = torch.tensor([total, float(count)], dtype=torch.float64, device=device)
@@ -98,18 +116,20 @@ def _dense_partial(experiment, config, n_timesteps, rank, world, max_images=0):
     loader = dataset.create_one_time_eval_dataset(config, 1, experiment.device, rank, world)
     rng = PRNGKey(0)
     total, count = 0.0, 0
-    for eval_step, batch in enumerate(loader):
-        if max_images and eval_step * world + rank >= max_images:
-            break
-        images = batch['images'].reshape(1, 32, 32, 3).expand(n_timesteps, 32, 32, 3).contiguous()
-        tiled = {'images': images, 'labels': batch['labels'].expand(n_timesteps),
-                 'conditioning': torch.zeros(n_timesteps, dtype=torch.uint8, device=experiment.device)}
-        with torch.no_grad():
-            bpd, _ = experiment.loss_fn(experiment.orig_params, tiled, eval_step, rng=rng, is_train=False, same_image=True)
-        total += float(bpd)
-        count += 1
-        if count % 100 == 0 and rank == 0:
-            print(f'eval_step {count} cum_avg_bpd {total / count} ')
+    with _packed_weights(experiment):
+        for eval_step, batch in enumerate(loader):
+            if max_images and eval_step * world + rank >= max_images:
+                break
+            images = batch['images'].reshape(1, 32, 32, 3).expand(n_timesteps, 32, 32, 3).contiguous()
+            tiled = {'images': images, 'labels': batch['labels'].expand(n_timesteps),
+                     'conditioning': torch.zeros(n_timesteps, dtype=torch.uint8, device=experiment.device)}
+            with torch.no_grad():
+                bpd, _ = experiment.loss_fn(experiment.orig_params, tiled, eval_step, rng=rng, is_train=False,
+                                            same_image=True)
+            total += float(bpd)
+            count += 1
+            if count % 100 == 0 and rank == 0:
+                print(f'eval_step {count} cum_avg_bpd {total / count} ')
     return total, count
 
 
@@ -129,15 +149,16 @@ def _sparse_partial(experiment, config, rank, world, max_images=0):
     loader = dataset.create_one_time_eval_dataset(config, batch_size, experiment.device, rank, world)
     rng = PRNGKey(0)
     total, count = 0.0, 0
-    for eval_step, batch in enumerate(loader):
-        if max_images and (eval_step * world + rank) * batch_size >= max_images:
-            break
-        with torch.no_grad():
-            bpd, _ = experiment.loss_fn(experiment.orig_params, batch, eval_step, rng=rng, is_train=False)
-        total += float(bpd)
-        count += 1
-        if count % 100 == 0 and rank == 0:
-            print(f'eval_step {count} cum_avg_bpd {total / count} ')
+    with _packed_weights(experiment):
+        for eval_step, batch in enumerate(loader):
+            if max_images and (eval_step * world + rank) * batch_size >= max_images:
+                break
+            with torch.no_grad():
+                bpd, _ = experiment.loss_fn(experiment.orig_params, batch, eval_step, rng=rng, is_train=False)
+            total += float(bpd)
+            count += 1
+            if count % 100 == 0 and rank == 0:
+                print(f'eval_step {count} cum_avg_bpd {total / count} ')
     return total, count
 
 

@@ -643,7 +643,8 @@ def _conv3x3_backward(ctx, dy):
             dx = conv3x3_dgrad_planes_raw(dys, dymax, w, wmax=ctx.wmax, want_max=want_max)
             dw = wgrad_from_planes(dys, dymax) if ctx.needs_input_grad[1] else None
         else:
-            if dy.numel() > 1 and all(s == 0 for s in dy.stride()):
+            nan = _NAN.get(dy.device)
+            if nan is not None and dy.numel() > 1 and dy.data_ptr() == nan.data_ptr() and all(s == 0 for s in dy.stride()):
                 # the NaN stand-in of _planes_only_grad without (valid) planes: autograd handed on another tensor object than
                 # the GroupNorm backward returned (a tensor hook, retain_grad or an accumulation on conv1's output)
                 raise RuntimeError("planes-only gradient arrived without its planes: hooks / retain_grad / a second consumer "
