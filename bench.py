@@ -17,12 +17,15 @@ configs[1] -- MuLAN-epsilon, ldm/configs/cifar10-conditioned.py (E=128, 32+2+33 
 --vfe --global-batch 1024`.
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel: the 3x3-conv implicit GEMM) and
 `cpu_baseline` (oracle port on the host cores, bounded samples) objects.  At N = 1 the line also carries, under
-"configs", a short timing of the other BASELINE configurations at their per-GPU size (#3 MuLAN-velocity at 64 images,
-#4 ImageNet-32 velocity_from_epsilon at 128 images, #5 dense VLB evaluation with T = 1000), each with the convolution
-kernel's own roofline fraction (`--no-also-configs` skips them, `--also-configs` forces them at N > 1).
+"configs", at every N (`--no-also-configs` skips them), a short timing of the other BASELINE configurations -- #3
+MuLAN-velocity at GLOBAL batch 512 (strong scaling), #4 ImageNet-32 velocity_from_epsilon at 128 images per GPU (global
+1024 at N = 8), #5 the dense VLB evaluator (T = 1000) with the test images sharded over the ranks -- each training entry
+with the convolution kernel's own roofline fraction, and of the SURVEY 8(f) widenings "sampler" (ancestral sampler) and
+"ode" (exact-likelihood evaluator: function evaluations/s, adaptive RK45 at rtol = atol = 1e-5, n_is = 1).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -35,6 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # same guide: dense bf16 MFMA (~2.5 PF)
 FWD_GFLOP_PER_IMAGE = 57.78           # score 53.37 + encoder 4.33 + gamma 0.076 (CIFAR config)
 FWD_GFLOP_BY_WIDTH = {128: 57.78, 256: 228.58}   # CIFAR config / ImageNet-32 config
+SCORE_FWD_GFLOP_BY_WIDTH = {128: 53.37, 256: 212.32}   # the score U-Net alone (sampler / ODE: no encoder pass per step)
 
 
 def parse():
@@ -551,8 +555,15 @@ def main():
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     backend = dist.get_backend() if world > 1 else None
+    rccl_ranks = 0
     if world > 1:
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+        if backend == "nccl":
+            # every rank of the RCCL communicator answers one all-reduce: the count must be --gpus
+            one = torch.ones(1, device="cuda")
+            dist.all_reduce(one)
+            rccl_ranks = int(one.item())
+            assert rccl_ranks == a.gpus, f"RCCL communicator spans {rccl_ranks} ranks, --gpus {a.gpus}"
     strong = a.global_batch > 0
     if strong and a.global_batch % world != 0:
         raise SystemExit(f"--global-batch {a.global_batch} is not divisible by {world} ranks")
@@ -560,33 +571,51 @@ def main():
     head = train_workload(a, rank, world, a.config, a.vdm_type, a.vfe, B, a.steps, a.warmup, not a.no_f32_mode)
     elapsed, roof = head["elapsed"], head["roof"]
 
-    # ---- the other BASELINE configurations at their per-GPU size (driver-timed with the headline: "configs")
-    also = a.also_configs if a.also_configs is not None else world == 1
+    # ---- the other BASELINE configurations, driver-timed with the headline ("configs"), at every N:
+    #   "3": configs[2] as worded -- MuLAN-velocity CIFAR-10 at GLOBAL batch 512 (strong scaling: 512 / N images per GPU;
+    #        at N = 1 also "3_at_64_per_gpu", the per-GPU size of the 8-GPU configuration, as in rounds 1-3);
+    #   "4": configs[3] -- MuLAN-velocity ImageNet-32, velocity_from_epsilon, 128 images per GPU (global 128 N: the
+    #        configuration's global batch of 1024 at N = 8);
+    #   "5": configs[4] -- the dense evaluator itself, test images sharded over the ranks;
+    #   "sampler", "ode": SURVEY 8(f) ranks 3 and 2 (rank 0's GPU only).
+    also = a.also_configs if a.also_configs is not None else True
     extra = None
     if also:
         extra = {}
         cif = os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")
         inet = os.path.join(ROOT, "ldm", "configs", "imagenet32.py")
-        for key, (cfgp, vt, vfe, bsz, label) in {
-                "3": (cif, "mulan_velocity", False, 64, "BASELINE configs[2]: MuLAN-velocity CIFAR-10, global batch 512 "
-                                                        "over 8 GPUs = 64 images per GPU"),
-                "4": (inet, "mulan_velocity", True, 128, "BASELINE configs[3]: MuLAN-velocity ImageNet-32 (E=256), "
-                                                         "velocity_from_epsilon, global batch 1024 over 8 GPUs = 128 per GPU")}.items():
+        if 512 % world != 0:
+            b3, l3 = 64, "BASELINE configs[2]: MuLAN-velocity CIFAR-10 at its 8-GPU per-GPU size of 64 images"
+        else:
+            b3, l3 = 512 // world, (f"BASELINE configs[2]: MuLAN-velocity CIFAR-10, GLOBAL batch 512 (strong scaling: "
+                                    f"{512 // world} images per GPU)")
+        table = {"3": (cif, "mulan_velocity", False, b3, l3),
+                 "4": (inet, "mulan_velocity", True, 128, "BASELINE configs[3]: MuLAN-velocity ImageNet-32 (E=256), "
+                                                          f"velocity_from_epsilon, 128 per GPU = global batch {128 * world} "
+                                                          "(the configuration's 1024 at 8 GPUs)")}
+        if world == 1:
+            table["3_at_64_per_gpu"] = (cif, "mulan_velocity", False, 64, "BASELINE configs[2] at its 8-GPU per-GPU size: "
+                                        "MuLAN-velocity CIFAR-10, 64 images per GPU (512 / 8)")
+        for key, (cfgp, vt, vfe, bsz, label) in table.items():
             r = train_workload(a, rank, world, cfgp, vt, vfe, bsz, a.also_steps, 3, False)
             ips = bsz * world * a.also_steps / r["elapsed"]
             gf = FWD_GFLOP_BY_WIDTH[r["E"]]
             rr = r["roof"] or {}
             extra[key] = {"workload": label + f"; full train step, {world} GPU(s) x {bsz}", "value": round(ips, 2),
-                          "unit": "images/s", "ms_per_step": round(r["elapsed"] / a.also_steps * 1e3, 2),
+                          "unit": "images/s", "global_batch": bsz * world, "ms_per_step": round(r["elapsed"] / a.also_steps * 1e3, 2),
                           "steps": a.also_steps, "warmup": 3, "hip_graph": r["graph_used"],
                           "model_tflops_per_gpu": round(ips / world * 3 * gf / 1e3, 2),
                           "conv_kernel": {k: rr.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us",
                                                                  "launches_per_step", "measured")},
                           "conv_kernel_as_run_frac": (rr.get("as_run") or {}).get("frac"),
                           "last_train_bpd": round(r["last_bpd"], 4)}
-        if world == 1:
-            extra["5"] = dense_eval_workload(2, 1000)
-            extra["5"]["workload"] = "BASELINE configs[4]: " + extra["5"]["workload"]
+        extra["5"] = dense_eval_workload(2, 1000, rank, world)
+        extra["5"]["workload"] = "BASELINE configs[4]: " + extra["5"]["workload"]
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            extra["sampler"] = sampler_workload(64, 1000, 20)
+            extra["ode"] = ode_workload(64)
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -625,7 +654,7 @@ def main():
                                (f"global batch {B * world} fixed (strong scaling), {B}/GPU" if strong else
                                 f"batch {B}/GPU (weak scaling)"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
-        "collective": ({"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+        "collective": ({"backend": backend, "rccl_ranks": rccl_ranks,
                         "note": "torch.distributed backend 'nccl' is RCCL on ROCm; bucketed gradient all-reduce on a "
                                 "side stream, overlapped with the backward pass"} if world > 1 else None),
         "model_tflops_per_gpu": round(value / world * 3 * fwd_gflop / 1e3, 2),

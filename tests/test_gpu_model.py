@@ -1,6 +1,8 @@
 """End-to-end parity of the HIP model (through mulan_amd.model / the C ABI) with the float64 oracle:
 forward ELBO terms and every parameter gradient of one MuLAN step, with identical explicit noise and
 the oracle reproducing the kernel's Philox dropout masks."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -444,8 +446,8 @@ def test_gradient_sink_equals_autograd_accumulation():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("graph,launcher", [("", "self"), ("0", "torchrun")])
-def test_bench_two_ranks_share_one_gpu(graph, launcher):
+@pytest.mark.parametrize("graph,launcher,configs", [("", "self", True), ("0", "torchrun", False)])
+def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
     """bench.py's N > 1 control flow (sharded batches, bucketed side-stream all-reduce, barriers, max-over-ranks timing,
     rank-0 JSON) with two ranks on the one GPU of this box.  RCCL refuses two ranks per device, so the collective
     backend is gloo over the device tensors here; the calls are the same torch.distributed ones.  graph = "": the
@@ -453,7 +455,10 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher):
     it (the host could not keep up with an eager step); "0": MULAN_HIP_GRAPH=0, the eager step whose all-reduce overlaps
     the backward pass (the default from 96 images per rank at E = 128).  launcher = "self": plain `python bench.py --gpus 2` -- the bench starts
     torch.distributed.run itself as a child process and relays rank 0's line (the reference needs no launcher either,
-    ldm/experiment.py:89-95); "torchrun": the driver's command line."""
+    ldm/experiment.py:89-95); "torchrun": the driver's command line.  configs: the default at every N -- the line also
+    carries BASELINE configs[2] at GLOBAL batch 512 (strong scaling: 256 images per rank here), configs[3] at 128 per rank,
+    configs[4] through the sharded evaluator (eval_bpd_dense_sampling, one (sum, count) all-reduce) and the sampler / ODE
+    entries; False: --no-also-configs."""
     import json
     import os
     import socket
@@ -469,7 +474,8 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher):
         env.pop(k, None)
     if graph:
         env["MULAN_HIP_GRAPH"] = graph
-    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8"]
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8",
+            "--also-steps", "2"] + ([] if configs else ["--no-also-configs"])
     if launcher == "self":
         cmd = [sys.executable] + args
     else:
@@ -480,7 +486,15 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher):
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
-    assert out["roofline"] is not None and out["cpu_baseline"] is None and out["configs"] is None
+    assert out["roofline"] is not None and out["cpu_baseline"] is None
+    if configs:
+        c = out["configs"]
+        assert set(c) == {"3", "4", "5", "sampler", "ode"}
+        assert c["3"]["global_batch"] == 512 and c["4"]["global_batch"] == 256 and c["3"]["value"] > 0 and c["4"]["value"] > 0
+        assert "sharded over 2 rank(s)" in c["5"]["workload"] and c["5"]["value"] > 0 and math.isfinite(c["5"]["bpd_random_init"])
+        assert c["sampler"]["finite"] and c["sampler"]["value"] > 0 and c["ode"]["finite"] and c["ode"]["nfev"] >= 8
+    else:
+        assert out["configs"] is None
     assert out["hip_graph"] == (graph != "0")
     assert out["collective"]["backend"] == "gloo" and out["collective"]["rccl_ranks"] == 0    # (nccl on a multi-GPU node)
 
