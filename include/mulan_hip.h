@@ -37,6 +37,19 @@ int mulan_set_tuning(int key, int value);
 /* dev-only: device buffer (>= 64 x u64) that receives s_memtime stamps of block 0; NULL (default) disables */
 int mulan_set_debug_buffer(void* dev_ptr);
 
+/* ---- a point INSIDE a captured HIP graph that work OUTSIDE it can wait for ----------------------------------------
+ * The reference's pmap(scan(train_step)) overlaps lax.pmean of the gradients with the rest of the backward pass inside
+ * one compiled program (ldm/experiment.py:89-95,341).  Here the train step is a replayed HIP graph and the RCCL
+ * all-reduce of gradient bucket k is issued outside it (torch.distributed): it may start as soon as the captured backward
+ * pass has produced that bucket.  mulan_event_record_external on a capturing stream becomes an event-record NODE
+ * (hipEventRecordWithFlags, hipEventRecordExternal) instead of an internal fork / join edge; after hipGraphLaunch the
+ * collective's stream waits for it with mulan_stream_wait_event.  Outside a capture the pair is an ordinary
+ * record / wait.  (torch.cuda.Event(external=True) is refused on ROCm builds of torch 2.10, hence these four.) */
+int mulan_event_create(void** event);
+int mulan_event_destroy(void* event);
+int mulan_event_record_external(void* event, hipStream_t stream);
+int mulan_stream_wait_event(hipStream_t stream, void* event);
+
 /* ---- 3x3 SAME convolution, NHWC, HWIO weights [3,3,C,N] --------------------------------------
  * flax nn.Conv(kernel_size=(3,3)) in ResnetBlock conv1/conv2 (ldm/model_vdm.py:633-634,645-650;
  * ldm/ldm_unet.py:33-34,49-54), conv_in / conv_out (model_vdm.py:348-349,378-383;

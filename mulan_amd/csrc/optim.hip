@@ -192,4 +192,37 @@ MULAN_API int mulan_set_tuning(int key, int value) {
   return 0;
 }
 
+MULAN_API int mulan_event_create(void** event) {
+  if (!event) return (int)hipErrorInvalidValue;
+  hipEvent_t e;
+  const hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  *event = r == hipSuccess ? static_cast<void*>(e) : nullptr;
+  return (int)r;
+}
+
+MULAN_API int mulan_event_destroy(void* event) { return (int)hipEventDestroy(static_cast<hipEvent_t>(event)); }
+
+// On a capturing stream: an event-record NODE of the graph being captured, depending on everything the stream has
+// captured so far (every replay records the event when that node runs; work outside the graph waits for it with
+// mulan_stream_wait_event after the launch).  Added through the capture's own graph handle (hipStreamGetCaptureInfo_v2 +
+// hipGraphAddEventRecordNode): hipEventRecordWithFlags(..., hipEventRecordExternal) returns hipErrorInvalidValue in the
+// HIP runtime torch 2.10+rocm7.0 ships.  The node is a leaf: nothing captured later depends on it.  On a stream that is
+// not capturing: a plain hipEventRecord.
+MULAN_API int mulan_event_record_external(void* event, hipStream_t stream) {
+  hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t e = hipStreamGetCaptureInfo_v2(stream, &status, &id, &graph, &deps, &ndeps);
+  if (e != hipSuccess) return (int)e;
+  if (status != hipStreamCaptureStatusActive) return (int)hipEventRecord(static_cast<hipEvent_t>(event), stream);
+  hipGraphNode_t node;
+  return (int)hipGraphAddEventRecordNode(&node, graph, deps, ndeps, static_cast<hipEvent_t>(event));
+}
+
+MULAN_API int mulan_stream_wait_event(hipStream_t stream, void* event) {
+  return (int)hipStreamWaitEvent(stream, static_cast<hipEvent_t>(event), 0);
+}
+
 MULAN_API const char* mulan_version(void) { return "mulan_hip 0.1 (gfx950, fp32 MFMA)"; }

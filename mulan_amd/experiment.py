@@ -34,6 +34,9 @@ def restore_partial(state, state_restore_dict):
     return state
 
 
+GRAPH_OVERLAP = os.environ.get("MULAN_GRAPH_OVERLAP", "1") == "1"    # A/B switch: 0 = all-reduce behind the whole graph
+
+
 def ops_kernel_timer_off():
     from . import ops
     return ops.KERNEL_TIMER is None
@@ -93,6 +96,11 @@ class GraphedStep:
             state.zero_grad()
             state.drop_graph_refs()                          # no autograd node of the eager stream may survive
             torch.cuda.synchronize()
+            # several ranks: the hooks that launch a bucket's all-reduce in the eager step plant an event-record node per
+            # bucket instead (parallel.GradReducer._mark); after the replay the collectives wait for those nodes, i.e.
+            # they run under the rest of the replayed backward pass (MULAN_GRAPH_OVERLAP=0: behind the whole graph)
+            if GRAPH_OVERLAP:
+                exp.reducer.begin_capture()
             with torch.cuda.graph(self.graph):
                 state.zero_grad()
                 packer = state.param_packer()
@@ -102,6 +110,7 @@ class GraphedStep:
                                            noise=self.noise)
                 with ops.weight_gradient_stream():
                     bpd.backward()
+                exp.reducer.end_capture()
                 state.collect_grads()
                 if packer is not None:
                     packer.invalidate()
@@ -156,7 +165,7 @@ class GraphedStep:
         if self.whole:
             state.step += 1
         else:
-            exp.reducer.allreduce_now()
+            exp.reducer.allreduce_captured()
             state.apply_gradients(lr=exp.lr_schedule(state.step), ema_rate=exp.config.optimizer.ema_rate,
                                   grad_scale=1.0 / exp.world,
                                   clip_norm=exp.config.optimizer.get('gradient_clip_norm', None))
@@ -205,12 +214,12 @@ class Experiment(abc.ABC):
         self._sample_dummy = None
         self._profile = None                 # profiling.Profile while config.training.profile is set (train_and_evaluate)
         # the lax.scan of the reference (ldm/experiment.py:89-91: `substeps` train steps per host dispatch) becomes a
-        # HIP-graph replay per step (GraphedStep).  Default: on for one rank.  With several ranks the eager step overlaps
-        # the bucketed gradient all-reduce with the backward pass (a replayed graph ends before the collectives, which
-        # then run exposed behind it: ~2-3 ms for 285 MB over xGMI), so it stays eager WHERE THE HOST KEEPS UP: issuing
-        # the ~1100 launches of a step takes the host ~54 ms whatever the batch (measured, 32-block U-Nets), the GPU
-        # ~0.6 ms per image at E = 128 -- 128 images per GPU: 77.8 ms eager = replayed; 64 per GPU (BASELINE config #3
-        # on 8 GPUs): 54.3 ms eager against 43.5 replayed.  Hence: replay when local_batch * (E / 128)^2 < 96.
+        # HIP-graph replay per step (GraphedStep), on one rank and on several.  With several ranks the collectives stay
+        # outside the graph, but every bucket's all-reduce waits only for the event node the capture planted behind that
+        # bucket (parallel.GradReducer.begin_capture / allreduce_captured), so it runs under the rest of the replayed
+        # backward pass like the eager step's does -- and the host, which needs ~54 ms to issue the ~1100 launches of an
+        # eager step whatever the batch, is out of the picture at every batch size (rounds 1-3 chose between the replay
+        # with exposed collectives and the eager step by batch size).
         # MULAN_HIP_GRAPH=1 / 0 or config.training.hip_graph=True / False override.
         env = os.environ.get("MULAN_HIP_GRAPH", "")
         want = config.training.get("hip_graph", None)
@@ -220,9 +229,7 @@ class Experiment(abc.ABC):
         if env in ("0", "1"):
             want = env == "1" and want is not False
         elif want is None:
-            local = int(config.training.batch_size_train) // max(1, self.world)
-            width = float(config.model.get("sm_n_embd", 128)) / 128.0
-            want = self.world == 1 or local * width * width < 96
+            want = True
         self.hip_graph = bool(want) and torch.device(self.device).type == "cuda"
         self._graphed = None
         self._eager_steps = 0

@@ -112,6 +112,10 @@ SIGNATURES = {
     "mulan_version": [],
     "mulan_set_tuning": [I, I],
     "mulan_set_debug_buffer": [P],
+    "mulan_event_create": [P],
+    "mulan_event_destroy": [P],
+    "mulan_event_record_external": [P, P],
+    "mulan_stream_wait_event": [P, P],
 }
 _RESTYPES = {"mulan_rk_workspace_bytes": c_size_t, "mulan_global_norm_clip_workspace": c_size_t, "mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
              "mulan_conv3x3_pack_f16x3_bytes": c_size_t, "mulan_conv3x3_planes_bytes": c_size_t, "mulan_linear_pack_f16x3_bytes": c_size_t,
@@ -160,6 +164,11 @@ def ptr(t):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, name):
+    if rc != 0:
+        raise MulanHipError(f"{name} failed with hipError_t {rc}")
 
 
 def call(name, *args):

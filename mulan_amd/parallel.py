@@ -50,7 +50,9 @@ class GradReducer:
     when all of its leaves have reported ready through their post-accumulate hook.
     """
 
-    def __init__(self, flat_grad, leaves, bucket_bytes=64 << 20, process_group=None):
+    def __init__(self, flat_grad, leaves, bucket_bytes=None, process_group=None):
+        if bucket_bytes is None:             # 64 MB: a few large all-reduces per step (xGMI ring: per-link bound)
+            bucket_bytes = int(os.environ.get("MULAN_BUCKET_MB", "64")) << 20
         self.flat = flat_grad
         self.pg = process_group
         self.world = world_size()
@@ -80,6 +82,7 @@ class GradReducer:
         if self.buckets:
             self.buckets[0][0] = 0
         self.paused = False         # True while a train step is being captured into a HIP graph: hooks do not launch
+        self.capture = None         # while / after a capture: {"order": [bucket, ...], "events": {bucket: handle}}
         self.pending = [0] * len(self.buckets)
         self.ready_order = []       # bucket indices in the order they were launched in the last backward
         self.works = []
@@ -117,11 +120,81 @@ class GradReducer:
             gv.copy_(t.grad)
             t.grad = gv       # so TrainState.collect_grads() does not overwrite the reduced bucket later
         if self.paused:
+            if self.capture is not None and self.capture["open"]:
+                bi = self.leaf_bucket[id(t)]
+                self.pending[bi] -= 1
+                if self.pending[bi] == 0 and not self.launched[bi]:
+                    self._mark(bi)
             return
         bi = self.leaf_bucket[id(t)]
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and not self.launched[bi]:
             self._launch(bi)
+
+    # ---- a replayed (HIP-graph) backward pass with the all-reduce still overlapped ------------------------------------
+    # The collectives stay outside the graph (torch.distributed), but each bucket's all-reduce may start as soon as the
+    # REPLAYED backward pass has produced the bucket: while the step is captured, the hook that would launch bucket k
+    # plants an event-record node behind everything bucket k depends on (mulan_event_record_external: the capturing
+    # stream's position and the weight-gradient stream's); after graph.replay() the collective stream waits for node k
+    # and all-reduces bucket k under the rest of the graph (the reference gets the same overlap from XLA inside
+    # pmap(scan(train_step)), ldm/experiment.py:89-95,341).
+    def begin_capture(self):
+        """call before capturing a train step (with paused = True)"""
+        if not (self.enabled and self.side is not None):
+            return
+        import ctypes
+        from . import lib
+        L = lib.load()
+        self.prepare()
+        events = self.capture["events"] if self.capture else {}
+        for bi in range(len(self.buckets)):          # (created here: no handle is made while the stream captures)
+            if bi not in events:
+                h = ctypes.c_void_p()
+                lib.check(L.mulan_event_create(ctypes.byref(h)), "mulan_event_create")
+                events[bi] = h.value
+        self.capture = {"order": [], "events": events, "open": True}
+
+    def _mark(self, bi):
+        from . import lib, ops
+        L = lib.load()
+        ev = self.capture["events"][bi]
+        # the collective stream joins the capture here only to carry the node's dependencies: the capturing stream's
+        # position and the weight-gradient stream's (the bucket's last weight gradient may still be queued there)
+        self.side.wait_stream(torch.cuda.current_stream())
+        wg = ops.side_stream()
+        if wg is not None:
+            self.side.wait_stream(wg)
+        lib.check(L.mulan_event_record_external(ev, self.side.cuda_stream), "mulan_event_record_external")
+        self.launched[bi] = True
+        self.capture["order"].append(bi)
+
+    def end_capture(self):
+        """call inside the capture, after the backward pass: the collective stream rejoins the capturing stream"""
+        if self.capture is not None and self.capture["open"]:
+            self.capture["open"] = False
+            if self.capture["order"]:
+                torch.cuda.current_stream().wait_stream(self.side)
+
+    def allreduce_captured(self):
+        """after graph.replay(): every bucket that was marked in the capture is all-reduced behind its event node (i.e.
+        while the rest of the graph still runs), whatever was not marked behind the whole graph; the current stream then
+        waits for all of them"""
+        if not self.enabled:
+            return
+        marked = self.capture["order"] if (self.capture is not None and self.side is not None) else []
+        if not marked:
+            return self.allreduce_now()
+        from . import lib
+        L = lib.load()
+        self.prepare()
+        for bi in marked:
+            lo, hi, _ = self.buckets[bi]
+            lib.check(L.mulan_stream_wait_event(self.side.cuda_stream, self.capture["events"][bi]), "mulan_stream_wait_event")
+            self.launched[bi] = True
+            self.ready_order.append(bi)
+            with torch.cuda.stream(self.side):
+                self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self.finish()
 
     def allreduce_now(self):
         """All buckets at once, after a graph-replayed backward (no hooks ran): same result as prepare() ... finish(),

@@ -500,6 +500,34 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
 
 
 @pytest.mark.timeout(900)
+def test_two_rank_replayed_step_overlaps_the_allreduce_and_equals_the_eager_step():
+    """replay AND overlap.  Two ranks (gloo over the device tensors of the one GPU here; RCCL
+    where two GPUs are visible): the train step replayed as a HIP graph, each gradient bucket all-reduced outside the
+    graph behind the event node the capture planted after that bucket (tests/overlap_replay_check.py), equals the eager
+    overlapped step bit for bit over four optimizer steps -- parameters, EMA, Adam moments, reduced gradient, logged
+    bits/dim -- and the buckets are issued in the order they were marked."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {**os.environ, "MULAN_BUCKET_MB": "16"}
+    if torch.cuda.device_count() < 2:
+        env.update({"MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"})
+    for k in ("MULAN_HIP_GRAPH", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MULAN_GRAPH_OVERLAP"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tests", "overlap_replay_check.py")],
+                       capture_output=True, text=True, timeout=840, env=env, cwd=root)
+    assert r.returncode == 0 and "OVERLAP_REPLAY_CHECK ok" in r.stdout, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+
+
+@pytest.mark.timeout(900)
 def test_imagenet32_width_train_parity():
     """E = 256 (ldm/configs/imagenet32.py): 256 / 512-channel convolutions, GroupNorm over 512 concatenated channels,
     two cout blocks per convolution tile, four weight-gradient tiles -- same parity bars as the CIFAR width"""

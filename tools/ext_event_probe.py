@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Dev probe (round 4): can work OUTSIDE a replayed HIP graph wait for a point INSIDE it?  The multi-rank train step wants
 the gradient all-reduce of bucket k (a collective, outside the graph) to start as soon as the captured backward pass has
-produced that bucket, while the rest of the graph still runs.  torch.cuda.Event(external=True) is captured as an event-record
-NODE (hipEventRecordWithFlags(..., hipEventRecordExternal)) instead of an internal fork/join edge.  Checked here:
+produced that bucket, while the rest of the graph still runs.  mulan_event_record_external (hipEventRecordWithFlags(..., hipEventRecordExternal);
+torch.cuda.Event(external=True) raises "External events are disallowed in rocm" in torch 2.10) on the capturing stream is
+captured as an event-record NODE instead of an internal fork/join edge.  Checked here:
   (1) a side stream that waits for the event after graph.replay() sees the value written BEFORE the node (every replay:
       the value changes from replay to replay, so a stale wait shows), and
   (2) it gets going long before the graph ends (timestamps).
     python tools/ext_event_probe.py"""
+import ctypes
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
@@ -17,7 +24,11 @@ def main():
     y = torch.zeros_like(x)
     main_s = torch.cuda.Stream()
     side = torch.cuda.Stream()
-    ev = torch.cuda.Event(external=True)
+    from mulan_amd import lib as L
+    lib = L.load()
+    evp = ctypes.c_void_p()
+    assert lib.mulan_event_create(ctypes.byref(evp)) == 0
+    ev = evp.value
 
     def chain(n):
         b = a
@@ -32,7 +43,8 @@ def main():
         with torch.cuda.graph(g, stream=main_s):
             chain(20)                  # ~ 1 ms in front
             x.add_(1.0)
-            ev.record()                # external: an event-record node
+            rc = lib.mulan_event_record_external(ev, main_s.cuda_stream)            # an event-record node
+            print("mulan_event_record_external inside the capture ->", rc, flush=True)
             out = chain(600)           # the long tail (~ 20 ms) the side stream should NOT wait for
     torch.cuda.synchronize()
     ok = True
@@ -43,7 +55,7 @@ def main():
             t0.record()
             g.replay()
             t_end.record()
-        side.wait_event(ev)
+        assert lib.mulan_stream_wait_event(side.cuda_stream, ev) == 0
         with torch.cuda.stream(side):
             y.copy_(x)
             t_side.record()
