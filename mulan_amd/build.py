@@ -35,8 +35,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True, extra_flags=()):
+def build_library(force=False, verbose=True, extra_flags=(), variant=""):
+    """variant (dev A/B builds: `python -m mulan_amd.build --variant b -DMULAN_X=1`): objects under csrc/_obj_<variant>/,
+    library libmulan_hip_<variant>.so, selected at run time with MULAN_HIP_LIB=<path> (mulan_amd/lib.py)"""
     hipcc = _hipcc()
+    global OBJ, LIB
+    if variant:
+        OBJ = os.path.join(HERE, "csrc", "_obj_" + variant)
+        LIB = os.path.join(HERE, f"libmulan_hip_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     jobs = []
@@ -66,4 +72,6 @@ def build_library(force=False, verbose=True, extra_flags=()):
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else ""
+    print(build_library(force="--force" in sys.argv, variant=variant,
+                        extra_flags=tuple(a for a in sys.argv[1:] if a.startswith("-D"))))

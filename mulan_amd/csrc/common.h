@@ -10,6 +10,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define MULAN_CHECK_LAUNCH() return (int)hipGetLastError()
 
+// A 16-byte load of data this kernel reads once (the rows of the per-pixel dense kernel, its residual, optimizer state).
+// tools/mall_probe.hip (profiles/r04_mall_probe.log): a plain streaming consumer reads 13-25 % faster with non-temporal
+// loads, and the GroupNorm forward kernel gains 0.5 ms per step from them -- but in these kernels the A/B went the other
+// way (profiles/r04_nt_loads_ab.log: the step 0.3 ms SLOWER with nt loads in the dense kernel + AdamW, and the
+// convolution's residual loads cost it 0.527 vs 0.538 of its roofline), so the default is the plain load;
+// -DMULAN_NT_MORE=1: dev A/B build.  nt STORES bypass the Infinity Cache (the next reader falls to the cold rate): never.
+#ifndef MULAN_NT_MORE
+#define MULAN_NT_MORE 0
+#endif
+__device__ __forceinline__ f32x4 ld_stream4(const float* p) {
+#if MULAN_NT_MORE
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+
 // developer tuning knobs (mulan_set_tuning): [0] conv fwd variant, [1] wgrad resident-block target
 extern int g_mulan_tune[32];
 extern unsigned long long* g_mulan_debug_buffer;   // dev-only stamp buffer (>= 64 u64), normally null

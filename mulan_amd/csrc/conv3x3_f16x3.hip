@@ -832,7 +832,11 @@ __device__ __forceinline__ int clamped_exp(unsigned maxbits) {
 // forward kernel used to hand on (split2 of x * s with the concat's per-image scale): bit-identical dw.
 // PROBE16 (dev, timing only, wrong numbers): every 32x32x16 MFMA replaced by two 16x16x32 ones on the same fragments --
 // the same operand traffic and matrix-core time on the shape the chip clocks higher under its power limit
-template <int TAPS, bool XF32 = false, bool PROBE16 = false>
+// ABL (dev, timing only, wrong numbers; tools/wgrad_ab.py --tunes 7=N): 2 = the x fragments of taps kw = 0, 2 are not read
+// (the centre tap's are used: what sharing one fragment per k step between the three taps could save at most), 3 = no
+// staging (no global loads, no LDS stores: the main loop multiplies what the prologue staged), 4 = 2 + 3, 5 = no slab
+// stores, 6 = no barrier in the loop (+ 3)
+template <int TAPS, bool XF32 = false, bool PROBE16 = false, int ABL = 0>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradArgsP p) {
   static_assert(!XF32 || TAPS == 1, "fp32 x operand: one-tap kernel only");
   constexpr int NQ = 4 * TAPS;                   // stages per row pair: 4 k steps x TAPS
@@ -1035,11 +1039,18 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
       if (q + 1 < NQ) {                                // next stage's x fragments
         const int ks1 = (q + 1) / TAPS, kw1 = TAPS == 3 ? (q + 1) - ks1 * 3 : 1;
         const int rr = ks1 >> 1, w0 = (ks1 & 1) * 16;
+        if ((ABL == 2 || ABL == 4) && kw1 != 0) {       // (ablation) one fragment read per k step
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[(q + 1) & 1][i][pl] = af[q & 1][i][pl];
+        } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl)
             af[(q + 1) & 1][i][pl] = tr_read8h(xa + pl * X3_PLANE + i * X3_HALF + (rr * kPW + w0 + kw1) * 64);
+        }
       }
       if ((TAPS == 1 || kw == 1) && ks + 1 < 4) {      // next k step's dy fragments
         const int rr = (ks + 1) >> 1, w0 = ((ks + 1) & 1) * 16;
@@ -1051,7 +1062,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
       }
       // staging, each register refilled at once with the same unit of pair p + 2.  TAPS = 3: x unit q in stages
       // 0..8, dy unit q - 4 in stages 4..11.  TAPS = 1 (4 stages): units q, q + 4, (q + 8).
-      if (TAPS == 3) {
+      if (ABL == 3 || ABL == 4 || ABL == 6) {
+      } else if (TAPS == 3) {
         if (q < XV) { store_x(bn, q); gload_x1(pr2, q); }
         if (q >= 4) { store_d(bn, q - 4); gload_d1(pr2, q - 4); }
       } else {
@@ -1091,7 +1103,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    if (ABL != 6) __syncthreads();
   }
 
   if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
@@ -1111,6 +1123,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_f16x3_planes_kernel(WgradAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = c0 + wci * 64 + i * 32 + mfma32_row(r, lane);
+          if (ABL != 5 || acc[kw][i][j][r] == 12345.678f)
           slab[((size_t)(TAPS == 3 ? kh * 3 + kw : 0) * C + c) * N + n] = (acc[kw][i][j][r] * inv_x) * inv_g;
         }
       }
@@ -1412,14 +1425,25 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
   const int S = wgrad_splits_p(B, H, C, N, share_chip);
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
                B, H, C, N, S, g_mulan_debug_buffer};
-  if (g_mulan_tune[7] == 1) {   // dev: timing probe (wrong numbers)
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<3, false, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
-    hipLaunchKernelGGL((conv3x3_wgrad_f16x3_planes_kernel<3, false, true>), dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256),
-                       WG3_SMEM + 64, stream, a);
-  } else
-  hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<3>, dim3(S, 3, (C / WG3_T) * (N / WG3_T)), dim3(256), WG3_SMEM + 64,
-                     stream, a);
+  const dim3 grid(S, 3, (C / WG3_T) * (N / WG3_T));
+#define MULAN_WG_ABL(PROBE, ABLV)                                                                                       \
+  {                                                                                                                     \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<3, false, PROBE, ABLV>),        \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);                                     \
+    hipLaunchKernelGGL((conv3x3_wgrad_f16x3_planes_kernel<3, false, PROBE, ABLV>), grid, dim3(256), WG3_SMEM + 64,      \
+                       stream, a);                                                                                      \
+  }
+  switch (g_mulan_tune[7]) {   // dev: timing probes (wrong numbers)
+    case 1: MULAN_WG_ABL(true, 0) break;
+    case 2: MULAN_WG_ABL(false, 2) break;
+    case 3: MULAN_WG_ABL(false, 3) break;
+    case 4: MULAN_WG_ABL(false, 4) break;
+    case 5: MULAN_WG_ABL(false, 5) break;
+    case 6: MULAN_WG_ABL(false, 6) break;
+    default:
+      hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<3>, grid, dim3(256), WG3_SMEM + 64, stream, a);
+  }
+#undef MULAN_WG_ABL
   const int E = 9 * C * N;
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
   MULAN_CHECK_LAUNCH();

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
     if (c < p.K1) { src = p.x1; ld = p.K1; cl = c; } else { src = p.x2; ld = p.K2; cl = c - p.K1; }
     const float* base = src + (size_t)(r0 + arow) * ld + cl + aq * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = *reinterpret_cast<const f32x4*>(base + (size_t)(32 * i) * ld);
+    for (int i = 0; i < 4; ++i) areg[i] = ld_stream4(base + (size_t)(32 * i) * ld);
   };
   // plane output window: this block's image (only the first column block writes; nothing when not requested)
   const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
     if (res) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const f32x4 c = *reinterpret_cast<const f32x4*>(res + rowbase + (size_t)(it * 4 + prl) * ldo);
+        const f32x4 c = ld_stream4(res + rowbase + (size_t)(it * 4 + prl) * ldo);
         add[it][0] += c[0]; add[it][1] += c[1]; add[it][2] += c[2]; add[it][3] += c[3];
       }
     }

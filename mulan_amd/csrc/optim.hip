@@ -23,11 +23,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   if (a.dyn) { a.lr = a.dyn[0]; a.bc1 = a.dyn[1]; a.bc2 = a.dyn[2]; }
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
     const size_t i = q << 2;
-    f32x4 p = *reinterpret_cast<const f32x4*>(a.p + i);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + i);
-    f32x4 m = *reinterpret_cast<const f32x4*>(a.m + i);
-    f32x4 v = *reinterpret_cast<const f32x4*>(a.v + i);
-    f32x4 e = *reinterpret_cast<const f32x4*>(a.ema + i);
+    f32x4 p = ld_stream4(a.p + i);
+    const f32x4 g = ld_stream4(a.g + i);
+    f32x4 m = ld_stream4(a.m + i);
+    f32x4 v = ld_stream4(a.v + i);
+    f32x4 e = ld_stream4(a.ema + i);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gk = g[k] * a.gscale;

@@ -10,6 +10,8 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_u
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmulan_hip.so")
+if os.environ.get("MULAN_HIP_LIB"):        # dev A/B builds (python -m mulan_amd.build --variant b -D...): another build of THIS library
+    LIB_PATH = os.environ["MULAN_HIP_LIB"]
 
 P, I, F, Z, U, LL, D = c_void_p, c_int, c_float, c_size_t, c_ulonglong, c_longlong, c_double
 
