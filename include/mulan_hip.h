@@ -42,13 +42,15 @@ int mulan_set_debug_buffer(void* dev_ptr);
  * one compiled program (ldm/experiment.py:89-95,341).  Here the train step is a replayed HIP graph and the RCCL
  * all-reduce of gradient bucket k is issued outside it (torch.distributed): it may start as soon as the captured backward
  * pass has produced that bucket.  mulan_event_record_external on a capturing stream becomes an event-record NODE
- * (hipEventRecordWithFlags, hipEventRecordExternal) instead of an internal fork / join edge; after hipGraphLaunch the
- * collective's stream waits for it with mulan_stream_wait_event.  Outside a capture the pair is an ordinary
- * record / wait.  (torch.cuda.Event(external=True) is refused on ROCm builds of torch 2.10, hence these four.) */
+ * (hipGraphAddEventRecordNode on the capture's own graph, behind everything the stream has captured so far) instead of an
+ * internal fork / join edge; after hipGraphLaunch the collective's stream waits for it with mulan_stream_wait_event.
+ * Outside a capture the pair is an ordinary record / wait.  (torch.cuda.Event(external=True) is refused on ROCm builds
+ * of torch 2.10 and hipEventRecordWithFlags(hipEventRecordExternal) returns hipErrorInvalidValue in the runtime it ships,
+ * hence these four; tools/ext_event_probe.py, profiles/r04_ext_event_probe.log.) */
 int mulan_event_create(void** event);
 int mulan_event_destroy(void* event);
-int mulan_event_record_external(void* event, hipStream_t stream);
-int mulan_stream_wait_event(hipStream_t stream, void* event);
+int mulan_event_record_external(void* event, mulan_stream_t stream);
+int mulan_stream_wait_event(mulan_stream_t stream, void* event);
 
 /* ---- 3x3 SAME convolution, NHWC, HWIO weights [3,3,C,N] --------------------------------------
  * flax nn.Conv(kernel_size=(3,3)) in ResnetBlock conv1/conv2 (ldm/model_vdm.py:633-634,645-650;
@@ -216,8 +218,9 @@ int mulan_gemm(const float* A, const float* B, float* C, const float* bias, cons
 size_t mulan_gemm_workspace(int M, int N, int K, int batch);
 
 /* ---- fused attention core (f16x3), S = 1024 positions, one head ----------------------------------------------
- * C = 128: forward and backward (the CIFAR width, configs/cifar10-conditioned.py:70).  C = 256 (configs/imagenet32.py:70):
- * pack + forward only -- evaluation and sampling; a training step at that width keeps the unfused products.
+ * C = 128 (the CIFAR width, configs/cifar10-conditioned.py:70) and C = 256 (configs/imagenet32.py:70): forward and
+ * backward; B <= 65535.  (C = 256 backward: dq and dk with the output channels split over two blocks per column tile, dv
+ * in a launch of its own -- attention_f16x3.hip.)
  * AttnBlock core softmax((q / sqrt(C)) k^T) v and its gradients (model_vdm.py:679-683, 704-802) without the
  * [1024 x 1024] score / probability matrices in HBM.  Operands are the packs of mulan_linear_pack_f16x3_batched:
  * "T" pack of x [B,1024,C]: (K = C, N = 1024, transpose = 1); "N" pack: (K = 1024, N = C, transpose = 0); *max: the

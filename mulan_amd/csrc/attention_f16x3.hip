@@ -19,10 +19,16 @@
 // the a-priori bound C max|do| max|v| + max|delta| (the split is accurate relative to each element: a loose bound only
 // raises the absolute error floor, 2^-38 of the bound).
 // Block = 4 waves = 128 columns; X / X2 / Z / Z2 tiles of the current 32 rows go through LDS (next tile's global loads
-// are in flight in registers meanwhile), the column-side fragments Y / Y2 stay in registers.  C = 128 for all three
-// kernels; the forward kernel also exists for C = 256 (round 3: the ImageNet-32 width; evaluation and sampling paths,
-// one block per CU at ~370 registers).  The backward kernels at C = 256 would hold Y, Y2 and the output accumulators in
-// 128 + 128 + 128 (+ 128) registers: beyond the 512 of one wave per SIMD -- they need the 16-column / 16x16x32 form.
+// are in flight in registers meanwhile), the column-side fragments Y / Y2 stay in registers.  C = 128: the three kernels
+// above.  C = 256 (the ImageNet-32 width): the forward kernel as it is (one block per CU at ~370 registers); in the
+// backward pass Y, Y2 and the output accumulators of MODE 1 / 2 would need 128 + 128 + 128 (+ 128) registers, so the
+// OUTPUT channels are split over blocks (OSPLIT = 2: blockIdx.z owns 128 of the 256 output channels, i.e. 64 accumulator
+// registers and half of the Z tile; the scores are recomputed by both halves) and MODE 2 is split by product:
+//   MODE 3 (dv):  columns = keys; X = q, Y = k;                    E = P;  Z = do  -> dv   (no T2, all 256 channels)
+//   MODE 4 (dk):  columns = keys; X = q, Y = k, X2 = do, Y2 = v;   E = dS; Z = q   -> dk   (OSPLIT = 2)
+// -- five launches (dq x 2 halves in one grid, dv, dk x 2 halves in one grid) instead of two, 15 % more matrix-core work
+// than an unsplit kernel would do, and no [B, 1024, 1024] tensor in HBM (the unfused path a training step at E = 256
+// used until round 4 materialised S, P, dP and dS: 16 GiB at B = 1024).
 #include "common.h"
 #include "f16x3_common.h"
 
@@ -47,22 +53,27 @@ struct AttnArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int AC = 128>
+template <int MODE, int AC = 128, int OSPLIT = 1>
 __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f16x3_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  static_assert(AC == 128 || (AC == 256 && MODE == 0), "C = 256: forward kernel only");
+  static_assert(AC == 128 || AC == 256, "C = 128 or 256");
+  static_assert(MODE <= 2 || AC == 256, "MODE 3 / 4: the split form of MODE 2 for C = 256");
   constexpr int NCH = AC / 16;             // channel chunks (8 / 16)
-  constexpr int NDT = AC / 32;             // output-channel tiles (4 / 8)
+  constexpr int OC = AC / OSPLIT;          // output channels of this block (blockIdx.z-th part of the AC)
+  constexpr int NDT = OC / 32;             // output-channel tiles
   constexpr int X_BYTES = NCH * 32 * XP;   // 20480 / 40960
-  constexpr int Z_BYTES = 2 * AC * ZP;     // 18432 / 36864
+  constexpr int Z_BYTES = 2 * OC * ZP;     // 18432 / 36864
   constexpr int NPX = NCH / 2;             // 16-byte pieces per thread and T-packed tile (NCH * 128 pieces)
-  constexpr int NPZ = AC / 32;             // ... and N-packed tile (8 AC pieces)
-  constexpr bool BWD = MODE != 0;
+  constexpr int NPZ = OC / 32;             // ... and N-packed tile (8 OC pieces)
+  constexpr bool BWD = MODE != 0;          // (the staging / fragment code below reads BWD as "there is a T2")
+  constexpr bool KEYS = MODE >= 2;         // the columns are keys
+  constexpr bool T2ON = MODE == 1 || MODE == 2 || MODE == 4;
   constexpr int NZ = MODE == 2 ? 2 : 1;
   unsigned char* xs = smem;                               // X tile
   unsigned char* x2s = smem + X_BYTES;                    // X2 tile (backward)
-  unsigned char* zs = smem + (BWD ? 2 : 1) * X_BYTES;     // Z tile(s)
-  float* rowvals = reinterpret_cast<float*>(zs + NZ * Z_BYTES);   // MODE 2: lse / delta of the tile's 32 rows
+  unsigned char* zs = smem + (T2ON ? 2 : 1) * X_BYTES;    // Z tile(s)
+  float* rowvals = reinterpret_cast<float*>(zs + NZ * Z_BYTES);   // KEYS: lse / delta of the tile's 32 rows
+  const int oc0 = blockIdx.z * OC;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,11 +82,11 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   const int col0 = blockIdx.x * 128 + wave * 32;
   const size_t img = (size_t)AS * AC * 4;                 // bytes of one packed image
   // operands by role
-  const unsigned char* X = (MODE == 2 ? p.qt : p.kt) + b * img;
-  const unsigned char* Y = (MODE == 2 ? p.kt : p.qt) + b * img;
-  const unsigned char* X2 = (MODE == 2 ? p.dot : p.vt) + b * img;
-  const unsigned char* Y2 = (MODE == 2 ? p.vt : p.dot) + b * img;
-  const unsigned char* Z = (MODE == 0 ? p.vn : (MODE == 1 ? p.kn : p.don)) + b * img;
+  const unsigned char* X = (KEYS ? p.qt : p.kt) + b * img;
+  const unsigned char* Y = (KEYS ? p.kt : p.qt) + b * img;
+  const unsigned char* X2 = (KEYS ? p.dot : p.vt) + b * img;
+  const unsigned char* Y2 = (KEYS ? p.vt : p.dot) + b * img;
+  const unsigned char* Z = (MODE == 0 ? p.vn : (MODE == 1 ? p.kn : (MODE == 4 ? p.qn : p.don))) + b * img;
   const unsigned char* Z2 = p.qn + b * img;
 
   float s_, inv_q, inv_k, inv_v, inv_do = 0.f, s_ds = 0.f, inv_ds = 0.f;
@@ -92,14 +103,14 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   const float c2 = inv_v * inv_do;                        // accumulator of T2 -> dP
 
   // ---- column-side fragments (B operand of T1 / T2): lane = column r, channels 8 h .. 8 h + 7 of chunk c
-  f16x8 yf[NCH][2], y2f[BWD ? NCH : 1][2];
+  f16x8 yf[NCH][2], y2f[T2ON ? NCH : 1][2];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
       const size_t off = (((size_t)c * AS + col0 + r) * 2 + pl) * 32 + h * 16;
       yf[c][pl] = *reinterpret_cast<const f16x8*>(Y + off);
-      if (BWD) y2f[c][pl] = *reinterpret_cast<const f16x8*>(Y2 + off);
+      if (T2ON) y2f[c][pl] = *reinterpret_cast<const f16x8*>(Y2 + off);
     }
   float col_l = 0.f, col_d = 0.f;                         // MODE 1: lse / delta of this lane's column
   if (MODE == 1) {
@@ -115,7 +126,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   float m_run = -3.0e38f, l_run = 0.f;                    // MODE 0: online softmax state of this lane's column (own half of the rows)
 
   // ---- staging: 16-byte pieces, NPX / NPZ per thread and tile (C = 128: 1024 pieces = 16 KB per tile)
-  constexpr int OX2 = NPX, OZ = (BWD ? 2 : 1) * NPX, OZ2 = OZ + NPZ;
+  constexpr int OX2 = NPX, OZ = (T2ON ? 2 : 1) * NPX, OZ2 = OZ + NPZ;
   constexpr int NSTG = OZ + NZ * NPZ;
   i32x4 stg[NSTG];
   auto gload = [&](int t) {
@@ -125,13 +136,14 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
       // T pack: chunk c = idx >> 7, row = (idx >> 2) & 31, piece = idx & 3
       const size_t xo = (((size_t)(idx >> 7) * AS + t * 32 + ((idx >> 2) & 31)) * 64) + (idx & 3) * 16;
       stg[i] = *reinterpret_cast<const i32x4*>(X + xo);
-      if (BWD) stg[OX2 + i] = *reinterpret_cast<const i32x4*>(X2 + xo);
+      if (T2ON) stg[OX2 + i] = *reinterpret_cast<const i32x4*>(X2 + xo);
     }
 #pragma unroll
     for (int i = 0; i < NPZ; ++i) {
       const int idx = tid + 256 * i;
-      // N pack: the two 16-row chunks of the tile are contiguous: [2][C][64 B]
-      const size_t zo = (size_t)t * 2 * AC * 64 + (size_t)idx * 16;
+      // N pack: the two 16-row chunks of the tile are [2][C][64 B]; this block's OC channels start at oc0
+      const int rc2 = idx / (OC * 4), rem = idx - rc2 * (OC * 4);
+      const size_t zo = ((size_t)(t * 2 + rc2) * AC + oc0) * 64 + (size_t)rem * 16;
       stg[OZ + i] = *reinterpret_cast<const i32x4*>(Z + zo);
       if (MODE == 2) stg[OZ2 + i] = *reinterpret_cast<const i32x4*>(Z2 + zo);
     }
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
       const int idx = tid + 256 * i;
       const int xd = ((idx >> 7) * 32 + ((idx >> 2) & 31)) * XP + (idx & 3) * 16;
       *reinterpret_cast<i32x4*>(xs + xd) = stg[i];
-      if (BWD) *reinterpret_cast<i32x4*>(x2s + xd) = stg[OX2 + i];
+      if (T2ON) *reinterpret_cast<i32x4*>(x2s + xd) = stg[OX2 + i];
     }
 #pragma unroll
     for (int i = 0; i < NPZ; ++i) {
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   // accumulator-as-operand k order (cdna guide, "An accumulator tile as the next MFMA's operand"): element j is row
   // 16 s + 8 (j >> 2) + 4 h + (j & 3)  ->  two 8-byte pieces of the 16 packed rows
   auto zfrag = [&](const unsigned char* zb, int s, int dt, int pl) {
-    const unsigned char* a = zb + (s * AC + dt * 32 + r) * ZP + pl * 32 + h * 8;
+    const unsigned char* a = zb + (s * OC + dt * 32 + r) * ZP + pl * 32 + h * 8;
     const s16x4 lo = *reinterpret_cast<const s16x4*>(a);
     const s16x4 hi = *reinterpret_cast<const s16x4*>(a + 16);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -181,13 +193,13 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
 
   gload(0);
   lstore();
-  if (MODE == 2 && tid < 64) rowvals[tid] = (tid < 32 ? p.lse : p.delta)[(size_t)b * AS + (tid & 31)];
+  if (KEYS && tid < 64) rowvals[tid] = (tid < 32 ? p.lse : p.delta)[(size_t)b * AS + (tid & 31)];
   __syncthreads();
 
   for (int t = 0; t < AS / 32; ++t) {
     if (t + 1 < AS / 32) gload(t + 1);
     float nxt_rv = 0.f;
-    if (MODE == 2 && tid < 64 && t + 1 < AS / 32) nxt_rv = (tid < 32 ? p.lse : p.delta)[(size_t)b * AS + (t + 1) * 32 + (tid & 31)];
+    if (KEYS && tid < 64 && t + 1 < AS / 32) nxt_rv = (tid < 32 ? p.lse : p.delta)[(size_t)b * AS + (t + 1) * 32 + (tid & 31)];
 
     // ---- T1 (and T2): contraction over the channels
     f32x16 t1, t2;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
       t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yf[c][0], t1, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yf[c][1], t1, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yf[c][0], t1, 0, 0, 0);
-      if (BWD) {
+      if (T2ON) {
         const unsigned char* x2a = x2s + (c * 32 + r) * XP + h * 16;
         const f16x8 x2h = *reinterpret_cast<const f16x8*>(x2a), x2l = *reinterpret_cast<const f16x8*>(x2a + 32);
         t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2l, y2f[c][0], t2, 0, 0, 0);
@@ -245,9 +257,10 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         E[e] = __expf(t1[e] * c1 - lr[e >> 2][e & 3]);
-        E2[e] = E[e] * (t2[e] * c2 - dr[e >> 2][e & 3]);
+        if (MODE == 2) E2[e] = E[e] * (t2[e] * c2 - dr[e >> 2][e & 3]);
+        if (MODE == 4) E[e] = E[e] * (t2[e] * c2 - dr[e >> 2][e & 3]);
       }
-      escale = kPScale;
+      escale = MODE == 4 ? s_ds : kPScale;
       e2scale = s_ds;
     }
 
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
     __syncthreads();                                          // every wave is done with this tile's LDS image
     if (t + 1 < AS / 32) {
       lstore();
-      if (MODE == 2 && tid < 64) rowvals[tid] = nxt_rv;
+      if (KEYS && tid < 64) rowvals[tid] = nxt_rv;
     }
     __syncthreads();
   }
@@ -289,12 +302,14 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
     if (h == 0) p.lse_out[(size_t)b * AS + col0 + r] = m_run + __logf(l_run);
   } else if (MODE == 1) {
     oscale = p.alpha * inv_ds * inv_k;
+  } else if (MODE == 4) {
+    oscale = p.alpha * inv_ds * inv_q;                        // dk = alpha dS^T q
   } else {
     oscale = kPInv * inv_do;                                  // dv = P^T do
     o2scale = p.alpha * inv_ds * inv_q;                       // dk = alpha dS^T q
   }
-  float* orow = p.out + ((size_t)b * AS + col0 + r) * AC;
-  float* orow2 = MODE == 2 ? p.out2 + ((size_t)b * AS + col0 + r) * AC : nullptr;
+  float* orow = p.out + ((size_t)b * AS + col0 + r) * AC + oc0;
+  float* orow2 = MODE == 2 ? p.out2 + ((size_t)b * AS + col0 + r) * AC + oc0 : nullptr;
 #pragma unroll
   for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
@@ -310,16 +325,21 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
     }
 }
 
-// delta[b, i] = sum_c do[b, i, c] * o[b, i, c]   (the row term of the softmax gradient; C = 128)
+// delta[b, i] = sum_c do[b, i, c] * o[b, i, c]   (the row term of the softmax gradient; C = 128 or 256: 32 lanes per
+// row, one or two float4 per lane)
+template <int AC>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dout, const float* __restrict__ o,
                                                          float* __restrict__ delta, size_t rows) {
-  constexpr int AC = 128;
   const size_t row = (size_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   const int l = threadIdx.x & 31;
   if (row >= rows) return;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(dout + row * AC + l * 4);
-  const f32x4 c = *reinterpret_cast<const f32x4*>(o + row * AC + l * 4);
-  float s = a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < AC / 128; ++i) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(dout + row * AC + i * 128 + l * 4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(o + row * AC + i * 128 + l * 4);
+    s += (a[0] * c[0] + a[1] * c[1]) + (a[2] * c[2] + a[3] * c[3]);
+  }
 #pragma unroll
   for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (l == 0) delta[row] = s;
@@ -379,17 +399,17 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
   }
 }
 
-template <int MODE, int AC = 128>
+template <int MODE, int AC = 128, int OSPLIT = 1>
 int launch(const AttnArgs& a, hipStream_t stream) {
-  constexpr int smem = (MODE == 0 ? 1 : 2) * (AC / 16) * 32 * XP + (MODE == 2 ? 2 : 1) * 2 * AC * ZP + 256;
+  constexpr int smem = ((MODE == 0 || MODE == 3) ? 1 : 2) * (AC / 16) * 32 * XP + (MODE == 2 ? 2 : 1) * 2 * (AC / OSPLIT) * ZP + 256;
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<MODE, AC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<MODE, AC, OSPLIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL((attn_f16x3_kernel<MODE, AC>), dim3(AS / 128, a.B), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((attn_f16x3_kernel<MODE, AC, OSPLIT>), dim3(AS / 128, a.B, OSPLIT), dim3(256), smem, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -428,22 +448,26 @@ MULAN_API int mulan_attention_pack_f16x3(const float* x, const unsigned* xmax, v
 // delta[B,1024] = rowsum(do * o): input of mulan_attention_bwd_f16x3 (and its maxima, mulan_absmax_rows(delta, B rows))
 MULAN_API int mulan_attention_delta(const float* dout, const float* o, float* delta, int B, int S, int C,
                                     hipStream_t stream) {
-  if (S != AS || C != 128 || B <= 0) return (int)hipErrorInvalidValue;
+  if (S != AS || (C != 128 && C != 256) || B <= 0) return (int)hipErrorInvalidValue;
   const size_t rows = (size_t)B * S;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, dout, o, delta, rows);
+  if (C == 128)
+    hipLaunchKernelGGL(attn_delta_kernel<128>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, dout, o, delta, rows);
+  else
+    hipLaunchKernelGGL(attn_delta_kernel<256>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, dout, o, delta, rows);
   MULAN_CHECK_LAUNCH();
 }
 
 // Backward: dq, dk, dv from the packs of q, k, v, do (both layouts each where listed), lse of the forward pass and
-// delta.  Two launches: the query-major kernel (dq) and the key-major kernel (dk, dv); the probabilities are
-// recomputed in both.
+// delta.  C = 128: two launches, the query-major kernel (dq) and the key-major kernel (dk, dv); the probabilities are
+// recomputed in both.  C = 256: three launches -- dq and dk with the output channels split over two blocks per column
+// tile, dv alone (see the header of this file).
 MULAN_API int mulan_attention_bwd_f16x3(const void* qt, const void* qn, const void* kt, const void* kn, const void* vt,
                                         const void* dot, const void* don, const unsigned* qmax, const unsigned* kmax,
                                         const unsigned* vmax, const unsigned* domax, const unsigned* dmax,
                                         const float* lse, const float* delta, float* dq, float* dk, float* dv, int B,
                                         int S, int C, float alpha, hipStream_t stream) {
-  if (S != AS || C != 128 || B <= 0 || !qt || !qn || !kt || !kn || !vt || !dot || !don || !qmax || !kmax || !vmax ||
-      !domax || !dmax || !lse || !delta || !dq || !dk || !dv)
+  if (S != AS || (C != 128 && C != 256) || B <= 0 || B > 65535 || !qt || !qn || !kt || !kn || !vt || !dot || !don || !qmax ||
+      !kmax || !vmax || !domax || !dmax || !lse || !delta || !dq || !dk || !dv)
     return (int)hipErrorInvalidValue;
   AttnArgs a{};
   a.qt = static_cast<const unsigned char*>(qt); a.qn = static_cast<const unsigned char*>(qn);
@@ -453,6 +477,15 @@ MULAN_API int mulan_attention_bwd_f16x3(const void* qt, const void* qn, const vo
   a.qmax = qmax; a.kmax = kmax; a.vmax = vmax; a.domax = domax; a.dmax = dmax;
   a.lse = lse; a.delta = delta; a.alpha = alpha; a.B = B;
   a.out = dq;
+  if (C == 256) {
+    int e = launch<1, 256, 2>(a, stream);
+    if (e) return e;
+    a.out = dv;
+    e = launch<3, 256, 1>(a, stream);
+    if (e) return e;
+    a.out = dk;
+    return launch<4, 256, 2>(a, stream);
+  }
   int e = launch<1>(a, stream);
   if (e) return e;
   a.out = dv; a.out2 = dk;

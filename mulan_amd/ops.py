@@ -1496,19 +1496,20 @@ def bmm_tn_planes_raw(xs, xmax, dys, dymax, B, C, N):
     return out
 
 
-ATTN_FUSED = True      # fused (flash-style) attention kernels for C = 128: S and P never reach HBM
+ATTN_FUSED = True      # fused (flash-style) attention kernels, C = 128 and 256: S and P never reach HBM
 
 
 def _attn_fused_ok(q):
+    """forward and backward kernels exist for C = 128 and, since round 4, C = 256 (the ImageNet-32 width: the backward
+    pass with its output channels split over blocks, attention_f16x3.hip); blockIdx.y carries the image"""
     B, S, C = q.shape
-    return CONV_MODE == "f16x3" and ATTN_F16X3 and ATTN_FUSED and S == HW and C == 128
+    return CONV_MODE == "f16x3" and ATTN_F16X3 and ATTN_FUSED and S == HW and C in (128, 256) and B <= 65535
 
 
 def _attn_fused_fwd_only_ok(q, k, v):
-    """C = 256 (the ImageNet-32 width): only the forward kernel exists in fused form -- used wherever no gradient is
-    taken through the attention (the variational-bound evaluators, the ancestral sampler)"""
+    """kept for callers that want the bare forward kernel (no autograd node at all)"""
     B, S, C = q.shape
-    return (CONV_MODE == "f16x3" and ATTN_F16X3 and ATTN_FUSED and S == HW and C == 256 and B <= 65535 and
+    return (_attn_fused_ok(q) and
             not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)))
 
 

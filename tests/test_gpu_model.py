@@ -530,8 +530,19 @@ def test_two_rank_replayed_step_overlaps_the_allreduce_and_equals_the_eager_step
 @pytest.mark.timeout(900)
 def test_imagenet32_width_train_parity():
     """E = 256 (ldm/configs/imagenet32.py): 256 / 512-channel convolutions, GroupNorm over 512 concatenated channels,
-    two cout blocks per convolution tile, four weight-gradient tiles -- same parity bars as the CIFAR width"""
-    run_case("mulan_velocity", "vdm", True, train=True, E=256, tol=3.0)
+    two cout blocks per convolution tile, four weight-gradient tiles -- same parity bars as the CIFAR width.  The
+    attention blocks of a training step at this width run on the fused kernels (round 4): no softmax / score-matrix
+    launch, i.e. no [B, 1024, 1024] tensor, forward or backward (BASELINE configs[3])."""
+    from mulan_amd import ops
+    names = []
+    real = ops.call
+    ops.call = lambda n, *a: (names.append(n), real(n, *a))[1]
+    try:
+        run_case("mulan_velocity", "vdm", True, train=True, E=256, tol=3.0)
+    finally:
+        ops.call = real
+    assert names.count("mulan_attention_fwd_f16x3") >= 2 and names.count("mulan_attention_bwd_f16x3") >= 2, names.count
+    assert not any(n.startswith("mulan_softmax") for n in names)
 
 
 def test_grouped_film_projections_match_per_block_gemms():
