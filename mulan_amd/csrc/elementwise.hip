@@ -22,23 +22,25 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
 }
 
 // out[s][c] = sum_{r < seg} x[(s*seg + r)][c];  x is [nseg*seg, C] with row stride ld.
-// block = 4 row-lanes x 64 columns.
+// block = 4 row-lanes x 64 columns.  This scalar form serves the narrow tensors (C = 1 / 3: the bias gradients of the
+// conv_out layers), whose column sums cancel almost completely (measured: |sum| ~ 1e-5 of sum |x|): it accumulates in
+// float64, so the result carries the rounding of its inputs only, not that of 1024 sequential fp32 additions.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int seg,
                                                      int C, int ld, int accumulate) {
-  __shared__ float red[256];
+  __shared__ double red[256];
   const int col = blockIdx.y * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int s = blockIdx.x;
-  float acc = 0.f;
+  double acc = 0.0;
   if (col < C) {
     const float* base = x + (size_t)s * seg * ld + col;
-    for (int r = rl; r < seg; r += 4) acc += base[(size_t)r * ld];
+    for (int r = rl; r < seg; r += 4) acc += (double)base[(size_t)r * ld];
   }
   red[threadIdx.x] = acc;
   __syncthreads();
   if (rl == 0 && col < C) {
-    const float v = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+    const double v = (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
     float* o = out + (size_t)s * C + col;
-    *o = accumulate ? *o + v : v;
+    *o = accumulate ? (float)((double)*o + v) : (float)v;
   }
 }
 
