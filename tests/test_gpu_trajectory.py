@@ -35,7 +35,7 @@ from tests.test_gpu_model import block_names, oracle_masks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, E, STEPS, WARMUP = 4, 128, 4, 2
-ONE_ELEMENT_BAR = 2e-3
+ONE_ELEMENT_BAR = 5e-2
 
 
 def _experiment(graph, vdm_type):
@@ -186,8 +186,11 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
                 ev = rel_leaf(_leaf(got_v, p), own_v[p], 1e-13)
                 worst["grad"], worst["mom"] = max(worst["grad"], eg), max(worst["mom"], em)
                 # (a one-element leaf -- the bias of the encoder's single-channel conv_out -- is the sum of B * 1024
-                # cancelling terms; round 4: mulan_colsum accumulates the narrow tensors in float64, so the sum itself no
-                # longer adds to the error of its terms -- round 3 needed 5e-2 here)
+                # cancelling terms: its own magnitude says nothing about the size of its error.  Round 4 moved that sum to
+                # float64 accumulation (mulan_colsum, narrow tensors) and the measured error did not move (2.3e-2 before,
+                # 3.1e-2 after, another box): it is the fp32 rounding of the 4096 TERMS -- each the end of a ~40-kernel fp32
+                # chain, 1e-6 relative to the float64 oracle -- amplified by the cancellation sum |t| / |sum t| ~ 1e4, not
+                # the summation order; no bar below that amplification can hold for a correct fp32 implementation)
                 bar = 2e-3 if want_g[p].size > 16 else ONE_ELEMENT_BAR
                 if p[0] == "gamma":      # the schedule network's gradients sum sigma(gamma) / exp terms over a 18-unit range
                     bar = 1e-2           # of gamma in fp32 (measured up to 5e-3 once the parameters have moved)
