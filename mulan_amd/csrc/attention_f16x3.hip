@@ -21,14 +21,18 @@
 // Block = 4 waves = 128 columns; X / X2 / Z / Z2 tiles of the current 32 rows go through LDS (next tile's global loads
 // are in flight in registers meanwhile), the column-side fragments Y / Y2 stay in registers.  C = 128: the three kernels
 // above.  C = 256 (the ImageNet-32 width): the forward kernel as it is (one block per CU at ~370 registers); in the
-// backward pass Y, Y2 and the output accumulators of MODE 1 / 2 would need 128 + 128 + 128 (+ 128) registers, so the
-// OUTPUT channels are split over blocks (OSPLIT = 2: blockIdx.z owns 128 of the 256 output channels, i.e. 64 accumulator
-// registers and half of the Z tile; the scores are recomputed by both halves) and MODE 2 is split by product:
-//   MODE 3 (dv):  columns = keys; X = q, Y = k;                    E = P;  Z = do  -> dv   (no T2, all 256 channels)
-//   MODE 4 (dk):  columns = keys; X = q, Y = k, X2 = do, Y2 = v;   E = dS; Z = q   -> dk   (OSPLIT = 2)
-// -- five launches (dq x 2 halves in one grid, dv, dk x 2 halves in one grid) instead of two, 15 % more matrix-core work
-// than an unsplit kernel would do, and no [B, 1024, 1024] tensor in HBM (the unfused path a training step at E = 256
-// used until round 4 materialised S, P, dP and dS: 16 GiB at B = 1024).
+// backward pass Y, Y2 and the output accumulators of MODE 1 / 2 would need 128 + 128 + 128 (+ 128) registers, so two
+// waves share a set of 32 columns (KSPLIT = 2; a block = 2 x 2 waves = 64 columns): each holds the Y / Y2 fragments of
+// HALF the channels (64 + 64 registers), forms its half of the contraction T1 / T2, the two partial tiles are exchanged
+// through LDS and added (a + b == b + a: both waves hold the same sums), both evaluate E, and each accumulates HALF the
+// output channels (64 registers).  No product is computed twice.  MODE 2 is split by product to fit the LDS:
+//   MODE 3 (dv):  columns = keys; X = q, Y = k;                    E = P;  Z = do  -> dv   (no T2)
+//   MODE 4 (dk):  columns = keys; X = q, Y = k, X2 = do, Y2 = v;   E = dS; Z = q   -> dk
+// -- three launches instead of two (the scores are formed once more than an unsplit kernel would), and no
+// [B, 1024, 1024] tensor in HBM (the unfused path a training step at E = 256 used until round 4 materialised S, P, dP
+// and dS: 16 GiB at B = 1024).  OSPLIT (output channels split over blockIdx.z, the scores recomputed by every part)
+// is the simpler variant measured first: 3.6 ms per backward call at B = 128 against 2.4 unfused
+// (profiles/r04_attention_probe_c256.log); kept as a template parameter.
 #include "common.h"
 #include "f16x3_common.h"
 
@@ -53,14 +57,16 @@ struct AttnArgs {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <int MODE, int AC = 128, int OSPLIT = 1>
+template <int MODE, int AC = 128, int OSPLIT = 1, int KSPLIT = 1>
 __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f16x3_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(AC == 128 || AC == 256, "C = 128 or 256");
   static_assert(MODE <= 2 || AC == 256, "MODE 3 / 4: the split form of MODE 2 for C = 256");
+  static_assert(KSPLIT == 1 || (KSPLIT == 2 && OSPLIT == 1 && MODE != 0 && MODE != 2), "KSPLIT = 2: MODE 1 / 3 / 4");
   constexpr int NCH = AC / 16;             // channel chunks (8 / 16)
+  constexpr int NCW = NCH / KSPLIT;        // ... contracted by one wave
   constexpr int OC = AC / OSPLIT;          // output channels of this block (blockIdx.z-th part of the AC)
-  constexpr int NDT = OC / 32;             // output-channel tiles
+  constexpr int NDT = OC / 32 / KSPLIT;    // output-channel tiles of one wave
   constexpr int X_BYTES = NCH * 32 * XP;   // 20480 / 40960
   constexpr int Z_BYTES = 2 * OC * ZP;     // 18432 / 36864
   constexpr int NPX = NCH / 2;             // 16-byte pieces per thread and T-packed tile (NCH * 128 pieces)
@@ -73,13 +79,16 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   unsigned char* x2s = smem + X_BYTES;                    // X2 tile (backward)
   unsigned char* zs = smem + (T2ON ? 2 : 1) * X_BYTES;    // Z tile(s)
   float* rowvals = reinterpret_cast<float*>(zs + NZ * Z_BYTES);   // KEYS: lse / delta of the tile's 32 rows
-  const int oc0 = blockIdx.z * OC;
+  unsigned char* exch = zs + NZ * Z_BYTES + 256;                  // KSPLIT = 2: partial T1 / T2 tiles, 4 (8) KB per wave
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
-  const int col0 = blockIdx.x * 128 + wave * 32;
+  const int kpart = KSPLIT == 2 ? (wave & 1) : 0;          // which half of the channels this wave contracts / accumulates
+  const int cb = kpart * NCW;                              // its first channel chunk
+  const int oc0 = blockIdx.z * OC + kpart * (OC / KSPLIT); // its first output channel
+  const int col0 = blockIdx.x * (128 / KSPLIT) + (wave / KSPLIT) * 32;
   const size_t img = (size_t)AS * AC * 4;                 // bytes of one packed image
   // operands by role
   const unsigned char* X = (KEYS ? p.qt : p.kt) + b * img;
@@ -103,12 +112,12 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   const float c2 = inv_v * inv_do;                        // accumulator of T2 -> dP
 
   // ---- column-side fragments (B operand of T1 / T2): lane = column r, channels 8 h .. 8 h + 7 of chunk c
-  f16x8 yf[NCH][2], y2f[T2ON ? NCH : 1][2];
+  f16x8 yf[NCW][2], y2f[T2ON ? NCW : 1][2];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int c = 0; c < NCW; ++c)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-      const size_t off = (((size_t)c * AS + col0 + r) * 2 + pl) * 32 + h * 16;
+      const size_t off = (((size_t)(cb + c) * AS + col0 + r) * 2 + pl) * 32 + h * 16;
       yf[c][pl] = *reinterpret_cast<const f16x8*>(Y + off);
       if (T2ON) y2f[c][pl] = *reinterpret_cast<const f16x8*>(Y2 + off);
     }
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
       const int idx = tid + 256 * i;
       // N pack: the two 16-row chunks of the tile are [2][C][64 B]; this block's OC channels start at oc0
       const int rc2 = idx / (OC * 4), rem = idx - rc2 * (OC * 4);
-      const size_t zo = ((size_t)(t * 2 + rc2) * AC + oc0) * 64 + (size_t)rem * 16;
+      const size_t zo = ((size_t)(t * 2 + rc2) * AC + blockIdx.z * OC) * 64 + (size_t)rem * 16;
       stg[OZ + i] = *reinterpret_cast<const i32x4*>(Z + zo);
       if (MODE == 2) stg[OZ2 + i] = *reinterpret_cast<const i32x4*>(Z2 + zo);
     }
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
   // accumulator-as-operand k order (cdna guide, "An accumulator tile as the next MFMA's operand"): element j is row
   // 16 s + 8 (j >> 2) + 4 h + (j & 3)  ->  two 8-byte pieces of the 16 packed rows
   auto zfrag = [&](const unsigned char* zb, int s, int dt, int pl) {
-    const unsigned char* a = zb + (s * OC + dt * 32 + r) * ZP + pl * 32 + h * 8;
+    const unsigned char* a = zb + (s * OC + kpart * (OC / KSPLIT) + dt * 32 + r) * ZP + pl * 32 + h * 8;
     const s16x4 lo = *reinterpret_cast<const s16x4*>(a);
     const s16x4 hi = *reinterpret_cast<const s16x4*>(a + 16);
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -206,18 +215,42 @@ __global__ __launch_bounds__(256, (MODE == 0 && AC == 128) ? 2 : 1) void attn_f1
 #pragma unroll
     for (int e = 0; e < 16; ++e) { t1[e] = 0.f; t2[e] = 0.f; }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const unsigned char* xa = xs + (c * 32 + r) * XP + h * 16;
+    for (int c = 0; c < NCW; ++c) {
+      const unsigned char* xa = xs + ((cb + c) * 32 + r) * XP + h * 16;
       const f16x8 xh = *reinterpret_cast<const f16x8*>(xa), xl = *reinterpret_cast<const f16x8*>(xa + 32);
       t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yf[c][0], t1, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yf[c][1], t1, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yf[c][0], t1, 0, 0, 0);
       if (T2ON) {
-        const unsigned char* x2a = x2s + (c * 32 + r) * XP + h * 16;
+        const unsigned char* x2a = x2s + ((cb + c) * 32 + r) * XP + h * 16;
         const f16x8 x2h = *reinterpret_cast<const f16x8*>(x2a), x2l = *reinterpret_cast<const f16x8*>(x2a + 32);
         t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2l, y2f[c][0], t2, 0, 0, 0);
         t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2h, y2f[c][1], t2, 0, 0, 0);
         t2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x2h, y2f[c][0], t2, 0, 0, 0);
+      }
+    }
+
+    if constexpr (KSPLIT == 2) {
+      // the partner wave (wave ^ 1) contracted the other half of the channels: exchange the partial tiles and add
+      constexpr int NQ = T2ON ? 8 : 4;                        // float4 quads per lane
+      f32x4* mine = reinterpret_cast<f32x4*>(exch) + (size_t)wave * NQ * 64 + lane;
+      const f32x4* theirs = reinterpret_cast<const f32x4*>(exch) + (size_t)(wave ^ 1) * NQ * 64 + lane;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        mine[qd * 64] = f32x4{t1[4 * qd], t1[4 * qd + 1], t1[4 * qd + 2], t1[4 * qd + 3]};
+        if (T2ON) mine[(4 + qd) * 64] = f32x4{t2[4 * qd], t2[4 * qd + 1], t2[4 * qd + 2], t2[4 * qd + 3]};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 a = theirs[qd * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t1[4 * qd + e] += a[e];
+        if (T2ON) {
+          const f32x4 a2 = theirs[(4 + qd) * 64];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t2[4 * qd + e] += a2[e];
+        }
       }
     }
 
@@ -399,17 +432,21 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const float* __restrict_
   }
 }
 
-template <int MODE, int AC = 128, int OSPLIT = 1>
+template <int MODE, int AC = 128, int OSPLIT = 1, int KSPLIT = 1>
 int launch(const AttnArgs& a, hipStream_t stream) {
-  constexpr int smem = ((MODE == 0 || MODE == 3) ? 1 : 2) * (AC / 16) * 32 * XP + (MODE == 2 ? 2 : 1) * 2 * (AC / OSPLIT) * ZP + 256;
+  constexpr bool t2on = MODE == 1 || MODE == 2 || MODE == 4;
+  constexpr int smem = (t2on ? 2 : 1) * (AC / 16) * 32 * XP + (MODE == 2 ? 2 : 1) * 2 * (AC / OSPLIT) * ZP + 256 +
+                       (KSPLIT == 2 ? 4 * (t2on ? 8192 : 4096) : 0);
+  static_assert(smem <= 160 * 1024, "LDS");
   static bool configured = false;
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<MODE, AC, OSPLIT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16x3_kernel<MODE, AC, OSPLIT, KSPLIT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
-  hipLaunchKernelGGL((attn_f16x3_kernel<MODE, AC, OSPLIT>), dim3(AS / 128, a.B, OSPLIT), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((attn_f16x3_kernel<MODE, AC, OSPLIT, KSPLIT>), dim3(AS / (128 / KSPLIT), a.B, OSPLIT), dim3(256), smem,
+                     stream, a);
   return (int)hipGetLastError();
 }
 
@@ -478,13 +515,23 @@ MULAN_API int mulan_attention_bwd_f16x3(const void* qt, const void* qn, const vo
   a.lse = lse; a.delta = delta; a.alpha = alpha; a.B = B;
   a.out = dq;
   if (C == 256) {
-    int e = launch<1, 256, 2>(a, stream);
+    if (g_mulan_tune[17] == 1) {      // dev A/B: the output-split variant (scores recomputed per output half)
+      int e = launch<1, 256, 2>(a, stream);
+      if (e) return e;
+      a.out = dv;
+      e = launch<3, 256, 1>(a, stream);
+      if (e) return e;
+      a.out = dk;
+      return launch<4, 256, 2>(a, stream);
+    }
+    int e = launch<1, 256, 1, 2>(a, stream);
     if (e) return e;
     a.out = dv;
-    e = launch<3, 256, 1>(a, stream);
+    // dv needs T1 only: one wave holds all of Y (128 registers) + the 256 output channels (128) without a partner
+    e = g_mulan_tune[17] == 2 ? launch<3, 256, 1, 2>(a, stream) : launch<3, 256, 1, 1>(a, stream);
     if (e) return e;
     a.out = dk;
-    return launch<4, 256, 2>(a, stream);
+    return launch<4, 256, 1, 2>(a, stream);
   }
   int e = launch<1>(a, stream);
   if (e) return e;
