@@ -69,16 +69,12 @@ def parse():
 def self_launch(a):
     """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run` with the same arguments
     as a CHILD process (this parent never touches the GPU), pass its output through and exit with its code"""
-    import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun picks the rendezvous port itself (no bind / close / reuse gap on a shared box)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: launching", " ".join(cmd), file=sys.stderr, flush=True)
     r = subprocess.run(cmd, env=env)
     sys.exit(r.returncode)

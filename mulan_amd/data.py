@@ -149,7 +149,10 @@ class BatchStream:
 
     def seek(self, samples_drawn):
         """positions the infinite train stream as if `samples_drawn` samples per rank had been taken (resume from a
-        checkpoint: state.step * batch per rank); a no-op for synthetic data and one-pass streams"""
+        checkpoint: state.step * batch per rank): permutation, position and -- because they are derived from the position --
+        the cifar10_aug flips / rotations continue exactly where an uninterrupted run would be.  A no-op for synthetic
+        data (drawn from the per-rank generator: a resumed run sees other random images) and one-pass streams; the eval
+        stream is not repositioned (the reference's is not either: ldm/experiment.py:236-247 restarts it)."""
         if self.x is None or self.one_pass:
             return
         per_epoch = max(1, len(self.x) // self.world)
@@ -173,9 +176,12 @@ class BatchStream:
         cond = np.zeros(n, dtype=np.uint8)
         if self.augment:
             img = img.copy()
-            flip = self.gen.random(n) > 0.5
-            k = np.ceil(3.0 * self.gen.random(n)).astype(np.int64)
-            rot = self.gen.random(n) > 0.5
+            # the draws are a function of the stream position of this batch (epoch, pos after the take), not of how many
+            # batches this process has drawn: a run resumed with seek() sees the augmentations an uninterrupted run sees
+            aug = np.random.default_rng([self.seed, int(self.rank), 7, int(self.epoch), int(self.pos)])
+            flip = aug.random(n) > 0.5
+            k = np.ceil(3.0 * aug.random(n)).astype(np.int64)
+            rot = aug.random(n) > 0.5
             for i in range(n):
                 if flip[i]:
                     img[i] = img[i][:, ::-1]

@@ -543,6 +543,21 @@ def test_train_stream_ranks_stay_on_one_permutation_for_uneven_sizes(tmp_path):
     fresh = data.BatchStream(name, bs, train=True, device="cpu", seed=3, rank=1, world=world)
     fresh.seek((7 * 5 + 2) * 5)
     assert ident(next(fresh)) == ident(next(streams[1]))
+    # ... including the cifar10_aug flips / rotations (they came from a generator seek() did not restore);
+    # the pictures get an asymmetric mark so that every flip / rotation shows
+    imgs[:, 1, 2, 1] = 200
+    np.savez(tmp_path / "e.npz", images=imgs)
+    name2 = f"npz:{tmp_path / 'e.npz'}"
+    run = data.BatchStream(name2, bs, train=True, device="cpu", seed=3, rank=2, world=world)
+    run.augment = True
+    for _ in range(9):
+        next(run)
+    res = data.BatchStream(name2, bs, train=True, device="cpu", seed=3, rank=2, world=world)
+    res.augment = True
+    res.seek(9 * 5)
+    a, b = next(run), next(res)
+    assert torch.equal(a["images"], b["images"]) and torch.equal(a["conditioning"], b["conditioning"])
+    assert 0 < int(a["conditioning"].sum()) <= 5 or int(next(run)["conditioning"].sum()) > 0     # (augmentations do happen)
 
 
 def test_no_mfma_data_hazard_in_the_built_objects(built_lib):
