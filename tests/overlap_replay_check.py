@@ -17,11 +17,11 @@ sys.path.insert(0, ROOT)
 STEPS = 4
 
 
-def run(graph):
+def run(graph, vdm_type="mulan_epsilon"):
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
     config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
-    config.vdm_type = "mulan_epsilon"
+    config.vdm_type = vdm_type
     config.data.dataset = "synthetic"
     config.model.sm_n_layer = 2
     config.model.forward_n_layer = 1
@@ -56,14 +56,29 @@ def main():
     from mulan_amd import parallel
     rank, world, local = parallel.init_distributed()
     assert world == 2, world
-    eager, ie = run(False)
-    replay, ir = run(True)
+    bad, summary = [], []
+    for vdm_type in ("mulan_epsilon", "mulan_velocity"):
+        check(vdm_type, bad, summary)
+    ok = torch.tensor([0.0 if bad else 1.0], device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(f"OVERLAP_REPLAY_CHECK {'ok' if float(ok[0]) == 1.0 else 'FAILED'} backend={dist.get_backend()} " +
+              " | ".join(summary), flush=True)
+    for b in bad:
+        print(f"[rank {rank}] {b}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if float(ok[0]) == 1.0 else 1)
+
+
+def check(vdm_type, bad, summary):
+    eager, ie = run(False, vdm_type)
+    replay, ir = run(True, vdm_type)
     names = ("params", "ema", "mu", "nu", "reduced gradient")
-    bad = []
     for s in range(STEPS):
         for n, a, b in zip(names, eager[s][:5], replay[s][:5]):
             if not torch.equal(a, b):
-                bad.append(f"step {s} {n}: max |diff| {float((a - b).abs().max()):.3e}")
+                bad.append(f"{vdm_type} step {s} {n}: max |diff| {float((a - b).abs().max()):.3e}")
         if eager[s][5] != replay[s][5]:
             bad.append(f"step {s} train_bpd {eager[s][5]} vs {replay[s][5]}")
     # the replayed run really took the overlapped path: the step was captured, more than one bucket was marked with an
@@ -74,17 +89,8 @@ def main():
         bad.append(f"buckets marked in the capture {ir['marked']} vs issued {ir['ready_order']} of {ir['buckets']}")
     if sorted(ir["ready_order"]) != list(range(ir["buckets"])):
         bad.append(f"not every bucket was reduced: {ir['ready_order']}")
-    ok = torch.tensor([0.0 if bad else 1.0], device="cuda")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if rank == 0:
-        print(f"OVERLAP_REPLAY_CHECK {'ok' if float(ok[0]) == 1.0 else 'FAILED'} backend={dist.get_backend()} "
-              f"buckets={ir['buckets']} marked={ir['marked']} issued={ir['ready_order']} eager_order={ie['ready_order']} "
-              f"bpd={[round(s[5], 5) for s in replay]}", flush=True)
-    for b in bad:
-        print(f"[rank {rank}] {b}", flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
-    sys.exit(0 if float(ok[0]) == 1.0 else 1)
+    summary.append(f"{vdm_type}: buckets={ir['buckets']} marked={ir['marked']} issued={ir['ready_order']} "
+                   f"eager_order={ie['ready_order']} bpd={[round(s[5], 5) for s in replay]}")
 
 
 if __name__ == "__main__":

@@ -59,6 +59,18 @@ def _worker(rank, world, port, q):
         loss(ref.params, xg).backward()      # big-batch gradient on one process
         ref.collect_grads()
         ok = ok and torch.allclose(mean_grad, ref.grad, atol=1e-6)
+    # the replayed-step entry points on a reducer without device streams (CPU tensors): begin_capture / end_capture are
+    # no-ops and allreduce_captured reduces every bucket behind the whole backward pass -- the same sum
+    st.zero_grad()
+    red.paused = True
+    red.begin_capture()
+    loss(st.params, shard).backward()
+    red.end_capture()
+    st.collect_grads()
+    red.paused = False
+    ok = ok and red.capture is None
+    red.allreduce_captured()
+    ok = ok and torch.allclose(st.grad / world, ref.grad, atol=1e-6) and sorted(red.ready_order) == list(range(len(red.buckets)))
     m = parallel.allreduce_mean_scalars({"bpd": torch.tensor(float(rank + 1)), "var": 2.0 * (rank + 1)}, "cpu")
     ok = ok and abs(float(m["bpd"]) - 1.5) < 1e-6 and abs(float(m["var"]) - 3.0) < 1e-6
     # sharded evaluator reduction: per-image values split by index, (sum, count) all-reduced
