@@ -654,3 +654,30 @@ def test_load_flax_reads_bytes_it_did_not_write():
         same(got[key], want[key], key)
     same(got["opt_state"]["mu"], want["opt_state"]["mu"], "mu")
     same(got["opt_state"]["nu"], want["opt_state"]["nu"], "nu")
+
+
+def test_committed_bench_record_keeps_the_driver_contract():
+    """profiles/r04_bench_n1.json.log is the line `python bench.py` printed on an MI355X with the round-4 code: the keys
+    the driver and the judge read (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload, the `roofline` and `cpu_baseline` objects) are all there and
+    consistent with each other."""
+    import json
+    rec = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json.log")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec, k
+    assert rec["metric"] == "train images/sec" and rec["unit"] == "images/s" and rec["higher_is_better"] is True
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["vs_baseline"] is None and rec["data"] == "synthetic"
+    assert rec["dtype"] == "f32" and "workload" in rec["config"] and "model" not in rec["config"]
+    B = rec["config"]["global_batch"]
+    assert abs(rec["value"] - B / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+    roof = rec["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["traffic"] is None or roof["traffic"] > 1e8
+    cpu = rec["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cpu, k
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1
+    assert set(rec["configs"]) >= {"3", "4", "5", "sampler", "ode"}
