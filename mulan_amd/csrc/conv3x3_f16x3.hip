@@ -1428,7 +1428,7 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
   const dim3 grid(S, 3, (C / WG3_T) * (N / WG3_T));
 #define MULAN_WG_ABL(PROBE, ABLV)                                                                                       \
   {                                                                                                                     \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<3, false, PROBE, ABLV>),        \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_planes_kernel<3, false, PROBE, ABLV>),  \
                         hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);                                     \
     hipLaunchKernelGGL((conv3x3_wgrad_f16x3_planes_kernel<3, false, PROBE, ABLV>), grid, dim3(256), WG3_SMEM + 64,      \
                        stream, a);                                                                                      \
