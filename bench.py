@@ -63,6 +63,9 @@ def parse():
                     help="time BASELINE configs #3, #4, #5 after the headline (default: on at N = 1)")
     ap.add_argument("--no-also-configs", dest="also_configs", action="store_false")
     ap.add_argument("--also-steps", type=int, default=6, help="timed steps per extra training configuration")
+    ap.add_argument("--configs-small", action="store_true",
+                    help="test-sized extra configurations (global batch 32 / 8 per GPU, T = 64, tiny sampler / ODE batches): the "
+                         "control flow of \"configs\" in seconds; the numbers it prints are not the configurations' numbers")
     return ap.parse_args()
 
 
@@ -580,16 +583,19 @@ def main():
         extra = {}
         cif = os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")
         inet = os.path.join(ROOT, "ldm", "configs", "imagenet32.py")
-        if 512 % world != 0:
+        g3, b4, T5, n5, bs, bo = (32, 8, 64, 1, 8, 4) if a.configs_small else (512, 128, 1000, 2, 64, 64)
+        if a.configs_small:
+            b3, l3 = g3 // world, f"(--configs-small) MuLAN-velocity CIFAR-10, global batch {g3}"
+        elif 512 % world != 0:
             b3, l3 = 64, "BASELINE configs[2]: MuLAN-velocity CIFAR-10 at its 8-GPU per-GPU size of 64 images"
         else:
             b3, l3 = 512 // world, (f"BASELINE configs[2]: MuLAN-velocity CIFAR-10, GLOBAL batch 512 (strong scaling: "
                                     f"{512 // world} images per GPU)")
         table = {"3": (cif, "mulan_velocity", False, b3, l3),
-                 "4": (inet, "mulan_velocity", True, 128, "BASELINE configs[3]: MuLAN-velocity ImageNet-32 (E=256), "
-                                                          f"velocity_from_epsilon, 128 per GPU = global batch {128 * world} "
-                                                          "(the configuration's 1024 at 8 GPUs)")}
-        if world == 1:
+                 "4": (inet, "mulan_velocity", True, b4, "BASELINE configs[3]: MuLAN-velocity ImageNet-32 (E=256), "
+                                                         f"velocity_from_epsilon, {b4} per GPU = global batch {b4 * world} "
+                                                         "(the configuration's 1024 at 8 GPUs x 128)")}
+        if world == 1 and not a.configs_small:
             table["3_at_64_per_gpu"] = (cif, "mulan_velocity", False, 64, "BASELINE configs[2] at its 8-GPU per-GPU size: "
                                         "MuLAN-velocity CIFAR-10, 64 images per GPU (512 / 8)")
         for key, (cfgp, vt, vfe, bsz, label) in table.items():
@@ -605,13 +611,13 @@ def main():
                                                                  "launches_per_step", "measured")},
                           "conv_kernel_as_run_frac": (rr.get("as_run") or {}).get("frac"),
                           "last_train_bpd": round(r["last_bpd"], 4)}
-        extra["5"] = dense_eval_workload(2, 1000, rank, world)
+        extra["5"] = dense_eval_workload(n5, T5, rank, world)
         extra["5"]["workload"] = "BASELINE configs[4]: " + extra["5"]["workload"]
         if world > 1:
             dist.barrier()
         if rank == 0:
-            extra["sampler"] = sampler_workload(64, 1000, 20)
-            extra["ode"] = ode_workload(64)
+            extra["sampler"] = sampler_workload(bs, 1000, 3 if a.configs_small else 20)
+            extra["ode"] = ode_workload(bo)
     if rank != 0:
         if world > 1:
             dist.barrier()

@@ -456,9 +456,10 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
     the backward pass (the default from 96 images per rank at E = 128).  launcher = "self": plain `python bench.py --gpus 2` -- the bench starts
     torch.distributed.run itself as a child process and relays rank 0's line (the reference needs no launcher either,
     ldm/experiment.py:89-95); "torchrun": the driver's command line.  configs: the default at every N -- the line also
-    carries BASELINE configs[2] at GLOBAL batch 512 (strong scaling: 256 images per rank here), configs[3] at 128 per rank,
-    configs[4] through the sharded evaluator (eval_bpd_dense_sampling, one (sum, count) all-reduce) and the sampler / ODE
-    entries; False: --no-also-configs."""
+    carries BASELINE configs[2] at a GLOBAL batch (strong scaling), configs[3] per rank, configs[4] through the sharded
+    evaluator (eval_bpd_dense_sampling, one (sum, count) all-reduce) and the sampler / ODE entries -- here at the test
+    sizes of --configs-small (the full sizes run in every `python bench.py`: profiles/r04_bench_n1.json.log); False:
+    --no-also-configs."""
     import json
     import os
     import socket
@@ -475,7 +476,7 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
     if graph:
         env["MULAN_HIP_GRAPH"] = graph
     args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8",
-            "--also-steps", "2"] + ([] if configs else ["--no-also-configs"])
+            "--also-steps", "2"] + (["--configs-small"] if configs else ["--no-also-configs"])
     if launcher == "self":
         cmd = [sys.executable] + args
     else:
@@ -490,7 +491,7 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
     if configs:
         c = out["configs"]
         assert set(c) == {"3", "4", "5", "sampler", "ode"}
-        assert c["3"]["global_batch"] == 512 and c["4"]["global_batch"] == 256 and c["3"]["value"] > 0 and c["4"]["value"] > 0
+        assert c["3"]["global_batch"] == 32 and c["4"]["global_batch"] == 16 and c["3"]["value"] > 0 and c["4"]["value"] > 0
         assert "sharded over 2 rank(s)" in c["5"]["workload"] and c["5"]["value"] > 0 and math.isfinite(c["5"]["bpd_random_init"])
         assert c["sampler"]["finite"] and c["sampler"]["value"] > 0 and c["ode"]["finite"] and c["ode"]["nfev"] >= 8
     else:
