@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Dev probe (round 4): can work OUTSIDE a replayed HIP graph wait for a point INSIDE it?  The multi-rank train step wants
 the gradient all-reduce of bucket k (a collective, outside the graph) to start as soon as the captured backward pass has
-produced that bucket, while the rest of the graph still runs.  mulan_event_record_external (hipEventRecordWithFlags(..., hipEventRecordExternal);
-torch.cuda.Event(external=True) raises "External events are disallowed in rocm" in torch 2.10) on the capturing stream is
-captured as an event-record NODE instead of an internal fork/join edge.  Checked here:
+produced that bucket, while the rest of the graph still runs.  mulan_event_record_external on the capturing stream plants an event-record NODE in the
+graph being captured (hipStreamGetCaptureInfo_v2 + hipGraphAddEventRecordNode; torch.cuda.Event(external=True) raises
+"External events are disallowed in rocm" in torch 2.10, and hipEventRecordWithFlags(..., hipEventRecordExternal) returns
+hipErrorInvalidValue in the runtime it ships) instead of an internal fork/join edge.  Checked here:
   (1) a side stream that waits for the event after graph.replay() sees the value written BEFORE the node (every replay:
       the value changes from replay to replay, so a stale wait shows), and
   (2) it gets going long before the graph ends (timestamps).
