@@ -163,7 +163,10 @@ class GradReducer:
         self.side.wait_stream(torch.cuda.current_stream())
         wg = ops.side_stream()
         if wg is not None:
-            self.side.wait_stream(wg)
+            with torch.cuda.stream(wg):
+                forked = torch.cuda.is_current_stream_capturing()
+            if forked:      # (not yet part of this capture: nothing of this step is queued there, and a capturing stream
+                self.side.wait_stream(wg)    # must not wait for an event recorded outside its capture)
         lib.check(L.mulan_event_record_external(ev, self.side.cuda_stream), "mulan_event_record_external")
         self.launched[bi] = True
         self.capture["order"].append(bi)
