@@ -43,14 +43,27 @@ int mulan_set_debug_buffer(void* dev_ptr);
  * all-reduce of gradient bucket k is issued outside it (torch.distributed): it may start as soon as the captured backward
  * pass has produced that bucket.  mulan_event_record_external on a capturing stream becomes an event-record NODE
  * (hipGraphAddEventRecordNode on the capture's own graph, behind everything the stream has captured so far) instead of an
- * internal fork / join edge; after hipGraphLaunch the collective's stream waits for it with mulan_stream_wait_event.
+ * internal fork / join edge; `chain` (optional): a stream of the same capture whose next captured work shall depend on the
+ * node, which makes the node a link of that branch instead of a leaf the executor may run late; after hipGraphLaunch the
+ * collective's stream waits for it with mulan_stream_wait_event.
  * Outside a capture the pair is an ordinary record / wait.  (torch.cuda.Event(external=True) is refused on ROCm builds
  * of torch 2.10 and hipEventRecordWithFlags(hipEventRecordExternal) returns hipErrorInvalidValue in the runtime it ships,
  * hence these four; tools/ext_event_probe.py, profiles/r04_ext_event_probe.log.) */
 int mulan_event_create(void** event);
 int mulan_event_destroy(void* event);
-int mulan_event_record_external(void* event, mulan_stream_t stream);
+int mulan_event_record_external(void* event, mulan_stream_t stream, mulan_stream_t chain /* nullable */);
 int mulan_stream_wait_event(mulan_stream_t stream, void* event);
+/* The hand-off the replayed multi-rank train step uses (round 4; the event-record nodes above fire late in a multi-branch
+ * graph on this runtime): a word of signal memory (hipMallocSignalMemory) set by a one-thread KERNEL NODE at its place in
+ * the captured backward pass -- mulan_signal_set stores value_dev[0], a step counter the caller writes before each
+ * replay -- and waited for by the collective's stream with hipStreamWaitValue32 (*sig >= value; the command processor
+ * polls, no CU is held).  mulan_signal_create returns hipErrorNotSupported where the device cannot wait on values. */
+int mulan_signal_create(void** sig);
+int mulan_signal_destroy(void* sig);
+int mulan_signal_set(void* sig, const unsigned* value_dev, mulan_stream_t stream);
+int mulan_stream_wait_signal(mulan_stream_t stream, void* sig, unsigned value);
+/* diagnostic, synchronous: out2[0] = the value last stored, out2[1] = the 10 ns clock stamp of that store */
+int mulan_signal_read(void* sig, unsigned* out2);
 
 /* ---- 3x3 SAME convolution, NHWC, HWIO weights [3,3,C,N] --------------------------------------
  * flax nn.Conv(kernel_size=(3,3)) in ResnetBlock conv1/conv2 (ldm/model_vdm.py:633-634,645-650;

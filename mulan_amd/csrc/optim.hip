@@ -202,13 +202,18 @@ MULAN_API int mulan_event_create(void** event) {
 
 MULAN_API int mulan_event_destroy(void* event) { return (int)hipEventDestroy(static_cast<hipEvent_t>(event)); }
 
-// On a capturing stream: an event-record NODE of the graph being captured, depending on everything the stream has
+// On a capturing stream: an event-record NODE of the graph being captured, depending on everything `stream` has
 // captured so far (every replay records the event when that node runs; work outside the graph waits for it with
 // mulan_stream_wait_event after the launch).  Added through the capture's own graph handle (hipStreamGetCaptureInfo_v2 +
 // hipGraphAddEventRecordNode): hipEventRecordWithFlags(..., hipEventRecordExternal) returns hipErrorInvalidValue in the
-// HIP runtime torch 2.10+rocm7.0 ships.  The node is a leaf: nothing captured later depends on it.  On a stream that is
-// not capturing: a plain hipEventRecord.
-MULAN_API int mulan_event_record_external(void* event, hipStream_t stream) {
+// HIP runtime torch 2.10+rocm7.0 ships.
+// `chain` (optional, a stream of the same capture): the node also becomes a dependency of whatever `chain` captures next
+// (hipStreamUpdateCaptureDependencies, add).  A leaf node is placed by HIP's graph executor wherever its scheduler likes --
+// measured: five such leaves planted along the backward pass all fired together, when the main branch had drained, 4.7 ms
+// before the end of a 78 ms graph -- whereas a node that is a link of a branch's own chain runs at its place in that
+// branch.  The caller names the branch that reaches the point LAST (the weight-gradient stream), so nothing waits for the
+// node that would not have waited anyway.  On a stream that is not capturing: a plain hipEventRecord.
+MULAN_API int mulan_event_record_external(void* event, hipStream_t stream, hipStream_t chain) {
   hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
   unsigned long long id = 0;
   hipGraph_t graph = nullptr;
@@ -218,7 +223,59 @@ MULAN_API int mulan_event_record_external(void* event, hipStream_t stream) {
   if (e != hipSuccess) return (int)e;
   if (status != hipStreamCaptureStatusActive) return (int)hipEventRecord(static_cast<hipEvent_t>(event), stream);
   hipGraphNode_t node;
-  return (int)hipGraphAddEventRecordNode(&node, graph, deps, ndeps, static_cast<hipEvent_t>(event));
+  e = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, static_cast<hipEvent_t>(event));
+  if (e != hipSuccess || !chain) return (int)e;
+  hipStreamCaptureStatus cstatus = hipStreamCaptureStatusNone;
+  e = hipStreamIsCapturing(chain, &cstatus);
+  if (e != hipSuccess || cstatus != hipStreamCaptureStatusActive) return (int)e;
+  return (int)hipStreamUpdateCaptureDependencies(chain, &node, 1, hipStreamAddCaptureDependencies);
+}
+
+// ---- signals: a word of signal memory that a KERNEL NODE of a captured graph sets and a stream outside the graph waits
+// for (hipStreamWaitValue32: the command processor polls the word, no CU is held).  Event-record nodes turned out not to
+// be a usable hand-off from a multi-branch graph on this runtime: planted along the backward pass of the train step they
+// all fire together near the end of the graph, whichever branch they are chained into (tools/overlap_timing_probe.py);
+// a kernel node runs at its place in its branch like every other kernel of the step.
+__global__ void signal_set_kernel(unsigned* sig, const unsigned* __restrict__ value) {
+  // everything this branch wrote before is visible device-wide at the kernel boundary in front of this launch; the word
+  // itself is written through to memory for the command processor
+  sig[1] = (unsigned)__builtin_amdgcn_s_memrealtime();     // (dev: when it ran, 10 ns ticks; read by tools/overlap_timing_probe.py)
+  __hip_atomic_store(sig, value[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+MULAN_API int mulan_signal_create(void** sig) {
+  if (!sig) return (int)hipErrorInvalidValue;
+  int dev = 0, ok = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev);
+  if (e != hipSuccess) return (int)e;
+  if (!ok) return (int)hipErrorNotSupported;
+  void* p = nullptr;
+  e = hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemset(p, 0, 8);
+  *sig = e == hipSuccess ? p : nullptr;
+  return (int)e;
+}
+
+MULAN_API int mulan_signal_destroy(void* sig) { return (int)hipFree(sig); }
+
+// sig <- value_dev[0] by a one-thread kernel on `stream` (inside a capture: a kernel node); value_dev: device memory the
+// caller writes before every replay (a step counter), so that a replayed graph signals a fresh value each time
+MULAN_API int mulan_signal_set(void* sig, const unsigned* value_dev, hipStream_t stream) {
+  if (!sig || !value_dev) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(signal_set_kernel, dim3(1), dim3(1), 0, stream, static_cast<unsigned*>(sig), value_dev);
+  MULAN_CHECK_LAUNCH();
+}
+
+// (diagnostic, synchronous) the two words of a signal: [0] the last value stored, [1] the 10 ns clock stamp of that store
+MULAN_API int mulan_signal_read(void* sig, unsigned* out2) {
+  return (int)hipMemcpy(out2, sig, 8, hipMemcpyDeviceToHost);
+}
+
+// everything enqueued on `stream` after this call waits until *sig >= value
+MULAN_API int mulan_stream_wait_signal(hipStream_t stream, void* sig, unsigned value) {
+  return (int)hipStreamWaitValue32(stream, sig, value, hipStreamWaitValueGte, 0xffffffffu);
 }
 
 MULAN_API int mulan_stream_wait_event(hipStream_t stream, void* event) {

@@ -96,9 +96,10 @@ class GraphedStep:
             state.zero_grad()
             state.drop_graph_refs()                          # no autograd node of the eager stream may survive
             torch.cuda.synchronize()
-            # several ranks: the hooks that launch a bucket's all-reduce in the eager step plant an event-record node per
-            # bucket instead (parallel.GradReducer._mark); after the replay the collectives wait for those nodes, i.e.
-            # they run under the rest of the replayed backward pass (MULAN_GRAPH_OVERLAP=0: behind the whole graph)
+            # several ranks: the hooks that launch a bucket's all-reduce in the eager step plant a signal (a one-thread
+            # kernel node) per bucket instead (parallel.GradReducer._mark); after the replay the collectives wait for
+            # those signals, i.e. they run under the rest of the replayed backward pass (MULAN_GRAPH_OVERLAP=0: behind
+            # the whole graph)
             if GRAPH_OVERLAP:
                 exp.reducer.begin_capture()
             with torch.cuda.graph(self.graph):
@@ -121,6 +122,12 @@ class GraphedStep:
                 self.metrics = metrics
         finally:
             exp.reducer.paused = False
+        if not self.whole and GRAPH_OVERLAP:
+            # several ranks: make sure the collective stream is one on which the signals really release the
+            # collectives early (parallel.GradReducer.calibrate_stream: a few trial replays, once per capture)
+            leads = exp.reducer.calibrate_stream(self.graph.replay)
+            if leads is not None:
+                log.info("collective stream released %s ms before the end of the replayed graph (trial replays)", leads)
 
     def matches(self, batch):
         from . import ops
@@ -161,6 +168,8 @@ class GraphedStep:
         exp = self.exp
         self.copied.synchronize()      # the pinned staging buffers are rewritten below: the last copies must be done
         self._fill(base_rng, state, batch)
+        if not self.whole:
+            exp.reducer.before_replay()
         self.graph.replay()
         if self.whole:
             state.step += 1
@@ -215,7 +224,7 @@ class Experiment(abc.ABC):
         self._profile = None                 # profiling.Profile while config.training.profile is set (train_and_evaluate)
         # the lax.scan of the reference (ldm/experiment.py:89-91: `substeps` train steps per host dispatch) becomes a
         # HIP-graph replay per step (GraphedStep), on one rank and on several.  With several ranks the collectives stay
-        # outside the graph, but every bucket's all-reduce waits only for the event node the capture planted behind that
+        # outside the graph, but every bucket's all-reduce waits only for the signal the capture planted behind that
         # bucket (parallel.GradReducer.begin_capture / allreduce_captured), so it runs under the rest of the replayed
         # backward pass like the eager step's does -- and the host, which needs ~54 ms to issue the ~1100 launches of an
         # eager step whatever the batch, is out of the picture at every batch size (rounds 1-3 chose between the replay

@@ -116,8 +116,13 @@ SIGNATURES = {
     "mulan_set_debug_buffer": [P],
     "mulan_event_create": [P],
     "mulan_event_destroy": [P],
-    "mulan_event_record_external": [P, P],
+    "mulan_event_record_external": [P, P, P],
     "mulan_stream_wait_event": [P, P],
+    "mulan_signal_create": [P],
+    "mulan_signal_destroy": [P],
+    "mulan_signal_set": [P, P, P],
+    "mulan_stream_wait_signal": [P, P, ctypes.c_uint],
+    "mulan_signal_read": [P, P],
 }
 _RESTYPES = {"mulan_rk_workspace_bytes": c_size_t, "mulan_global_norm_clip_workspace": c_size_t, "mulan_conv3x3_wgrad_workspace": c_size_t, "mulan_conv3x3_pack_bf16x6_bytes": c_size_t, "mulan_conv3x3_wgrad_bf16x6_workspace": c_size_t,
              "mulan_conv3x3_pack_f16x3_bytes": c_size_t, "mulan_conv3x3_planes_bytes": c_size_t, "mulan_linear_pack_f16x3_bytes": c_size_t,

@@ -42,6 +42,11 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+# the hand-off between the replayed graph and the collectives: signal words set by kernel nodes (default) or, with
+# MULAN_OVERLAP_SIGNAL=0, the event-record nodes alone (which fire late in a multi-branch graph on this runtime)
+USE_SIGNALS = os.environ.get("MULAN_OVERLAP_SIGNAL", "1") == "1"
+
+
 class GradReducer:
     """Bucketed, backward-overlapped sum all-reduce of a flat gradient buffer.
 
@@ -82,6 +87,7 @@ class GradReducer:
         if self.buckets:
             self.buckets[0][0] = 0
         self.paused = False         # True while a train step is being captured into a HIP graph: hooks do not launch
+        self.tick, self.tick_dev = 0, None   # replay counter: the value the graph's signal kernels store (before_replay)
         self.capture = None         # while / after a capture: {"order": [bucket, ...], "events": {bucket: handle}}
         self.pending = [0] * len(self.buckets)
         self.ready_order = []       # bucket indices in the order they were launched in the last backward
@@ -122,6 +128,7 @@ class GradReducer:
         if self.paused:
             if self.capture is not None and self.capture["open"]:
                 bi = self.leaf_bucket[id(t)]
+                self.capture["hooks"] += 1
                 self.pending[bi] -= 1
                 if self.pending[bi] == 0 and not self.launched[bi]:
                     self._mark(bi)
@@ -134,10 +141,12 @@ class GradReducer:
     # ---- a replayed (HIP-graph) backward pass with the all-reduce still overlapped ------------------------------------
     # The collectives stay outside the graph (torch.distributed), but each bucket's all-reduce may start as soon as the
     # REPLAYED backward pass has produced the bucket: while the step is captured, the hook that would launch bucket k
-    # plants an event-record node behind everything bucket k depends on (mulan_event_record_external: the capturing
-    # stream's position and the weight-gradient stream's); after graph.replay() the collective stream waits for node k
-    # and all-reduces bucket k under the rest of the graph (the reference gets the same overlap from XLA inside
-    # pmap(scan(train_step)), ldm/experiment.py:89-95,341).
+    # plants a one-thread kernel node behind the bucket's last weight gradient that stores the replay's tick into the
+    # bucket's word of signal memory (mulan_signal_set); after graph.replay() the collective stream waits for that word
+    # (hipStreamWaitValue32) and all-reduces bucket k under the rest of the graph (the reference gets the same overlap
+    # from XLA inside pmap(scan(train_step)), ldm/experiment.py:89-95,341).  An event-record node is planted as well
+    # (mulan_event_record_external): the fallback where the device cannot wait on values -- on this runtime such nodes
+    # all fire together near the end of a multi-branch graph (tools/overlap_timing_probe.py).
     def begin_capture(self):
         """call before capturing a train step (with paused = True)"""
         if not (self.enabled and self.side is not None):
@@ -152,7 +161,21 @@ class GradReducer:
                 h = ctypes.c_void_p()
                 lib.check(L.mulan_event_create(ctypes.byref(h)), "mulan_event_create")
                 events[bi] = h.value
-        self.capture = {"order": [], "events": events, "open": True}
+        signals = self.capture["signals"] if self.capture else {}
+        if USE_SIGNALS and signals is not None:
+            for bi in range(len(self.buckets)):
+                if bi not in signals:
+                    h = ctypes.c_void_p()
+                    rc = L.mulan_signal_create(ctypes.byref(h))
+                    if rc != 0:                      # (no stream wait-value on this device: the event nodes remain)
+                        signals = None
+                        break
+                    signals[bi] = h.value
+        if not USE_SIGNALS:
+            signals = None
+        if self.tick_dev is None:
+            self.tick_dev = torch.zeros(1, dtype=torch.int32, device=self.flat.device)
+        self.capture = {"order": [], "events": events, "signals": signals, "open": True, "hooks": 0, "hooks_at_mark": []}
 
     def _mark(self, bi):
         from . import lib, ops
@@ -162,14 +185,34 @@ class GradReducer:
         # position and the weight-gradient stream's (the bucket's last weight gradient may still be queued there)
         self.side.wait_stream(torch.cuda.current_stream())
         wg = ops.side_stream()
+        chain = None
         if wg is not None:
             with torch.cuda.stream(wg):
                 forked = torch.cuda.is_current_stream_capturing()
             if forked:      # (not yet part of this capture: nothing of this step is queued there, and a capturing stream
                 self.side.wait_stream(wg)    # must not wait for an event recorded outside its capture)
-        lib.check(L.mulan_event_record_external(ev, self.side.cuda_stream), "mulan_event_record_external")
+                chain = wg.cuda_stream
+        # the node becomes a link of the weight-gradient branch (the branch that reaches this point last: the main chain
+        # runs ahead of it), so it fires at its place in the backward pass; as a leaf HIP's executor ran it when the main
+        # branch had drained (all buckets but the last released together 4.7 ms before the end of the graph)
+        if os.environ.get("MULAN_EVENT_NODE_CHAIN", "1") != "1":
+            chain = None
+        lib.check(L.mulan_event_record_external(ev, self.side.cuda_stream, chain), "mulan_event_record_external")
+        sig = self.capture["signals"]
+        if sig is not None:
+            # the hand-off that works (see allreduce_captured): a one-thread kernel node that stores this replay's tick
+            # into the bucket's signal word, in the weight-gradient branch behind the bucket's last weight gradient (that
+            # branch runs behind the main chain, whose position it joins here like every weight-gradient launch does) --
+            # or in the main chain while no weight gradient has been launched yet
+            if chain is not None:
+                wg.wait_stream(torch.cuda.current_stream())
+                lib.check(L.mulan_signal_set(sig[bi], self.tick_dev.data_ptr(), wg.cuda_stream), "mulan_signal_set")
+            else:
+                lib.check(L.mulan_signal_set(sig[bi], self.tick_dev.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                          "mulan_signal_set")
         self.launched[bi] = True
         self.capture["order"].append(bi)
+        self.capture["hooks_at_mark"].append(self.capture["hooks"])
 
     def end_capture(self):
         """call inside the capture, after the backward pass: the collective stream rejoins the capturing stream"""
@@ -177,11 +220,97 @@ class GradReducer:
             self.capture["open"] = False
             if self.capture["order"]:
                 torch.cuda.current_stream().wait_stream(self.side)
+                from . import ops
+                wg = ops.side_stream()               # the signal kernels sit behind the last weight gradient there
+                if wg is not None and self.capture.get("signals") is not None:
+                    with torch.cuda.stream(wg):
+                        forked = torch.cuda.is_current_stream_capturing()
+                    if forked:
+                        torch.cuda.current_stream().wait_stream(wg)
+
+    def before_replay(self):
+        """call right before graph.replay(): the tick the replayed signal kernels will store (stream-ordered parameter)"""
+        if self.capture is not None and self.capture.get("signals") is not None and self.tick_dev is not None:
+            self.tick += 1
+            self.tick_dev.fill_(self.tick)
+
+    def _wait_bucket(self, stream, bi):
+        """`stream` waits until bucket bi of the replay in flight is complete"""
+        from . import lib
+        L = lib.load()
+        sig = self.capture.get("signals")
+        if sig is not None:
+            lib.check(L.mulan_stream_wait_signal(stream.cuda_stream, sig[bi], self.tick), "mulan_stream_wait_signal")
+        else:
+            lib.check(L.mulan_stream_wait_event(stream.cuda_stream, self.capture["events"][bi]), "mulan_stream_wait_event")
+
+    def calibrate_stream(self, replay, tries=5):
+        """Pick a collective stream on which the overlap really happens.  HIP multiplexes the streams of a process (the
+        graph's internal branch streams included) onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default; raising it
+        slows the two-stream train step by a third, measured), and work on one queue runs in FIFO order whatever its
+        dependencies say: on an unlucky queue the collective that waits for a point INSIDE the graph sits behind the
+        rest of the graph (tools/overlap_timing_probe.py: the first of three otherwise identical runs lost the overlap,
+        85.0 against 80.0 ms per step).  The mapping cannot be queried, so it is measured: one trial replay per
+        candidate stream; the candidate waits for the first marked bucket and stamps a timing event, and the candidate
+        released earliest before the graph's end is kept.  The trial
+        replays run the captured forward / backward kernels only (the optimizer is outside a multi-rank graph): the
+        gradient buffer they fill is rewritten by the next step."""
+        if not (self.enabled and self.side is not None and self.capture and self.capture["order"]):
+            return None
+        if os.environ.get("MULAN_COMM_STREAM_PROBE", "1") != "1":
+            return None
+        from . import lib
+        L = lib.load()
+        first = self.capture["order"][0]
+        main = torch.cuda.current_stream()
+        best, best_lead, leads = None, -1.0, []
+        cand = self.side
+        for _ in range(tries):
+            t_c, t_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.before_replay()
+            replay()
+            t_end.record(main)
+            self._wait_bucket(cand, first)
+            t_c.record(cand)
+            main.synchronize()
+            cand.synchronize()
+            lead = t_c.elapsed_time(t_end)           # ms between the candidate's release and the end of the graph
+            leads.append(round(lead, 2))
+            if lead > best_lead:
+                best, best_lead = cand, lead
+            cand = torch.cuda.Stream()               # (every candidate is tried: a stream can be partly blocked too)
+        self.side = best
+        self.calibration = leads
+        # for the record: when each marked bucket's node fires, in ms before the end of the graph (one more trial replay)
+        stamps = []
+        t_end = torch.cuda.Event(enable_timing=True)
+        self.before_replay()
+        replay()
+        t_end.record(main)
+        for bi in self.capture["order"]:
+            self._wait_bucket(best, bi)
+            t = torch.cuda.Event(enable_timing=True)
+            t.record(best)
+            stamps.append(t)
+        main.synchronize()
+        best.synchronize()
+        self.bucket_leads = [round(t.elapsed_time(t_end), 2) for t in stamps]
+        sig = self.capture.get("signals")
+        if sig is not None:      # when the signal kernels themselves ran (their own clock stamps): ms before the last one
+            import ctypes
+            ticks = []
+            for bi in self.capture["order"]:
+                buf = (ctypes.c_uint32 * 2)()
+                lib.check(L.mulan_signal_read(sig[bi], buf), "mulan_signal_read")
+                ticks.append(int(buf[1]))
+            last = ticks[-1]
+            self.signal_leads = [round(((last - t) & 0xffffffff) * 1e-5, 2) for t in ticks]      # 10 ns ticks -> ms
+        return leads
 
     def allreduce_captured(self):
-        """after graph.replay(): every bucket that was marked in the capture is all-reduced behind its event node (i.e.
-        while the rest of the graph still runs), whatever was not marked behind the whole graph; the current stream then
-        waits for all of them"""
+        """after graph.replay(): every bucket that was marked in the capture is all-reduced behind its signal (i.e. while
+        the rest of the graph still runs), whatever was not marked behind the whole graph; the current stream then waits
+        for all of them"""
         if not self.enabled:
             return
         marked = self.capture["order"] if (self.capture is not None and self.side is not None) else []
@@ -192,7 +321,7 @@ class GradReducer:
         self.prepare()
         for bi in marked:
             lo, hi, _ = self.buckets[bi]
-            lib.check(L.mulan_stream_wait_event(self.side.cuda_stream, self.capture["events"][bi]), "mulan_stream_wait_event")
+            self._wait_bucket(self.side, bi)
             self.launched[bi] = True
             self.ready_order.append(bi)
             with torch.cuda.stream(self.side):

@@ -44,7 +44,7 @@ def main():
         with torch.cuda.graph(g, stream=main_s):
             chain(20)                  # ~ 1 ms in front
             x.add_(1.0)
-            rc = lib.mulan_event_record_external(ev, main_s.cuda_stream)            # an event-record node
+            rc = lib.mulan_event_record_external(ev, main_s.cuda_stream, None)            # an event-record node
             print("mulan_event_record_external inside the capture ->", rc, flush=True)
             out = chain(600)           # the long tail (~ 20 ms) the side stream should NOT wait for
     torch.cuda.synchronize()
