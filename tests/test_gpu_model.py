@@ -501,12 +501,15 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_replayed_step_overlaps_the_allreduce_and_equals_the_eager_step():
+@pytest.mark.parametrize("handoff", ["signal", "event"])
+def test_two_rank_replayed_step_overlaps_the_allreduce_and_equals_the_eager_step(handoff):
     """replay AND overlap.  Two ranks (gloo over the device tensors of the one GPU here; RCCL
     where two GPUs are visible): the train step replayed as a HIP graph, each gradient bucket all-reduced outside the
-    graph behind the event node the capture planted after that bucket (tests/overlap_replay_check.py), equals the eager
-    overlapped step bit for bit over four optimizer steps -- parameters, EMA, Adam moments, reduced gradient, logged
-    bits/dim -- and the buckets are issued in the order they were marked."""
+    graph behind the signal word a kernel node of the graph sets after that bucket (handoff = "signal": mulan_signal_set /
+    hipStreamWaitValue32, the shipped form) or behind the event-record node planted there (handoff = "event":
+    MULAN_OVERLAP_SIGNAL=0, the fallback), equals the eager overlapped step bit for bit over four optimizer steps --
+    parameters, EMA, Adam moments, reduced gradient, logged bits/dim -- for the epsilon and the velocity model, and the
+    buckets are issued in the order they were marked (tests/overlap_replay_check.py)."""
     import os
     import socket
     import subprocess
@@ -516,7 +519,7 @@ def test_two_rank_replayed_step_overlaps_the_allreduce_and_equals_the_eager_step
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = {**os.environ, "MULAN_BUCKET_MB": "16"}
+    env = {**os.environ, "MULAN_BUCKET_MB": "16", "MULAN_OVERLAP_SIGNAL": "1" if handoff == "signal" else "0"}
     if torch.cuda.device_count() < 2:
         env.update({"MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"})
     for k in ("MULAN_HIP_GRAPH", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MULAN_GRAPH_OVERLAP"):
