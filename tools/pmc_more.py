@@ -19,8 +19,8 @@ B = 128
 # (kernel substring, label, launches, algorithmic bytes per launch, MFMA 32x32x16 instructions per launch)
 PX = B * 1024
 GROUPS = [
-    ("conv3x3_wgrad_f16x3_planes_kernel<3>", "wgrad_128_128", 6, PX * 128 * 4 * 2, 3.0 * PX * 9 * 128 * 128 / (32 * 32 * 16)),
-    ("conv3x3_wgrad_f16x3_planes_kernel<3>", "wgrad_256_128", 5, PX * (256 + 128) * 4, 3.0 * PX * 9 * 256 * 128 / (32 * 32 * 16)),
+    ("conv3x3_wgrad_f16x3_planes_kernel<3,", "wgrad_128_128", 6, PX * 128 * 4 * 2, 3.0 * PX * 9 * 128 * 128 / (32 * 32 * 16)),
+    ("conv3x3_wgrad_f16x3_planes_kernel<3,", "wgrad_256_128", 5, PX * (256 + 128) * 4, 3.0 * PX * 9 * 256 * 128 / (32 * 32 * 16)),
     ("gn_fwd_kernel", "groupnorm_fwd_128_dropout", 6, PX * 128 * 4 * 2, 0),
     ("gn_fwd_kernel", "groupnorm_fwd_256_concat", 5, PX * 256 * 4 * 2, 0),
     ("gn_bwd_kernel_1pass", "groupnorm_bwd_128_dropout", 6, PX * 128 * 4 * 3, 0),
