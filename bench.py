@@ -469,14 +469,16 @@ def sampler_workload(B, T, steps):
     with torch.no_grad():
         if packer is not None:
             packer.refresh()
-        coeffs = model.sample_coefficients(st.ema_params, model.deterministic_embedding(B, exp.device))
+        emb = model.deterministic_embedding(B, exp.device)
+        coeffs = model.sample_coefficients(st.ema_params, emb)
+        step = model.reverse_stepper(st.ema_params, B, exp.device, emb, cond, coeffs, T)     # the product path: replayed graph
         z = float(config.model.sigma_prior) * key.normal((B, 3072), exp.device)
         for i in range(3):
-            z = model.sample(st.ema_params, i, T, z, cond, key, coeffs)
+            z = step(i, z, key)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(3, 3 + steps):
-            z = model.sample(st.ema_params, i, T, z, cond, key, coeffs)
+            z = step(i, z, key)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         x = model.generate_x(st.ema_params, z, coeffs, rng=key.fold_in(T))
@@ -491,6 +493,7 @@ def sampler_workload(B, T, steps):
     return {"workload": f"ancestral sampler (Experiment_VDM.sample_fn loop: VDM.sample + generate_x), cifar10-conditioned "
                         f"(E={E}), batch {B}, {steps} timed reverse steps of a T={T} schedule, EMA weights, 1 GPU",
             "metric": "sampled images per second at T=1000", "value": round(B / (dt * T), 3), "unit": "images/s",
+            "hip_graph": type(getattr(step, "__self__", None)).__name__ == "GraphedReverseStep",
             "ms_per_reverse_step": round(dt * 1e3, 3), "reverse_steps_per_s": round(1.0 / dt, 2),
             "image_steps_per_s": round(B / dt, 1), "seconds_per_grid_of_B_images": round(dt * T, 2),
             "model_tflops": round(B / dt * gf / 1e3, 1),

@@ -50,8 +50,9 @@ class Experiment_Colab(Experiment_VDM):
                 z = sample_rng.normal((B, 3072), self.device)
                 conditioning = torch.zeros(B, dtype=torch.uint8, device=self.device)
                 coeffs = self.model.sample_coefficients(self.params, embedding)
+                step = self.model.reverse_stepper(self.params, B, self.device, embedding, conditioning, coeffs, T)
                 for i in range(T):
-                    z = self.model.conditional_sample(self.params, i, T, z, embedding, conditioning, rng, coeffs)
+                    z = step(i, z, rng)
                 samples = self.model.generate_x(self.params, z, rng=rng.fold_in(T))
             finally:
                 if packer is not None:

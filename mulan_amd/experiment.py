@@ -510,10 +510,17 @@ class Experiment_VDM(Experiment):
             try:
                 z = float(self.config.model.sigma_prior) * sample_rng.normal((B, 3072), self.device)
                 coeffs = None
-                if hasattr(self.model, "deterministic_embedding"):
-                    coeffs = self.model.sample_coefficients(params, self.model.deterministic_embedding(B, self.device))
-                for i in range(T):
-                    z = self.model.sample(params, i, T, z, conditioning, rng, coeffs)
+                if hasattr(self.model, "reverse_stepper"):
+                    # MuLAN models: the embedding of the sampler is fixed, so the schedule's coefficients are formed once,
+                    # and the reverse step is a replayed HIP graph (model.GraphedReverseStep; MULAN_SAMPLER_GRAPH=0: eager)
+                    emb = self.model.deterministic_embedding(B, self.device)
+                    coeffs = self.model.sample_coefficients(params, emb)
+                    step = self.model.reverse_stepper(params, B, self.device, emb, conditioning, coeffs, T)
+                    for i in range(T):
+                        z = step(i, z, rng)
+                else:
+                    for i in range(T):
+                        z = self.model.sample(params, i, T, z, conditioning, rng, coeffs)
                 samples = self.model.generate_x(params, z, coeffs, rng=rng.fold_in(T))
             finally:
                 if packer is not None:

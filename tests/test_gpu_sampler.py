@@ -249,6 +249,61 @@ def test_experiment_sample_fn():
     assert torch.equal(before, exp.state.flat)
 
 
+@pytest.mark.parametrize("vdm_type,unet_type", [("mulan_velocity", "vdm"), ("mulan_epsilon", "ldm")])
+def test_replayed_reverse_step_equals_the_eager_step(vdm_type, unet_type, monkeypatch):
+    """model.GraphedReverseStep (the sampler's reverse step as a replayed HIP graph: static buffers for z_t, the step's
+    noise and the two times) against conditional_sample, the eager step (ldm/model_mulan_velocity.py:281-350): the latent
+    after every one of six steps and the generated images are bit-identical; Experiment_VDM.sample_fn gives the same
+    images with the replay on and off."""
+    from mulan_amd import model as M
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    from mulan_amd.rng import PRNGKey
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    config = load_config_file(os.path.join(root, "ldm", "configs", "cifar10-conditioned.py"))
+    config.vdm_type = vdm_type
+    config.model.unet_type = unet_type
+    config.data.dataset = 'synthetic'
+    config.model.sm_n_layer = 2
+    config.model.forward_n_layer = 1
+    config.training.batch_size_train = 4
+    config.training.batch_size_eval = 4
+    exp = Experiment_VDM(config)
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    with torch.no_grad():          # (zero-initialised layers would make the network output trivial)
+        exp.state.ema.copy_(torch.randn(exp.state.ema.shape, device="cuda", generator=gen) * 0.03)
+    model, params, B, T = exp.model, exp.state.ema_params, 5, 6
+    rng = PRNGKey(11)
+    packer = exp.state.param_packer("ema")
+    with torch.no_grad():
+        if packer is not None:
+            packer.refresh()
+        emb = model.deterministic_embedding(B, exp.device)
+        cond = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        coeffs = model.sample_coefficients(params, emb)
+        z0 = rng.normal((B, 3072), exp.device)
+        eager = model.reverse_stepper(params, B, exp.device, emb, cond, coeffs, T, graph=False)
+        replay = model.reverse_stepper(params, B, exp.device, emb, cond, coeffs, T, graph=True)
+        assert type(getattr(replay, "__self__", None)).__name__ == "GraphedReverseStep"
+        za, zb = z0.clone(), z0.clone()
+        for i in range(T):
+            za = eager(i, za, rng)
+            zb = replay(i, zb, rng).clone()
+            assert torch.equal(za, zb), (i, float((za - zb).abs().max()))
+        assert bool(torch.isfinite(za).all()) and float(za.std()) > 0
+        xa, xb = model.generate_x(params, za, coeffs), model.generate_x(params, zb, coeffs)
+        assert torch.equal(xa, xb)
+        if packer is not None:
+            packer.invalidate()
+    dummy = torch.zeros(3, 32, 32, 3, dtype=torch.uint8, device="cuda")
+    monkeypatch.setattr(M, "SAMPLER_GRAPH", True)
+    a = exp.sample_fn(dummy_inputs=dummy, rng=PRNGKey(1), params=exp.state.ema_params, T=4)
+    monkeypatch.setattr(M, "SAMPLER_GRAPH", False)
+    b = exp.sample_fn(dummy_inputs=dummy, rng=PRNGKey(1), params=exp.state.ema_params, T=4)
+    assert torch.equal(a, b) and a.dtype == torch.uint8
+
+
 def test_kernels_against_golden_fixture():
     """the committed fixture tests/golden/sampler_ode.npz (oracle outputs on seeded inputs) as a file-based target"""
     import os

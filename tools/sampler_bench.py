@@ -33,15 +33,18 @@ def main():
     packer = st.param_packer("ema")
     if packer is not None:
         packer.refresh()
-    coeffs = model.sample_coefficients(st.ema_params, model.deterministic_embedding(B, exp.device))
+    emb = model.deterministic_embedding(B, exp.device)
+    coeffs = model.sample_coefficients(st.ema_params, emb)
+    step = model.reverse_stepper(st.ema_params, B, exp.device, emb, cond, coeffs, a.T)   # MULAN_SAMPLER_GRAPH=0: eager
     z = key.normal((B, 3072), exp.device)
-    for i in range(3):
-        z = model.sample(st.ema_params, i, a.T, z, cond, key, coeffs)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(3, 3 + a.steps):
-        z = model.sample(st.ema_params, i, a.T, z, cond, key, coeffs)
-    torch.cuda.synchronize()
+    with torch.no_grad():
+        for i in range(3):
+            z = step(i, z, key)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3, 3 + a.steps):
+            z = step(i, z, key)
+        torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     x = model.generate_x(st.ema_params, z, coeffs)
     torch.cuda.synchronize()
