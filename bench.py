@@ -365,6 +365,14 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
            "graph_used": bool(exp.hip_graph and exp._graphed is not None), "E": int(config.model.sm_n_embd),
            "n_layer": int(config.model.sm_n_layer), "conv_mode": ops.CONV_MODE, "f32_mode": None,
            "graph_error": exp.graph_capture_error}
+    red = exp.reducer
+    if world > 1 and red.capture is not None:
+        # how the replayed step hands its gradient buckets to the collectives (parallel.GradReducer): per bucket, how long
+        # before the end of the graph the collective stream was released in the trial replay
+        res["overlap"] = {"handoff": "signal" if red.capture.get("signals") is not None else "event",
+                          "buckets": len(red.buckets), "marked": list(red.capture.get("order", [])),
+                          "released_ms_before_graph_end": getattr(red, "bucket_leads", None),
+                          "trial_replays_ms": getattr(red, "calibration", None)}
     state, res["roof"] = conv_roofline(exp, state, batches[-1], a, rank, world, B, res["E"], elapsed / steps)
     # ---- the same step with the exact-fp32 MFMA convolution kernels (MULAN_CONV_MODE=f32), for reference
     if f32_reference and world == 1 and ops.CONV_MODE != "f32":
@@ -660,8 +668,9 @@ def main():
                                 f"batch {B}/GPU (weak scaling)"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
         "collective": ({"backend": backend, "rccl_ranks": rccl_ranks,
+                        "replay_overlap": head.get("overlap"),
                         "note": "torch.distributed backend 'nccl' is RCCL on ROCm; bucketed gradient all-reduce on a "
-                                "side stream, overlapped with the backward pass"} if world > 1 else None),
+                                "side stream, overlapped with the (replayed) backward pass"} if world > 1 else None),
         "model_tflops_per_gpu": round(value / world * 3 * fwd_gflop / 1e3, 2),
         "model_roofline_frac": round(value / world * 3 * fwd_gflop / 1e3 /
                                      {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(

@@ -498,6 +498,12 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
         assert out["configs"] is None
     assert out["hip_graph"] == (graph != "0")
     assert out["collective"]["backend"] == "gloo" and out["collective"]["rccl_ranks"] == 0    # (nccl on a multi-GPU node)
+    ov = out["collective"]["replay_overlap"]
+    if graph != "0":
+        assert ov["handoff"] == "signal" and len(ov["marked"]) >= 2 and len(ov["released_ms_before_graph_end"]) == len(ov["marked"])
+        assert max(ov["released_ms_before_graph_end"]) > 0.5          # some bucket was released before the graph ended
+    else:
+        assert ov is None
 
 
 @pytest.mark.timeout(900)
