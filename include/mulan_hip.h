@@ -8,8 +8,10 @@
  * Conventions
  *   - all tensors are contiguous fp32 device buffers unless stated; images are NHWC with W == 32 and
  *     H*W == 1024 (the model never resamples: ldm/model_vdm.py:353-371), matrices are row-major;
- *   - the caller owns every buffer including workspaces; the library never allocates, frees or
- *     synchronises; every call is asynchronous on `stream` and re-entrant; the production entry points read no
+ *   - the caller owns every buffer including workspaces; the compute entry points never allocate, free or
+ *     synchronise (the only exceptions are the handle calls of the last section: mulan_event_create / _destroy and
+ *     mulan_signal_create / _destroy own an event / an 8-byte signal word, mulan_signal_read is a synchronous diagnostic);
+ *     every call is asynchronous on `stream` and re-entrant; the production entry points read no
  *     process-global state (mulan_set_tuning / mulan_set_debug_buffer are developer switches for kernel-variant A/B
  *     runs and timing probes: all zero by default, never set by the product path);
  *   - the return value is a hipError_t as int (0 == hipSuccess); no exceptions cross the boundary;
