@@ -33,8 +33,8 @@ constexpr int TR3 = 8;
 constexpr int P3_ROWS = TR3 + 2;                    // 10
 constexpr int P3_PLANE = P3_ROWS * kPW * 32;        // 10880 B: one plane of one 16-channel chunk
 constexpr int P3_BUF = 2 * P3_PLANE;                // 21760
-constexpr int P3_DUMMY = 3 * P3_BUF;                // 512 B dummy target for the slots past the patch
-constexpr int SMEM3_B = 3 * P3_BUF + 512;           // 65792: two blocks per CU fit the 160 KB
+constexpr int P3_DUMMY = 3 * P3_BUF;                // dummy target for the slots past the patch (512 B) / for the DMA of a row
+constexpr int SMEM3_B = 3 * P3_BUF + 1024;          // outside the image (1 KB).  66304: two blocks per CU fit the 160 KB
 constexpr int PV3 = 6;                              // float4 patch slots per thread and chunk (1360 of 1536 used)
 constexpr int GN_ENT = 48;                          // GroupNorm-fed fill: table entry (scale x 4, beta x 4, mean) per channel quad
 constexpr int GN_MAXC = 512;
@@ -72,9 +72,17 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const
 // scale: the patches hold bit for bit what mulan_groupnorm_fwd_planes would have handed over), from a per-block table
 // (scale = gamma rstd, beta, mean per channel quad of this image) in LDS.  GNF = 1: nothing else (forward-only paths: the
 // normalised tensor never reaches HBM); GNF = 2: the planes are also stored (xs) for a weight-gradient kernel.
-template <int ABL, bool PIN = false, int GNF = 0>
+// DMA (PIN only, round 4): the patch fill is an LDS-DMA (global_load_lds_dwordx4): one wave instruction moves the 32
+// interior pixels of one (plane, row) of a chunk's patch -- 64 lanes x 16 B = 1 KB, contiguous in the [plane][row][col][16 ch]
+// image -- straight into LDS; no staging registers, no ds_write, no per-slot address arithmetic in the MFMA shadows.  A
+// chunk is 2 planes x 10 rows = 20 instructions, 5 per wave, issued in one step (chunk 2 j + 2 into buffer C in step 0,
+// chunk 2 j + 3 into buffer A in step 5, right behind the barrier that frees it).  The halo columns and the rows outside
+// the image are never written: the buffers are zeroed once at the start (a row outside the image is DMA'd into the dummy
+// area instead: no branch in the loop body).  The barriers of the loop wait for the DMAs (vmcnt) like for any LDS write.
+template <int ABL, bool PIN = false, int GNF = 0, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   static_assert(!(PIN && GNF), "GroupNorm-fed fill reads fp32");
+  static_assert(!DMA || PIN, "LDS-DMA fill: plane-fed instantiation only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,6 +278,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, lo), xs_rsrc, eo == 0xffffffffu ? eo : eo + 32, 0, 0);
   };
 
+  // (DMA) the five (plane, row) pieces this wave moves per chunk: piece ri = 5 wave + k -> plane ri / 10, patch row ri % 10
+  auto dma_piece = [&](int pbuf, int cc, int k) {
+    typedef __attribute__((address_space(3))) void* lds_p;
+    typedef const __attribute__((address_space(1))) void* gbl_p;
+    const int ri = wave * 5 + k;
+    const int plane = ri / P3_ROWS, prow = ri - plane * P3_ROWS;
+    const int hh = h0 + prow - 1;
+    const bool inside = (unsigned)hh < (unsigned)p.H;                 // wave-uniform
+    const int hc = inside ? hh : 0;
+    const size_t goff = ((((size_t)b * nchunks + cc) * p.H + hc) * kW + (lane >> 1)) * 64 + plane * 32 + (lane & 1) * 16;
+    const int ldst = inside ? pbuf + plane * P3_PLANE + (prow * kPW + 1) * 32 : P3_DUMMY;
+    __builtin_amdgcn_global_load_lds((gbl_p)(p.xplanes + goff), (lds_p)(smem + ldst), 16, 0, 0);
+  };
+
   // ---- operand addressing
   // pixel fragments (B operand): lane = pixel l15 of the 16-pixel tile, k group grp: channels khalf * 8 .. + 7 of unit sel
   const int xlane = l15 * 32 + khalf * 16;
@@ -309,7 +331,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
 
   // ---- prologue: chunks 0 and 1 into buffers 0 and 1, weights of step 0
   int bufA = 0, bufB = P3_BUF, bufC = 2 * P3_BUF;
-  {
+  i32x4 stgA[2], stgB[2];
+  if constexpr (DMA) {
+    // zero the three buffers once (halo columns, rows outside the image), then the first two chunks by DMA
+#pragma unroll
+    for (int i = 0; i < (3 * P3_BUF + 4095) / 4096; ++i) {
+      const int o = (i * 256 + tid) * 16;
+      if (o < 3 * P3_BUF) *reinterpret_cast<i32x4*>(smem + o) = i32x4{0, 0, 0, 0};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { dma_piece(bufA, 0, k); dma_piece(bufB, nchunks > 1 ? 1 : 0, k); }
+  } else {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       i32x4 r[PV3];
@@ -326,8 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   //   store:  A k0 c0  B k1 c0  A k2 c0  -        -        A k0 c1  B k1 c1  A k2 c1  -
   //   fetch:  A k2 c0  -        -        A k0 c1  B k1 c1  A k2 c1  -        A k0 c0' B k1 c0'
   // (k: slot pair, c0 / c1: the two chunks being filled, c0': the first chunk of the next pair's fill)
-  i32x4 stgA[2], stgB[2];
-  {
+  if constexpr (!DMA) {
     const int c2 = nchunks > 2 ? 2 : nchunks - 1;
     stgA[0] = load_slot(slot_of(tid, 0), c2);
     stgA[1] = load_slot(slot_of(tid, 1), c2);
@@ -390,6 +422,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         mfma16<0>(acc[pt][1], wf[s & 1][1][1], xf[cur][0], false);
         mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][1], false);
         if (!(ABL & 2) && pt >= 1 && pt <= 4) load_w1(wf[(s + 1) & 1], uAn, uBn, pt - 1, sel_s);
+        if constexpr (DMA) {
+          // chunk 2 j + 2 -> buffer C in step 0 (free since the barrier that ended the pair before), chunk 2 j + 3 -> buffer A
+          // in step 5 (free since the step-4 barrier): five pieces per wave, one behind every second pixel tile
+          // (at the head of the step: the compiler's next wait for the weight fragments -- the in-order vmcnt counter makes it
+          // a wait for these pieces too -- comes at the end of the step)
+          if (!(ABL & 4) && (s == 0 || s == 5) && pt < 5)
+            dma_piece(s == 0 ? bufC : bufA, s == 0 ? cfill0 : cfill1, pt);
+        } else {
         if (!(ABL & 4) && (pt == 6 || pt == 8) && (fill0 || fill1)) {
           i32x4& r = st_useB ? stgB[pt == 8] : stgA[pt == 8];
           asm volatile("" : "+v"(r));                // pins the split arithmetic here (it would float to the step's top)
@@ -397,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         }
         if (!(ABL & 4) && (pt == 10 || pt == 12) && lk >= 0)
           (ld_useB ? stgB[pt == 12] : stgA[pt == 12]) = load_slot(slot_of(t_l, 2 * lk + (pt == 12)), lcc);
+        }
         mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][1], false);
         if (!(ABL & 1)) xf[nxt][1] = *reinterpret_cast<const f16x8*>(smem + xa + xo + P3_PLANE);
         mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][0], false);
@@ -536,10 +577,16 @@ int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a_in, hipStream_t stre
     if (!configured_pin) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, true, 0, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);
       if (e != hipSuccess) return (int)e;
       configured_pin = true;
     }
-    hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, true>), grid, dim3(256), SMEM3_B, stream, a);
+    if (g_mulan_tune[18] == 1)     // dev A/B: the register-staged patch fill of rounds 2-3
+      hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, true>), grid, dim3(256), SMEM3_B, stream, a);
+    else                           // LDS-DMA patch fill (round 4: 76.72 / 76.79 / 76.71 vs 77.02 / 76.75 / 76.93 ms per step)
+      hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, true, 0, true>), grid, dim3(256), SMEM3_B, stream, a);
     return (int)hipGetLastError();
   }
 #define MULAN_V3_LAUNCH(ABL)                                                                                          \
