@@ -43,7 +43,7 @@ def main():
         _, dys = ops.conv3x3_dgrad_raw(dy, w, dymax=dymax, planes=True)
         ref = None
         for tune in a.tunes:
-            for k in (1, 6, 7, 10):
+            for k in (1, 6, 7, 10, 19):
                 lib.mulan_set_tuning(k, 0)
             for kv in filter(None, tune.split(",")):
                 k, v = kv.split("=")
