@@ -33,7 +33,7 @@ SHAPES = [  # name, kernel (fp32 input / plane-fed), C, N, residual, launches (d
     ("pin_dgrad_128_128", "pin_plain", 128, 128, False, 7),
     ("pin_dgrad_128_256", "pin_plain", 128, 256, False, 3),
 ]
-SYMBOL = {"fp32": "conv3x3_f16x3_v3_kernel<0, false, 0>", "pin": "conv3x3_f16x3_v3_kernel<0, true, 0>"}
+SYMBOL = {"fp32": "conv3x3_f16x3_v3_kernel<0, false, 0", "pin": "conv3x3_f16x3_v3_kernel<0, true, 0"}   # (prefixes: round 4 added a template parameter)
 KIND_SYMBOL = {"fp32": "fp32", "pin": "pin", "pin_plain": "pin"}
 B = 128
 
