@@ -102,7 +102,14 @@ class GraphedStep:
             # the whole graph)
             if GRAPH_OVERLAP:
                 exp.reducer.begin_capture()
-            with torch.cuda.graph(self.graph):
+            mode = "global"
+            if exp.world > 1:
+                # other threads of a multi-rank process keep talking to the runtime while this one captures (the RCCL
+                # process group's watchdog polls the events of the collectives it still tracks): they must not
+                # invalidate the capture, and it starts after their next poll of a now idle device
+                mode = "thread_local"
+                time.sleep(0.3)
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 state.zero_grad()
                 packer = state.param_packer()
                 if packer is not None:

@@ -181,7 +181,8 @@ class GraphedReverseStep:
                 model._reverse_step(params, self.z_in, self.eps, self.t, self.s, embedding, conditioning, coeffs)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # (thread_local: the RCCL watchdog thread of a multi-rank job keeps polling its events during the capture)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.z_out = model._reverse_step(params, self.z_in, self.eps, self.t, self.s, embedding, conditioning, coeffs)
 
     def step(self, i, z, rng):

@@ -64,6 +64,11 @@ class GradReducer:
         self.enabled = self.world > 1
         self.cuda = flat_grad.is_cuda
         self.side = torch.cuda.Stream() if (self.cuda and self.enabled) else None
+        # RCCL: a collective issued as a *synchronous* op is launched on the stream that is current (torch >= 2.8; before
+        # that on the process group's own stream, which the current one is then made to wait for) -- i.e. on `side`, the
+        # stream calibrate_stream() chose, instead of a pool stream whose hardware queue nobody measured.  Neither form
+        # blocks the host.  Other backends (gloo in the tests) keep the asynchronous op + wait()
+        self.sync_ops = bool(self.side is not None and dist.get_backend(process_group) == "nccl")
         order = sorted(leaves, key=lambda l: l[1])
         cap = max(1, bucket_bytes // 4)
         self.buckets = []          # [lo, hi, n_leaves]
@@ -116,7 +121,14 @@ class GradReducer:
             if wg is not None:
                 self.side.wait_stream(wg)
             with torch.cuda.stream(self.side):
-                self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._all_reduce(view)
+        else:
+            self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _all_reduce(self, view):
+        """sum over the ranks, on the current stream's timeline (see sync_ops)"""
+        if self.sync_ops:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
         else:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -325,7 +337,7 @@ class GradReducer:
             self.launched[bi] = True
             self.ready_order.append(bi)
             with torch.cuda.stream(self.side):
-                self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._all_reduce(self.flat[lo:hi])
         self.finish()
 
     def allreduce_now(self):

@@ -25,13 +25,17 @@ def main():
     ap.add_argument("--gbps", type=float, default=90.0, help="ring rate per direction and link the stand-in assumes (GB/s)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--rccl", action="store_true",
+                    help="no stand-in: the process group is RCCL (backend nccl) with this one rank, so the capture, the "
+                         "signal waits and the optimizer run beside ProcessGroupNCCL's own threads and streams (a "
+                         "one-rank all-reduce moves nothing: a smoke run of the plumbing, not a timing)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    dist.init_process_group("nccl" if a.rccl else "gloo", rank=0, world_size=1)
     from mulan_amd import experiment as E, parallel
     from mulan_amd.config import load_config_file
 
@@ -59,7 +63,14 @@ def main():
 
     real_world = parallel.world_size
     parallel.world_size = lambda: a.ranks             # GradReducer / the scalar mean believe in N ranks
-    dist.all_reduce = standin_all_reduce
+    real_all_reduce = dist.all_reduce
+
+    def counted_all_reduce(t, *args, **kw):
+        if t.numel() * t.element_size() >= (1 << 20):
+            calls["n"] += 1
+        return real_all_reduce(t, *args, **kw)
+
+    dist.all_reduce = counted_all_reduce if a.rccl else standin_all_reduce
 
     def run(hip_graph, overlap):
         E.GRAPH_OVERLAP = overlap
