@@ -22,10 +22,9 @@
 
 #include <stddef.h>
 
-#ifdef __HIP_PLATFORM_AMD__
-#include <hip/hip_runtime_api.h>
-typedef hipStream_t mulan_stream_t;
-#else
+/* (the library's own sources define MULAN_STREAM_T and typedef mulan_stream_t as hipStream_t before they include
+ * this header, so that the compiler checks every definition against the declaration below) */
+#ifndef MULAN_STREAM_T
 typedef void* mulan_stream_t;
 #endif
 

@@ -45,6 +45,7 @@ def build_library(force=False, verbose=True, extra_flags=(), variant=""):
         LIB = os.path.join(HERE, f"libmulan_hip_{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "mulan_hip.h"))     # csrc/common.h includes it
     jobs = []
     objs = []
     for src in sources():
@@ -69,6 +70,21 @@ def build_library(force=False, verbose=True, extra_flags=(), variant=""):
         if r.returncode != 0:
             raise RuntimeError("link failed: " + r.stderr)
     return LIB
+
+
+def build_abi_driver(out=None):
+    """tests/abi_driver.cpp: the torch-free C++ caller of the C ABI (host code only), linked against the in-tree library"""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "abi_driver.cpp")
+    out = out or os.path.join(root, "tests", "_bin", "abi_driver")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if _stale(out, [src, os.path.join(root, "include", "mulan_hip.h"), LIB]):
+        cmd = [_hipcc(), "-O1", "-I", os.path.join(root, "include"), src, "-o", out, "-L", HERE, "-lmulan_hip",
+               "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/../../mulan_amd"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("abi_driver: " + " ".join(cmd) + "\n" + r.stderr)
+    return out
 
 
 if __name__ == "__main__":

@@ -5,6 +5,12 @@
 
 #define MULAN_API extern "C" __attribute__((visibility("default")))
 
+// the public header, seen by every translation unit of the library: a definition whose parameter list differs from
+// its declaration there does not compile
+#define MULAN_STREAM_T
+typedef hipStream_t mulan_stream_t;
+#include "../../include/mulan_hip.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

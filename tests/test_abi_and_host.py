@@ -44,6 +44,27 @@ def test_shared_object_exports_every_declared_symbol(built_lib):
     assert b"gfx950" in h.mulan_version()
 
 
+def test_header_is_plain_c_and_the_cpp_driver_compiles_against_it(built_lib, tmp_path):
+    """the boundary needs neither torch nor HIP headers: include/mulan_hip.h passes a C99 compiler on its own, and the C++
+    caller of tests/abi_driver.cpp (run on the GPU by tests/test_gpu_kernels.py) compiles and links against the library.
+    The library's own sources include the same header (csrc/common.h), so a definition that drifts from its declaration
+    does not build."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "mulan_hip.h")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wpedantic", "-Werror", hdr],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "mulan_hip.h" in open(os.path.join(ROOT, "mulan_amd", "csrc", "common.h")).read()
+    from mulan_amd import build
+    exe = build.build_abi_driver(str(tmp_path / "abi_driver"))
+    assert os.path.exists(exe)
+    ldd = shutil.which("ldd")
+    if ldd:
+        out = subprocess.run([ldd, exe], capture_output=True, text=True).stdout
+        assert "libmulan_hip.so" in out and "libtorch" not in out and "libpython" not in out, out
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from mulan_amd import lib
     monkeypatch.setattr(lib, "_lib", None)

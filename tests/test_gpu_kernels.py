@@ -39,6 +39,22 @@ def rel_err(a, b):
 
 
 # ------------------------------------------------------------------------------ plumbing
+def test_cpp_driver_calls_the_c_abi_without_torch():
+    """tests/abi_driver.cpp -- plain C++ over include/mulan_hip.h + hipMalloc / hipMemcpy / its own stream: the exact and
+    the f16x3 convolution, input and weight gradients bit for bit against host loops on integer data, the maxima
+    by-product, the error convention, the signal word (the C++ unit-test driver of the boundary)"""
+    import os
+    import subprocess
+    from mulan_amd import build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "_bin", "abi_driver")
+    if not os.path.exists(exe):
+        exe = build.build_abi_driver()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ", 0 failed" in r.stdout, r.stdout
+
+
 def test_library_loads_and_runs(ops):
     assert "mulan_hip" in ops.lib.version()
     x = torch.arange(1000, dtype=torch.float32).cuda()
