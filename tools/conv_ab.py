@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--variants", default="0,2")
     ap.add_argument("--ablate", default="", help="v3 only: comma list of ablation masks (tuning knob 4) timed as extra variants")
     ap.add_argument("--timeline", action="store_true", help="v3 only: per-block phase times from the debug stamps")
+    ap.add_argument("--planes-in", action="store_true",
+                    help="time the plane-fed entry point (mulan_conv3x3_fwd_f16x3_planes_in) on the planes the fp32 launch wrote")
     a = ap.parse_args()
     L = ops.lib.load()
     B = a.batch
@@ -49,6 +51,14 @@ def main():
         def launch():
             call("mulan_conv3x3_fwd_f16x3", ptr(x), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cb), 1 if hcb else 0,
                  ptr(res), ptr(y), ptr(xs), ptr(ymax), B, 32, 32, C, N, stream())
+
+        if a.planes_in and planes:
+            launch()                 # the fp32 launch fills xs: from here on the plane-fed kernel is what is timed
+            torch.cuda.synchronize()
+
+            def launch():            # noqa: F811
+                call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(xs), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cb),
+                     1 if hcb else 0, ptr(res), ptr(y), ptr(ymax), B, 32, 32, C, N, stream())
 
         if a.timeline:
             import numpy as np
