@@ -2,12 +2,14 @@
 // (hipMalloc / hipMemcpy / a stream of its own), the way SURVEY 8(b) names "C++ unit-test driver" as the second caller of
 // the C ABI.  It runs the 3x3 convolution of the ResnetBlock (ldm/model_vdm.py:633-656) through the boundary in both
 // arithmetic modes, its weight gradient and its input gradient, on small-integer data -- where fp32 AND the f16x3 split
-// are exact, so the comparison with the loops below is bit for bit -- and checks the error convention (a hipError_t as
+// are exact, so the comparison with the loops below is bit for bit --, GroupNorm + swish and the AdamW / EMA step against
+// double-precision loops (tolerances at the checks), and checks the error convention (a hipError_t as
 // int, no exception, nothing launched) on arguments the entry points must refuse.
 //   hipcc -O1 -I include tests/abi_driver.cpp -o /tmp/abi_driver -L mulan_amd -lmulan_hip -Wl,-rpath,$PWD/mulan_amd
 // tests/test_abi_and_host.py compiles it (CPU suite); tests/test_gpu_kernels.py runs it on the GPU.
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -193,6 +195,81 @@ void f16x3_path(hipStream_t stream) {
   expect(same(gw.host(), wgrad_host(xs, gy, B, E, E)), "mulan_conv3x3_wgrad_f16x3 == host loops");
 }
 
+// floats in (-1, 1) from the same LCG
+std::vector<float> reals(size_t n, float amp, uint64_t seed) {
+  std::vector<float> v(n);
+  uint64_t s = seed * 6364136223846793005ull + 1442695040888963407ull;
+  for (size_t i = 0; i < n; ++i) {
+    s = s * 6364136223846793005ull + 1442695040888963407ull;
+    v[i] = amp * ((float)((s >> 40) & 0xffffff) / 8388608.f - 1.f);
+  }
+  return v;
+}
+
+double max_abs_diff(const std::vector<float>& a, const std::vector<double>& b) {
+  double m = 0;
+  for (size_t i = 0; i < a.size(); ++i) { const double d = std::fabs((double)a[i] - b[i]); m = d > m ? d : m; }
+  return m;
+}
+
+void groupnorm_and_optimizer(hipStream_t stream) {
+  // nn.GroupNorm(32 groups, eps 1e-6, fast variance E[x^2] - E[x]^2) + swish over the channel concat [x1 | x2]
+  // (ldm/model_vdm.py:622-623): against double-precision loops, tolerance 2e-5 absolute on O(1) outputs (fp32 sums over
+  // 4096 elements per group)
+  const int B = 2, C1 = 64, C2 = 64, Ct = C1 + C2, G = 32, cpg = Ct / G, HWp = H * W;
+  const auto x1 = reals((size_t)B * HWp * C1, 2.f, 31), x2 = reals((size_t)B * HWp * C2, 2.f, 32);
+  const auto gamma = reals(Ct, 1.5f, 33), beta = reals(Ct, 0.5f, 34);
+  DevBuf<float> dx1(x1), dx2(x2), dg(gamma), db(beta), y((size_t)B * HWp * Ct), mean((size_t)B * G), rstd((size_t)B * G);
+  expect(mulan_groupnorm_fwd(dx1.p, dx2.p, C1, C2, dg.p, db.p, y.p, mean.p, rstd.p, B, HWp, G, 1e-6f, 1, 1.f, 0ull, 0ull, nullptr,
+                             stream) == 0, "mulan_groupnorm_fwd returns 0");
+  hip_ok(hipStreamSynchronize(stream), "sync");
+  std::vector<double> want((size_t)B * HWp * Ct);
+  for (int b = 0; b < B; ++b)
+    for (int g = 0; g < G; ++g) {
+      double s1 = 0, s2 = 0;
+      for (int px = 0; px < HWp; ++px)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+          const double v = c < C1 ? x1[((size_t)b * HWp + px) * C1 + c] : x2[((size_t)b * HWp + px) * C2 + c - C1];
+          s1 += v; s2 += v * v;
+        }
+      const double n = (double)HWp * cpg, m = s1 / n, var = s2 / n - m * m, r = 1.0 / std::sqrt((var > 0 ? var : 0) + 1e-6);
+      for (int px = 0; px < HWp; ++px)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+          const double v = c < C1 ? x1[((size_t)b * HWp + px) * C1 + c] : x2[((size_t)b * HWp + px) * C2 + c - C1];
+          const double u = (v - m) * r * gamma[c] + beta[c];
+          want[((size_t)b * HWp + px) * Ct + c] = u / (1.0 + std::exp(-u));
+        }
+    }
+  expect(max_abs_diff(y.host(), want) < 2e-5, "mulan_groupnorm_fwd (+swish, concat input) == double loops to 2e-5");
+  expect(mulan_groupnorm_fwd(dx1.p, dx2.p, C1, C2, dg.p, db.p, y.p, mean.p, rstd.p, B, 1000, G, 1e-6f, 1, 1.f, 0ull, 0ull, nullptr,
+                             stream) != 0, "hw != 1024 is refused");
+
+  // optax.adamw (b1 0.9, b2 0.99, eps 1e-8, wd 0.01 on the first n_decay elements) + EMA, ldm/train_state.py:70-102
+  const size_t n = 10000, n_decay = 6000;
+  const auto p0 = reals(n, 1.f, 41), g0 = reals(n, 0.1f, 42), m0 = reals(n, 0.05f, 43), e0 = reals(n, 1.f, 45);
+  auto v0 = reals(n, 0.01f, 44);
+  for (auto& v : v0) v = std::fabs(v);
+  DevBuf<float> dp(p0), dgr(g0), dm(m0), dv(v0), de(e0);
+  const float lr = 2e-4f, b1 = 0.9f, b2 = 0.99f, eps = 1e-8f, wd = 0.01f, ema_rate = 0.9999f, gscale = 0.5f;
+  const int step = 7;
+  expect(mulan_adamw_ema_step(dp.p, dgr.p, dm.p, dv.p, de.p, n, n_decay, lr, b1, b2, eps, wd, step, ema_rate, gscale, stream) == 0,
+         "mulan_adamw_ema_step returns 0");
+  hip_ok(hipStreamSynchronize(stream), "sync");
+  std::vector<double> wp(n), wm(n), wv(n), we(n);
+  const double bc1 = 1.0 - std::pow((double)b1, step), bc2 = 1.0 - std::pow((double)b2, step);
+  for (size_t i = 0; i < n; ++i) {
+    const double g = (double)g0[i] * gscale;
+    wm[i] = b1 * (double)m0[i] + (1.0 - b1) * g;
+    wv[i] = b2 * (double)v0[i] + (1.0 - b2) * g * g;
+    double u = (wm[i] / bc1) / (std::sqrt(wv[i] / bc2) + eps);
+    if (i < n_decay) u += wd * (double)p0[i];
+    wp[i] = (double)p0[i] - lr * u;
+    we[i] = ema_rate * (double)e0[i] + (1.0 - ema_rate) * wp[i];
+  }
+  expect(max_abs_diff(dp.host(), wp) < 2e-7 && max_abs_diff(dm.host(), wm) < 1e-7 && max_abs_diff(dv.host(), wv) < 1e-8 &&
+         max_abs_diff(de.host(), we) < 2e-7, "mulan_adamw_ema_step == optax.adamw + EMA in double (fp32 rounding)");
+}
+
 void error_convention(hipStream_t stream) {
   // refused arguments: a non-zero hipError_t comes back, nothing is launched, nothing throws, the stream stays usable
   DevBuf<float> a(1024), b(1024);
@@ -229,6 +306,7 @@ int main() {
   hip_ok(hipStreamCreate(&stream), "hipStreamCreate");
   exact_fp32_path(stream);
   f16x3_path(stream);
+  groupnorm_and_optimizer(stream);
   error_convention(stream);
   hip_ok(hipStreamDestroy(stream), "hipStreamDestroy");
   std::printf("abi_driver: %d checks, %d failed (library %s)\n", g_checks, g_failed, v ? v : "?");
