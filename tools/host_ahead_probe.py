@@ -40,8 +40,17 @@ def main():
             t[name].append((time.perf_counter() - t0) * 1e3)
             return r
         return f
+    ev = []      # (before the replay, after it): GPU time between the end of one replay and the start of the next = the
+                 # staging copies and noise kernels GraphedStep._fill queues between them
+
+    def replay_with_events():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        replay0()
+        b.record()
+        ev.append((a, b))
     gs._fill = timed("fill", fill0)
-    gs.graph.replay = timed("replay", replay0)
+    gs.graph.replay = timed("replay", replay_with_events)
     gs.copied.synchronize = timed("sync", sync0)
     n = 12
     t0 = time.perf_counter()
@@ -53,6 +62,8 @@ def main():
     total = (time.perf_counter() - t0) * 1e3
     print(f"{n} steps in {total:.1f} ms = {total / n:.2f} ms per step; host returned from step i at (ms): "
           + " ".join(f"{m:.1f}" for m in marks))
+    print("GPU ms inside the replayed graph : " + " ".join(f"{a.elapsed_time(b):6.2f}" for a, b in ev))
+    print("GPU ms between two replays       : " + " ".join(f"{ev[i][1].elapsed_time(ev[i + 1][0]):6.2f}" for i in range(len(ev) - 1)))
     for k, v in t.items():
         print(f"host ms in {k:7s}: " + " ".join(f"{x:6.2f}" for x in v))
 
