@@ -393,8 +393,18 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
                                    "split-operand kernels"}
     exp._graphed = None
     del exp, state, batches
-    torch.cuda.empty_cache()
+    _release_device_memory()
     return res
+
+
+def _release_device_memory():
+    """between two workloads: the experiment just dropped may still be held by reference cycles (autograd contexts of its last
+    eager step); collect them before the caching allocator gives its blocks back -- otherwise the next workload is laid out
+    around what is left (measured: config #4 at 248-253 ms behind the exact-fp32 reference steps instead of 236-237)"""
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def _max_over_ranks(seconds, world, dev):
@@ -447,7 +457,7 @@ def dense_eval_workload(images, T, rank=0, world=1):
     elapsed = _max_over_ranks(time.perf_counter() - t0, world, exp.device)
     dt = elapsed / images                                 # seconds per test image on one GPU
     del exp
-    torch.cuda.empty_cache()
+    _release_device_memory()
     return {"workload": f"eval_bpd dense VLB (evaluators.eval_bpd_dense_sampling), ldm/configs/imagenet32.py (E=256, "
                         f"velocity_from_epsilon), T={T} copies per image, {images} images per rank after one warm-up "
                         f"image, test images sharded over {world} rank(s) by index, one (sum, count) all-reduce, forward "
@@ -496,7 +506,7 @@ def sampler_workload(B, T, steps):
     ok = tuple(x.shape) == (B, 32, 32, 3) and bool(torch.isfinite(z).all())
     E = int(config.model.sm_n_embd)
     del exp
-    torch.cuda.empty_cache()
+    _release_device_memory()
     gf = SCORE_FWD_GFLOP_BY_WIDTH[E]
     return {"workload": f"ancestral sampler (Experiment_VDM.sample_fn loop: VDM.sample + generate_x), cifar10-conditioned "
                         f"(E={E}), batch {B}, {steps} timed reverse steps of a T={T} schedule, EMA weights, 1 GPU",
@@ -535,7 +545,7 @@ def ode_workload(B):
     bpd = float((-(log_p) + aux.double()).mean() / (3072 * math.log(2.0)) + offset)
     E = int(config.model.sm_n_embd)
     del exp
-    torch.cuda.empty_cache()
+    _release_device_memory()
     per = dt / info["nfev"]
     gf = 3 * SCORE_FWD_GFLOP_BY_WIDTH[E] * 2.0 / 3.0       # forward + input-gradient pass (no weight gradients)
     return {"workload": f"exact-likelihood ODE evaluator (evaluators.get_ode_likelihood_fn), cifar10-conditioned (E={E}), "
