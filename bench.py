@@ -399,8 +399,9 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
 
 def _release_device_memory():
     """between two workloads: the experiment just dropped may still be held by reference cycles (autograd contexts of its last
-    eager step); collect them before the caching allocator gives its blocks back -- otherwise the next workload is laid out
-    around what is left (measured: config #4 at 248-253 ms behind the exact-fp32 reference steps instead of 236-237)"""
+    eager step); collect them before the caching allocator gives its blocks back, so that every workload starts from an
+    empty pool.  (Config #4 reads 236-237 ms on most boxes and 248-253 ms on some, inside this run and alone alike: that
+    spread is the box's, not this function's -- same-box sequences in profiles/r04_config4_box_spread.log.)"""
     import gc
     import torch
     gc.collect()
