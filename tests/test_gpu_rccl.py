@@ -48,10 +48,12 @@ red = parallel.GradReducer(flat, leaves, bucket_bytes=4 << 20)
 red.world, red.enabled = 2, True            # exercise the launch path on the one-rank group
 red.side = red.side or torch.cuda.Stream()
 want = flat.clone()
-red.prepare()
-red.finish()
-torch.cuda.synchronize()
-assert torch.equal(flat, want) and len(red.buckets) == 3 and sorted(red.ready_order) == [0, 1, 2]
+for sync_ops in (True, False):              # the collective as a synchronous op on the side stream (what a multi-rank RCCL
+    red.sync_ops = sync_ops                 # job uses) and as an asynchronous op + wait()
+    red.prepare()
+    red.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(flat, want) and len(red.buckets) == 3 and sorted(red.ready_order) == [0, 1, 2]
 t = torch.ones(4, device="cuda"); dist.all_reduce(t); dist.barrier()
 print("RCCL_SMOKE ok", dist.get_backend(), torch.cuda.get_device_name(0))
 dist.destroy_process_group()
