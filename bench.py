@@ -66,7 +66,23 @@ def parse():
     ap.add_argument("--configs-small", action="store_true",
                     help="test-sized extra configurations (global batch 32 / 8 per GPU, T = 64, tiny sampler / ODE batches): the "
                          "control flow of \"configs\" in seconds; the numbers it prints are not the configurations' numbers")
-    return ap.parse_args()
+    ap.add_argument("--small-depth", type=int, default=0, help=argparse.SUPPRESS)   # tests only: ResBlocks per U-Net stage
+    a = ap.parse_args()
+    global TEST_DEPTH
+    TEST_DEPTH = a.small_depth
+    return a
+
+
+TEST_DEPTH = 0
+
+
+def _test_depth(config):
+    """(tests only, --small-depth N) N ResnetBlocks per U-Net stage instead of the configuration's 32 / 4: the control flow
+    of a multi-rank run in seconds.  Never set by the driver; the JSON line says so (`test_depth`) when it is."""
+    if TEST_DEPTH > 0:
+        config.model.sm_n_layer = TEST_DEPTH
+        config.model.forward_n_layer = min(TEST_DEPTH, int(config.model.forward_n_layer))
+    return config
 
 
 def self_launch(a):
@@ -186,15 +202,16 @@ def conv_roofline(exp, state, batch, a, rank, world, B, E, step_s):
     import torch.distributed as dist
     from mulan_amd import ops
     roof = None
-    if rank == 0:
-        ops.KERNEL_TIMER = []
+    # (every rank times: with the timer on a step runs eagerly, and all ranks must run the same kind of step -- the
+    # eager step launches its bucket all-reduces as the backward pass completes them, a replayed one behind the graph)
+    ops.KERNEL_TIMER = []
     state, _ = exp.train_step(exp._train_rng, state, batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    recs = ops.KERNEL_TIMER
+    ops.KERNEL_TIMER = None
     if rank == 0:
-        recs = ops.KERNEL_TIMER
-        ops.KERNEL_TIMER = None
         # an event pair around nothing still reads a few microseconds (the two records themselves): measured here and
         # taken off every launch, so the average below is the kernel's own duration (it then agrees with rocprofv3)
         ov = []
@@ -318,7 +335,7 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
     from mulan_amd import ops
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
-    config = load_config_file(cfg_path)
+    config = _test_depth(load_config_file(cfg_path))
     config.vdm_type = vdm_type
     config.data.dataset = "synthetic"
     if vfe:
@@ -429,7 +446,7 @@ def dense_eval_workload(images, T, rank=0, world=1):
     from mulan_amd import evaluators
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
-    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "imagenet32.py"))
+    config = _test_depth(load_config_file(os.path.join(ROOT, "ldm", "configs", "imagenet32.py")))
     config.data.dataset = "synthetic"
     config.vdm_type = "mulan_velocity"
     config.model.velocity_from_epsilon = True
@@ -476,10 +493,11 @@ def sampler_workload(B, T, steps):
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
     from mulan_amd.rng import PRNGKey
-    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    config = _test_depth(load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")))
     config.data.dataset = "synthetic"
-    config.training.batch_size_train = B
-    config.training.batch_size_eval = B
+    from mulan_amd import parallel
+    config.training.batch_size_train = B * parallel.world_size()      # (the configuration's batch sizes are global ones:
+    config.training.batch_size_eval = B * parallel.world_size()       # B images per rank, as the reference samples)
     exp = Experiment_VDM(config)
     st, model = exp.state, exp.model
     cond = torch.zeros(B, dtype=torch.uint8, device=exp.device)
@@ -528,10 +546,11 @@ def ode_workload(B):
     from mulan_amd.config import load_config_file
     from mulan_amd.experiment import Experiment_VDM
     from mulan_amd.rng import PRNGKey
-    config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
+    config = _test_depth(load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")))
     config.data.dataset = "synthetic"
-    config.training.batch_size_train = B
-    config.training.batch_size_eval = B
+    from mulan_amd import parallel
+    config.training.batch_size_train = B * parallel.world_size()      # (global batch sizes: B images per rank)
+    config.training.batch_size_eval = B * parallel.world_size()
     exp = Experiment_VDM(config)
     exp.orig_params = exp.state.ema_params
     like = evaluators.get_ode_likelihood_fn(exp, hutchinson_type="Rademacher", rtol=1e-5, atol=1e-5, dequantization="tn")
@@ -679,6 +698,10 @@ def main():
                                 f"batch {B}/GPU (weak scaling)"),
                    "global_batch": B * world, "parallelism": f"dp{world}", "image": "32x32x3 uint8"},
         "collective": ({"backend": backend, "rccl_ranks": rccl_ranks,
+                        "schedule": ("replayed HIP graph, bucket all-reduces behind their signal words (opt-in)"
+                                     if head.get("overlap") else
+                                     ("replayed HIP graph, collectives behind it" if head["graph_used"] else
+                                      "eager step, bucketed all-reduce overlapping the backward pass")),
                         "replay_overlap": head.get("overlap"),
                         "note": "torch.distributed backend 'nccl' is RCCL on ROCm; bucketed gradient all-reduce on a "
                                 "side stream, overlapped with the (replayed) backward pass"} if world > 1 else None),
@@ -692,6 +715,8 @@ def main():
                       "released checkpoint is in the image (tools/verify_checkpoint.py pins it in one command)",
         "roofline": roof, "f32_mfma_mode": head["f32_mode"], "cpu_baseline": cpu, "configs": extra,
     }
+    if TEST_DEPTH > 0:        # (--small-depth: a test run; none of its numbers is the configuration's)
+        out["test_depth"] = TEST_DEPTH
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

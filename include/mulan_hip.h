@@ -329,6 +329,31 @@ int mulan_groupnorm_fwd_planes_keepbits(const float* x1, const float* x2, int C1
                                         float eps, int act, float keep, unsigned long long seed, unsigned long long offset,
                                         const unsigned long long* seed_dev, unsigned* ymax, unsigned* keepbits,
                                         mulan_stream_t stream);
+/* Streaming forms (round 5; the same layers, model_vdm.py:622-623,632,643-644 and their autodiff): the reductions that
+ * force the kernels above to hold a whole (sample, 32-channel slab) before they write -- mean / variance in the forward
+ * pass, the two group sums of the backward pass -- arrive from the PRODUCER of the tensor instead: the convolution whose
+ * epilogue wrote x leaves sum x, sum x^2 (`ystats` of mulan_conv3x3_fwd_f16x3_planes_in_stats), the input-gradient
+ * convolution that wrote dy leaves sum g gamma, sum g gamma xhat (`gstats` of mulan_conv3x3_fwd_f16x3_gstats /
+ * mulan_conv3x3_fwd_f16x3_planes_in_gstats), each per image, 8-row tile and channel quad: [B][4][C / 4][2] floats.  The
+ * GroupNorm kernels are then plain streaming passes (forward 1 read + 1 write, backward 2 reads + 1 write).
+ * _fwd_stream: exactly one of y (fp32; ymax optional: true maxima) and yplanes (split planes; ymax required: the bound).
+ * xstats1 (, xstats2 for C2 > 0) given: mean / rstd [B, G] are OUTPUTS; NULL: they are inputs.  keepbits (optional,
+ * keep < 1): as mulan_groupnorm_fwd_planes_keepbits.
+ * _bwd_stream: arguments of mulan_groupnorm_bwd_fused plus gstats; dx1planes (optional, then C2 == 0 and no add*):
+ * dx1 as split planes (mulan_groupnorm_bwd_fused_planes), dymax required, dx1max receives the bound. */
+int mulan_groupnorm_fwd_stream(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
+                               float* y, void* yplanes, float* mean, float* rstd, const float* xstats1,
+                               const float* xstats2, int B, int hw, int G, float eps, int act, float keep,
+                               unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
+                               unsigned* ymax, unsigned* keepbits, mulan_stream_t stream);
+int mulan_groupnorm_bwd_stream(const float* dy, const unsigned* dymax, const float* x1, const float* x2, int C1, int C2,
+                               const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               const float* gstats, float* dx1, float* dx2, void* dx1planes, float* dgamma_part,
+                               float* dbeta_part, int B, int hw, int G, int act, float keep, unsigned long long seed,
+                               unsigned long long offset, const unsigned long long* seed_dev, unsigned* dx1max,
+                               unsigned* dx2max, const float* add1, const float* add2, const float* add1b,
+                               float* dxsum_part, float* dgamma, float* dbeta, float* dxsum, float* dxsum2,
+                               unsigned* tickets, const unsigned* keepbits, mulan_stream_t stream);
 /* add1 / add2 (optional): gradients arriving through a skip path of x1 / x2 (the ResnetBlock residual, nin_shortcut),
  * added while dx is written, so that no separate accumulation pass exists.  By-products of the written gradients (the
  * dy of the convolution in front): dx1max / dx2max (optional, [B][16], mulan_absmax_rows format) and dxsum_part

@@ -136,10 +136,11 @@ def canonical_param_names(tree):
 
 
 def _normalise_flax_state(sd):
-    """Maps the reference's opt_state (optax.chain of two optax.masked AdamW states, ldm/experiment.py:151-173; as a
-    Flax state dict: {'0': {'inner_state': {'0': {count, mu, nu}, '1': {}, '2': {}}}, '1': {...}} with masked-out
-    leaves serialised as empty nodes) onto {'mu','nu'}, resolves the gamma-network name aliases, and leaves
-    step untouched."""
+    """Maps the reference's opt_state (optax.chain of two optax.masked AdamW states, ldm/experiment.py:151-173: number 0
+    over the score_model leaves, number 1 over the rest; as a Flax state dict
+    {'0': {'inner_state': {'0': {count, mu, nu}, '1': {'inner_state': {}}, '2': {}}}, '1': {...}} with masked-out leaves
+    serialised as empty nodes) onto {'mu','nu'} -- the two moment trees are merged leaf by leaf, whichever instance
+    holds a leaf --, resolves the gamma-network name aliases, and leaves step untouched."""
     out = {k: canonical_param_names(sd[k]) if k != "step" else sd[k] for k in ("step", "params", "ema_params") if k in sd}
     if "step" in out:
         out["step"] = int(np.asarray(out["step"]))

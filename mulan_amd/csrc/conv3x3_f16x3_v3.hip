@@ -445,7 +445,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         else mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
       }
       xaddr = xaddr_n;
-      if (!(ABL & 8) && (s == 4 || s == 8)) __syncthreads();
+      if (!(ABL & 8) && (s == 4 || s == 8)) {
+        // (DMA) the barrier must also cover this wave's LDS-DMA pieces: other waves read them behind it, and nothing but
+        // the issuing wave's vmcnt orders a global_load_lds against a later ds_read.  The compiler's barrier waits for
+        // lgkmcnt only; the vmcnt(0) it happens to emit for the weight fragments of this step is not a guarantee
+        // (ADVICE r04).  Free: the counter is already drained here.
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
     }
     const int t = bufA; bufA = bufC; bufC = bufB; bufB = t;      // (A, B, C) <- (C, A, B)
     // nine steps per pair: the weights fetched during step 8 sit in buffer 1, the next pair starts on buffer 0

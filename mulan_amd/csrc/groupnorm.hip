@@ -30,6 +30,10 @@ struct GnArgs {
                                               // this kernel; bit 4 i + e: element e of pixel prow + 32 i)
   int stats_only;                             // 1: mean / rstd and the bound (into ymax) only, nothing is normalised: the
                                               // consumer (mulan_conv3x3_fwd_f16x3_gn_in) applies them while it fills its patches
+  // streaming kernel only: the statistics arrive as the partial sums the convolutions that PRODUCED x1 (, x2) left
+  // (their `ystats`: [B][HW / 256][C1 / 4][2] = sum and sum of squares per image, 8-row tile and channel quad);
+  // mean / rstd are then OUTPUTS (for the backward pass).  NULL: mean / rstd are inputs.
+  const float* xstats1; const float* xstats2;
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -255,6 +259,9 @@ struct GnBwdArgs {
   // optional (single-pass kernel): a second gradient that reaches x1 from outside -- dx1 = (dx1 + add1) + add1b: the
   // gradient a block output receives through its U-Net skip connection, added here instead of by a kernel of its own
   const float* add1b;
+  // streaming kernel only: the partial sums of g gamma and g gamma xhat (g = dy mask / keep act'(u)) per image, 8-row
+  // tile and channel quad, [B][HW / 256][(C1 + C2) / 4][2], as the input-gradient convolution that produced dy left them
+  const float* gstats;
 };
 
 __global__ __launch_bounds__(256) void gn_bwd_kernel(GnBwdArgs p) {
@@ -632,6 +639,574 @@ __global__ __launch_bounds__(512) void gn_bwd_kernel_1pass(GnBwdArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming forms (round 5): the same arithmetic without the register-resident slab.  The slab kernels above read a
+// whole (sample, 32-channel slab) before the first byte is written, because the statistics (forward) / the two group
+// sums (backward) are reductions over it: every CU alternates between a read phase and a write phase, and with 512
+// blocks of one dispatch round the whole chip does so in step (4.0-4.3 TB/s).  Here the reductions arrive from the
+// PRODUCER of the tensor -- the convolution whose epilogue wrote x (forward: sum x, sum x^2) or dy (backward: sum g gamma,
+// sum g gamma xhat), per image, 8-row tile and channel quad -- so every element is final the moment it is loaded: 16 waves
+// per block, 8 pixels per lane, loads and stores of different waves overlap all the time.
+// Block = (sample, 32-channel slab), 1024 threads: thread (sp, prow, quad) = (tid >> 8, (tid >> 3) & 31, tid & 7) owns the
+// float4 `quad` of pixels prow + 32 (8 sp + i), i = 0..7 -- the pixels of keep-bit word `sp` of slab-kernel thread
+// (prow, quad): both kernel families read and write the same keep-bit layout.
+constexpr int SU = 8;
+
+// mean / rstd of group g of image b from the producers' partial sums (fixed order: quads of the group, then row tiles)
+__device__ __forceinline__ void stats_from_partials(const GnArgs& p, int b, int g, int cpg, float& mean, float& rstd) {
+  const int qpg = cpg >> 2, nq1 = p.C1 >> 2, nq2 = p.C2 >> 2;
+  float s1 = 0.f, s2 = 0.f;
+  for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) {
+    const bool first = qq < nq1;
+    const int nq = first ? nq1 : nq2;
+    const float* st = (first ? p.xstats1 : p.xstats2) + ((size_t)b * (HW / 256) * nq + (first ? qq : qq - nq1)) * 2;
+#pragma unroll
+    for (int t = 0; t < HW / 256; ++t) { s1 += st[(size_t)t * nq * 2]; s2 += st[(size_t)t * nq * 2 + 1]; }
+  }
+  const float inv_n = 1.f / (float)(HW * cpg);
+  mean = s1 * inv_n;
+  rstd = rsqrtf(fmaxf(0.f, s2 * inv_n - mean * mean) + p.eps);
+}
+
+// Addressing: one buffer resource per tensor and image (wave-uniform, scalar registers), one 32-bit lane offset per
+// tensor, the pixel step as the instruction's scalar offset -- no 64-bit address arithmetic, no address registers per
+// pixel (with flat pointers the compiler keeps all of a thread's 8-32 addresses live and spills).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t gn_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, f16x3::kBufWord3);
+}
+__device__ __forceinline__ f32x4 gn_ld4(rsrc_t r, unsigned voff, unsigned soff) {      // non-temporal: read once
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
+}
+// A 16-byte buffer store reads its data registers a few cycles AFTER it issues.  hipcc (ROCm 7.2) pads a following VALU
+// write of those registers with wait states only for the immediate-offset form, not when the scalar offset is a register
+// (LLVM's model of the hazard) -- and gfx950 then stored the NEW value of the first data register: `buffer_store_dwordx4
+// v[26:29], ..., s3 offen` followed at once by `v_and_b32 v26, 0x7fffffff, v26` (the maxima update) wrote |y| for element
+// 0 (seen as sign flips in tests/test_gpu_gn_stream.py, 256 NSP >= 512 threads).  The data registers are therefore kept
+// alive across three wait states behind the store; 8-byte stores (the plane pieces) have no such hazard.
+__device__ __forceinline__ void gn_st4(rsrc_t r, f32x4 v, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(f16x3::i32x4, v), r, voff, soff, 0);
+  asm volatile("s_nop 2" ::: "memory");
+  asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+}
+__device__ __forceinline__ void gn_st_planes(rsrc_t r, f32x4 o, float bound, float psc, unsigned voff, unsigned soff) {
+  // the split of gn_fwd_kernel's planes mode (clamp, scale, hi = fp16(v), lo = fp16(v - hi)), two 8-byte pieces
+  typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+  f16x3::f16x4 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    const f32x2 vs = f32x2{__builtin_amdgcn_fmed3f(o[e], -bound, bound), __builtin_amdgcn_fmed3f(o[e + 1], -bound, bound)} * psc;
+    const f16x2v h = __builtin_convertvector(vs, f16x2v);
+    const f16x2v l = __builtin_convertvector(vs - __builtin_convertvector(h, f32x2), f16x2v);
+    hi[e] = h[0]; hi[e + 1] = h[1]; lo[e] = l[0]; lo[e + 1] = l[1];
+  }
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f16x3::i32x2, hi), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(f16x3::i32x2, lo), r, voff + 32, soff, 0);
+}
+
+template <int NSP>     // NSP quarters (256 pixels each) of the slab per block: 256 NSP threads, grid.z = 4 / NSP
+__global__ __launch_bounds__(256 * NSP) void gn_fwd_stream_kernel(GnArgs p) {
+  if (p.seed_dev) p.seed ^= p.seed_dev[0];
+  constexpr int NW = 4 * NSP;
+  __shared__ unsigned ured[NW];
+  const int tid = threadIdx.x, quad = tid & 7, prow = (tid >> 3) & 31, sp = (tid >> 8) + blockIdx.z * NSP;
+  const int b = blockIdx.x, Ct = p.C1 + p.C2;
+  const int c0 = blockIdx.y * 32;
+  const int cpg = Ct / p.G, qpg = cpg >> 2, csh = 31 - __builtin_clz(cpg);   // (cpg is 4, 8, 16 or 32)
+  const bool first = c0 < p.C1;
+  const int ld = first ? p.C1 : p.C2, cs = first ? c0 : c0 - p.C1;
+  const rsrc_t xr = gn_rsrc((first ? p.x1 : p.x2) + (size_t)b * HW * ld, (size_t)HW * ld * 4);
+  const int px0 = prow + 256 * sp;            // pixel of i = 0; the others follow 32 apart
+  const unsigned xoff = (unsigned)((px0 * ld + cs + quad * 4) * 4);
+  const unsigned xstep = (unsigned)(32 * ld * 4);
+
+  f32x4 v[SU];
+#pragma unroll
+  for (int i = 0; i < SU; ++i) v[i] = gn_ld4(xr, xoff, i * xstep);
+  const int c = c0 + quad * 4, g = c >> csh;
+  float mean, rstd;
+  if (p.xstats1) {
+    stats_from_partials(p, b, g, cpg, mean, rstd);
+    if (sp == 0 && prow == 0 && (quad & (qpg - 1)) == 0) { p.mean[b * p.G + g] = mean; p.rstd[b * p.G + g] = rstd; }
+  } else {
+    mean = p.mean[b * p.G + g]; rstd = p.rstd[b * p.G + g];
+  }
+  // the bound of the planes (see gn_fwd_kernel): every wave forms it by itself (no barrier between the loads and the
+  // stores of a wave: a __syncthreads here would also wait for the loads in flight)
+  float bound = 0.f;
+  if (p.yplanes) {
+    float gm = 0.f, bm = 0.f;
+    for (int cc = tid & 63; cc < Ct; cc += 64) { gm = fmaxf(gm, fabsf(p.gamma[cc])); bm = fmaxf(bm, fabsf(p.beta[cc])); }
+    gm = wave_max(gm); bm = wave_max(bm);
+    bound = (sqrtf((float)(HW * cpg)) * gm + bm) / p.keep;
+  }
+  unsigned mb = 0u;
+  const bool dropping = p.keep < 1.f;
+  if (dropping) {
+    const uint32_t thr = (uint32_t)((double)p.keep * 4294967296.0);
+#pragma unroll
+    for (int i = 0; i < SU; ++i) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + (px0 + 32 * i)) * Ct + (c0 + quad * 4)) >> 2;
+      mb |= drop_bits4(thr, p.seed, p.offset + idx4) << (i * 4);
+    }
+    if (p.maskbits) p.maskbits[(((size_t)b * gridDim.y + blockIdx.y) * 256 + (tid & 255)) * 4 + sp] = mb;
+  }
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  unsigned amax = 0;
+  const float inv_keep = 1.f / p.keep;
+  float psc, pinv;
+  f16x3::scale_of(__float_as_uint(bound), psc, pinv);
+  // output: fp32 [HW][Ct] of image b, or the plane records [Ct / 16][HW][64 B] of image b
+  const rsrc_t yr = p.yplanes ? gn_rsrc(p.yplanes + (size_t)b * HW * Ct * 4, (size_t)HW * Ct * 4)
+                              : gn_rsrc(p.y + (size_t)b * HW * Ct, (size_t)HW * Ct * 4);
+  const unsigned yoff = p.yplanes ? (unsigned)(((c >> 4) * HW + px0) * 64 + (c & 15) * 2) : (unsigned)((px0 * Ct + c) * 4);
+  const unsigned ystep = p.yplanes ? 32u * 64u : (unsigned)(32 * Ct * 4);
+  const f32x2 sc_lo = lo2(ga) * rstd, sc_hi = hi2(ga) * rstd;
+#pragma unroll
+  for (int i = 0; i < SU; ++i) {
+    f32x4 o;
+    {
+      f32x2 u0 = fma2(lo2(v[i]) - mean, sc_lo, lo2(be)), u1 = fma2(hi2(v[i]) - mean, sc_hi, hi2(be));
+      if (p.act) {
+        u0 = u0 * sigmoid_fast2(u0);
+        u1 = u1 * sigmoid_fast2(u1);
+      }
+      o = f32x4{u0[0], u0[1], u1[0], u1[1]};
+    }
+    if (dropping) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = apply_bit(o[e], inv_keep, mb, i * 4 + e);
+    }
+    if (p.yplanes) {
+      gn_st_planes(yr, o, bound, psc, yoff, i * ystep);
+    } else {
+      gn_st4(yr, o, yoff, i * ystep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+    }
+  }
+  if (p.yplanes) amax = __float_as_uint(bound);
+  if (p.ymax) {     // partial maximum number (slab, z block) of image b; unused entries zeroed
+    const int part = blockIdx.y * gridDim.z + blockIdx.z, nparts = gridDim.y * gridDim.z;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+    if ((tid & 63) == 0) ured[tid >> 6] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned m = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m = max(m, ured[w]);
+      p.ymax[b * 16 + part] = m;
+    }
+    if (part == 0 && tid >= nparts && tid < 16) p.ymax[b * 16 + tid] = 0u;
+  }
+}
+
+// UB: pixels per load batch (8: the whole keep-bit word at once; 4, 2: in halves / quarters, each batch fenced from the
+// next so that the register count follows the batch -- UB = 2 fits 64 registers: eight waves per SIMD, or one wave beside
+// a matrix-core block that owns the CU's LDS and seven eighths of its registers)
+template <int NSP, int UB>
+__global__ __launch_bounds__(256 * NSP) __attribute__((amdgpu_waves_per_eu(UB == 2 ? 8 : 4, 8)))
+void gn_bwd_stream_kernel(GnBwdArgs p) {
+  if (p.seed_dev) p.seed ^= p.seed_dev[0];
+  constexpr int NT = 256 * NSP, NW = 4 * NSP, NZ = 4 / NSP;
+  __shared__ float cred[3 * 16 * 32 > NT ? 3 * 16 * 32 : NT];
+  __shared__ unsigned ured[NW];
+  const int tid = threadIdx.x, quad = tid & 7, prow = (tid >> 3) & 31, sp = (tid >> 8) + blockIdx.z * NSP;
+  const int b = blockIdx.x, Ct = p.C1 + p.C2;
+  const int c0 = blockIdx.y * 32;
+  const int cpg = Ct / p.G, qpg = cpg >> 2, csh = 31 - __builtin_clz(cpg);   // (cpg is 4, 8, 16 or 32)
+  const bool first = c0 < p.C1;
+  const int ld = first ? p.C1 : p.C2, cs = first ? c0 : c0 - p.C1;
+  const size_t xbytes = (size_t)HW * ld * 4;
+  const rsrc_t xr = gn_rsrc((first ? p.x1 : p.x2) + (size_t)b * HW * ld, xbytes);
+  const rsrc_t dyr = gn_rsrc(p.dy + (size_t)b * HW * Ct, (size_t)HW * Ct * 4);
+  const float* addp = first ? p.add1 : p.add2;
+  const float* addq = first ? p.add1b : nullptr;
+  const rsrc_t a1r = gn_rsrc(addp ? addp + (size_t)b * HW * ld : nullptr, addp ? xbytes : 0);
+  const rsrc_t a2r = gn_rsrc(addq ? addq + (size_t)b * HW * ld : nullptr, addq ? xbytes : 0);
+  const int c = c0 + quad * 4, g = c >> csh;
+  const int px0 = prow + 256 * sp;
+  const unsigned xoff = (unsigned)((px0 * ld + cs + quad * 4) * 4), xstep = (unsigned)(32 * ld * 4);
+  const unsigned dyoff = (unsigned)((px0 * Ct + c) * 4), dystep = (unsigned)(32 * Ct * 4);
+
+  // (UB = 8) the loads go out before anything else: the statistics / bound / keep-bit loads below overlap them.  The
+  // batched forms load inside the loop: nothing is live across the prologue
+  f32x4 xh[UB], gq[UB];
+  if (UB == SU) {
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      xh[i] = gn_ld4(xr, xoff, i * xstep);
+      gq[i] = gn_ld4(dyr, dyoff, i * dystep);
+    }
+  }
+  const float mean = p.mean[b * p.G + g], rstd = p.rstd[b * p.G + g];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  // the two group sums, from the partial sums the producer of dy left (fixed order: quads of the group, then row tiles)
+  float m1, m2;
+  {
+    const int nq = Ct >> 2;
+    float t1 = 0.f, t2 = 0.f;
+    for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) {
+      const float* st = p.gstats + ((size_t)b * (HW / 256) * nq + qq) * 2;
+#pragma unroll
+      for (int t = 0; t < HW / 256; ++t) { t1 += st[(size_t)t * nq * 2]; t2 += st[(size_t)t * nq * 2 + 1]; }
+    }
+    const float inv_n = 1.f / (float)(HW * cpg);
+    m1 = t1 * inv_n; m2 = t2 * inv_n;
+  }
+  float bound = 0.f;     // planes mode: the a-priori bound of |dx[b]| (see gn_bwd_kernel_1pass)
+  if (p.dx1planes) {
+    const int ln = tid & 63;
+    float rm = 0.f, gm = 0.f, dm = ln < 16 ? __uint_as_float(p.dymax[b * 16 + ln]) : 0.f;
+    for (int gg = ln; gg < p.G; gg += 64) rm = fmaxf(rm, p.rstd[b * p.G + gg]);
+    for (int cc = ln; cc < Ct; cc += 64) gm = fmaxf(gm, fabsf(p.gamma[cc]));
+    rm = wave_max(rm); gm = wave_max(gm); dm = wave_max(dm);
+    bound = ((sqrtf((float)(HW * cpg)) + 2.f) * (p.act ? 1.1f : 1.f)) * rm * gm * (dm / p.keep);
+  }
+  unsigned mb = 0u;
+  const bool dropping = p.keep < 1.f;
+  const float inv_keep = 1.f / p.keep;
+  if (dropping && p.maskbits) {
+    mb = p.maskbits[(((size_t)b * gridDim.y + blockIdx.y) * 256 + (tid & 255)) * 4 + sp];
+  } else if (dropping) {
+    const uint32_t thr = (uint32_t)((double)p.keep * 4294967296.0);
+#pragma unroll
+    for (int i = 0; i < SU; ++i) {
+      const unsigned long long idx4 = (((unsigned long long)b * HW + (px0 + 32 * i)) * Ct + c) >> 2;
+      mb |= drop_bits4(thr, p.seed, p.offset + idx4) << (i * 4);
+    }
+  }
+  float psc, pinv;
+  f16x3::scale_of(__float_as_uint(bound), psc, pinv);
+  // output: fp32 [HW][ld] of image b (dx1 or dx2), or the plane records [C1 / 16][HW][64 B] of image b
+  const rsrc_t or_ = p.dx1planes ? gn_rsrc(p.dx1planes + (size_t)b * HW * Ct * 4, (size_t)HW * Ct * 4)
+                                 : gn_rsrc((first ? p.dx1 : p.dx2) + (size_t)b * HW * ld, xbytes);
+  const unsigned ooff = p.dx1planes ? (unsigned)(((c >> 4) * HW + px0) * 64 + (c & 15) * 2) : xoff;
+  const unsigned ostep = p.dx1planes ? 32u * 64u : xstep;
+  f32x2 dg_lo = {0.f, 0.f}, dg_hi = {0.f, 0.f}, db_lo = {0.f, 0.f}, db_hi = {0.f, 0.f};
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  unsigned amax = 0;
+  // (rolled over the batches: one batch's registers; the scalar offsets advance by a batch per iteration)
+#pragma unroll 1
+  for (int h = 0; h < SU / UB; ++h) {
+    const unsigned hx = (unsigned)(h * UB) * xstep, hd = (unsigned)(h * UB) * dystep, ho = (unsigned)(h * UB) * ostep;
+    if (UB < SU) {
+#pragma unroll
+      for (int i = 0; i < UB; ++i) {
+        xh[i] = gn_ld4(xr, xoff, hx + i * xstep);
+        gq[i] = gn_ld4(dyr, dyoff, hd + i * dystep);
+      }
+    }
+    f32x4 ad1[UB], ad2[UB];
+    if (addp) {
+#pragma unroll
+      for (int i = 0; i < UB; ++i) ad1[i] = gn_ld4(a1r, xoff, hx + i * xstep);
+    }
+    if (addq) {
+#pragma unroll
+      for (int i = 0; i < UB; ++i) ad2[i] = gn_ld4(a2r, xoff, hx + i * xstep);
+    }
+    const unsigned mbh = mb >> (h * UB * 4);
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      if (dropping) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[i][e] = apply_bit(gq[i][e], inv_keep, mbh, i * 4 + e);
+      }
+      f32x4 o;
+      {
+        const f32x2 xa = (lo2(xh[i]) - mean) * rstd, xb = (hi2(xh[i]) - mean) * rstd;
+        f32x2 ga_ = lo2(gq[i]), gb_ = hi2(gq[i]);
+        if (p.act) {
+          const f32x2 ua = fma2(xa, lo2(ga), lo2(be)), ub = fma2(xb, hi2(ga), hi2(be));
+          const f32x2 sa = sigmoid_fast2(ua), sb = sigmoid_fast2(ub);
+          ga_ = ga_ * (sa * fma2(ua, 1.f - sa, f32x2{1.f, 1.f}));      // g * silu'(u)
+          gb_ = gb_ * (sb * fma2(ub, 1.f - sb, f32x2{1.f, 1.f}));
+        }
+        dg_lo = fma2(ga_, xa, dg_lo); dg_hi = fma2(gb_, xb, dg_hi);
+        db_lo += ga_; db_hi += gb_;
+        const f32x2 da = ga_ * lo2(ga), dbv = gb_ * hi2(ga);
+        const f32x2 oa = (da - m1 - xa * m2) * rstd, ob = (dbv - m1 - xb * m2) * rstd;
+        o = f32x4{oa[0], oa[1], ob[0], ob[1]};
+      }
+      if (p.dx1planes) {
+        gn_st_planes(or_, o, bound, psc, ooff, ho + i * ostep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) csum[e] += o[e];
+        continue;
+      }
+      if (addp) { o[0] += ad1[i][0]; o[1] += ad1[i][1]; o[2] += ad1[i][2]; o[3] += ad1[i][3]; }
+      if (addq) { o[0] += ad2[i][0]; o[1] += ad2[i][1]; o[2] += ad2[i][2]; o[3] += ad2[i][3]; }
+      gn_st4(or_, o, ooff, ho + i * ostep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+        csum[e] += o[e];
+      }
+    }
+  }
+  // per-channel partial sums of this block: over the 8 pixel rows of a wave, then over the waves
+  f32x4 dg = {dg_lo[0], dg_lo[1], dg_hi[0], dg_hi[1]}, db = {db_lo[0], db_lo[1], db_hi[0], db_hi[1]};
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); csum[e] += __shfl_xor(csum[e], o, 64);
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cred[wave * 32 + lane * 4 + e] = dg[e];
+      cred[512 + wave * 32 + lane * 4 + e] = db[e];
+      cred[1024 + wave * 32 + lane * 4 + e] = csum[e];
+    }
+  }
+  __syncthreads();
+  const size_t prow_out = (size_t)b * NZ + blockIdx.z;      // this block's row of the partial arrays [B * NZ][Ct]
+  if (tid < 96) {
+    const int k = tid >> 5, ch = tid & 31;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) a += cred[k * 512 + w * 32 + ch];
+    float* dstp = k == 0 ? p.dgamma_part : (k == 1 ? p.dbeta_part : p.dxsum_part);
+    if (dstp) __hip_atomic_store(dstp + prow_out * Ct + c0 + ch, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned* mout = first ? p.dx1max : p.dx2max;
+  if (mout) {
+    const int slab = cs / 32, nslab = ld / 32;
+    const int part = slab * NZ + blockIdx.z, nparts = nslab * NZ;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+    if (lane == 0) ured[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned m = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) m = max(m, ured[w]);
+      mout[b * 16 + part] = p.dx1planes ? __float_as_uint(bound) : m;
+    }
+    if (part == 0 && tid >= nparts && tid < 16) mout[b * 16 + tid] = 0u;
+  }
+  {
+    // final reduction over the samples inside the launch: the hand-off of gn_bwd_kernel_1pass (write-through partials,
+    // every wave drains, barrier, one ticket per block; the block whose ticket comes last sums with sc1 loads, fixed order)
+    __shared__ unsigned s_last;
+    const int R = p.B * NZ;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)R - 1u) ? 1u : 0u;
+      if (s_last) __hip_atomic_store(p.tickets + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+    __syncthreads();
+    if (s_last) {
+      constexpr int LN = NT / 32;                              // row lanes x 32 channels
+      const int ch = tid & 31, sl = tid >> 5;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      const bool want_x = p.dxsum && first;
+      for (int s0 = sl; s0 < R; s0 += LN * 8) {
+        float gsm[8], bt[8], xs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int sm = s0 + LN * u;
+          const size_t o = (size_t)(sm < R ? sm : s0) * Ct + c0 + ch;
+          gsm[u] = __hip_atomic_load(p.dgamma_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bt[u] = __hip_atomic_load(p.dbeta_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          xs[u] = want_x ? __hip_atomic_load(p.dxsum_part + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (s0 + LN * u < R) { a0 += gsm[u]; a1 += bt[u]; a2 += xs[u]; }
+      }
+      float* outs[3] = {p.dgamma, p.dbeta, first ? p.dxsum : nullptr};
+      const float vals[3] = {a0, a1, a2};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        __syncthreads();
+        cred[tid] = vals[k];
+        __syncthreads();
+        if (tid < 32 && outs[k]) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < LN; ++j) t += cred[j * 32 + tid];
+          outs[k][c0 + tid] = t;
+          if (k == 2 && p.dxsum2) p.dxsum2[c0 + tid] = t;
+        }
+      }
+    }
+  }
+}
+
+// The backward streaming kernel as a THIN kernel (round 5 probe): 256 threads (one wave per SIMD), <= 64 registers, 3 KB of
+// LDS, so that its blocks fit on a CU whose other resources a matrix-core block of the weight-gradient stream owns
+// (conv3x3_wgrad_f16x3_planes_kernel: 448 registers, 137 KB).  Compile-time variants instead of run-time flags (every
+// run-time branch of gn_bwd_stream_kernel costs live registers), batches of 2 pixels, and NO final reduction over the
+// samples: the per-block partial rows [B * 4][Ct] are summed by the caller (mulan_colsum_pair or the next launch).
+template <bool PLANES, int NADD, bool DROP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void gn_bwd_thin_kernel(GnBwdArgs p) {
+  if (p.seed_dev) p.seed ^= p.seed_dev[0];
+  constexpr int UB = 2;
+  __shared__ float cred[3 * 4 * 32];
+  __shared__ unsigned ured[4];
+  const int tid = threadIdx.x, quad = tid & 7, prow = tid >> 3, sp = blockIdx.z;
+  const int b = blockIdx.x, Ct = p.C1 + p.C2;
+  const int c0 = blockIdx.y * 32;
+  const int cpg = Ct / p.G, qpg = cpg >> 2, csh = 31 - __builtin_clz(cpg);
+  const bool first = c0 < p.C1;
+  const int ld = first ? p.C1 : p.C2, cs = first ? c0 : c0 - p.C1;
+  const size_t xbytes = (size_t)HW * ld * 4;
+  const int c = c0 + quad * 4, g = c >> csh;
+  const int px0 = prow + 256 * sp;
+  const float mean = p.mean[b * p.G + g], rstd = p.rstd[b * p.G + g];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+  float m1, m2;
+  {
+    const int nq = Ct >> 2;
+    float t1 = 0.f, t2 = 0.f;
+    for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) {
+      const float* st = p.gstats + ((size_t)b * (HW / 256) * nq + qq) * 2;
+#pragma unroll
+      for (int t = 0; t < HW / 256; ++t) { t1 += st[(size_t)t * nq * 2]; t2 += st[(size_t)t * nq * 2 + 1]; }
+    }
+    const float inv_n = 1.f / (float)(HW * cpg);
+    m1 = t1 * inv_n; m2 = t2 * inv_n;
+  }
+  float bound = 0.f;
+  if (PLANES) {
+    const int ln = tid & 63;
+    float rm = 0.f, gm = 0.f, dm = ln < 16 ? __uint_as_float(p.dymax[b * 16 + ln]) : 0.f;
+    for (int gg = ln; gg < p.G; gg += 64) rm = fmaxf(rm, p.rstd[b * p.G + gg]);
+    for (int cc = ln; cc < Ct; cc += 64) gm = fmaxf(gm, fabsf(p.gamma[cc]));
+    rm = wave_max(rm); gm = wave_max(gm); dm = wave_max(dm);
+    bound = ((sqrtf((float)(HW * cpg)) + 2.f) * (p.act ? 1.1f : 1.f)) * rm * gm * (dm / p.keep);
+  }
+  unsigned mb = 0u;
+  const float inv_keep = 1.f / p.keep;
+  if (DROP) {
+    if (p.maskbits) {
+      mb = p.maskbits[(((size_t)b * gridDim.y + blockIdx.y) * 256 + tid) * 4 + sp];
+    } else {
+      const uint32_t thr = (uint32_t)((double)p.keep * 4294967296.0);
+#pragma unroll 1
+      for (int i = 0; i < SU; ++i) {
+        const unsigned long long idx4 = (((unsigned long long)b * HW + (px0 + 32 * i)) * Ct + c) >> 2;
+        mb |= drop_bits4(thr, p.seed, p.offset + idx4) << (i * 4);
+      }
+    }
+  }
+  float psc, pinv;
+  f16x3::scale_of(__float_as_uint(bound), psc, pinv);
+  const rsrc_t xr = gn_rsrc((first ? p.x1 : p.x2) + (size_t)b * HW * ld, xbytes);
+  const rsrc_t dyr = gn_rsrc(p.dy + (size_t)b * HW * Ct, (size_t)HW * Ct * 4);
+  const float* addp = first ? p.add1 : p.add2;
+  const float* addq = first ? p.add1b : nullptr;
+  const rsrc_t a1r = gn_rsrc(NADD >= 1 && addp ? addp + (size_t)b * HW * ld : nullptr, NADD >= 1 && addp ? xbytes : 0);
+  const rsrc_t a2r = gn_rsrc(NADD >= 2 && addq ? addq + (size_t)b * HW * ld : nullptr, NADD >= 2 && addq ? xbytes : 0);
+  const rsrc_t or_ = PLANES ? gn_rsrc(p.dx1planes + (size_t)b * HW * Ct * 4, (size_t)HW * Ct * 4)
+                            : gn_rsrc((first ? p.dx1 : p.dx2) + (size_t)b * HW * ld, xbytes);
+  const unsigned xoff = (unsigned)((px0 * ld + cs + quad * 4) * 4), xstep = (unsigned)(32 * ld * 4);
+  const unsigned dyoff = (unsigned)((px0 * Ct + c) * 4), dystep = (unsigned)(32 * Ct * 4);
+  const unsigned ooff = PLANES ? (unsigned)(((c >> 4) * HW + px0) * 64 + (c & 15) * 2) : xoff;
+  const unsigned ostep = PLANES ? 32u * 64u : xstep;
+  f32x2 dg_lo = {0.f, 0.f}, dg_hi = {0.f, 0.f}, db_lo = {0.f, 0.f}, db_hi = {0.f, 0.f};
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  unsigned amax = 0;
+#pragma unroll 1
+  for (int h = 0; h < SU / UB; ++h) {
+    const unsigned hx = (unsigned)(h * UB) * xstep, hd = (unsigned)(h * UB) * dystep, ho = (unsigned)(h * UB) * ostep;
+    f32x4 xh[UB], gq[UB], ad1[UB], ad2[UB];
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      xh[i] = gn_ld4(xr, xoff, hx + i * xstep);
+      gq[i] = gn_ld4(dyr, dyoff, hd + i * dystep);
+      if (NADD >= 1) ad1[i] = gn_ld4(a1r, xoff, hx + i * xstep);     // (NULL tensor: zero-sized resource, reads 0)
+      if (NADD >= 2) ad2[i] = gn_ld4(a2r, xoff, hx + i * xstep);
+    }
+    const unsigned mbh = mb >> (h * UB * 4);
+#pragma unroll
+    for (int i = 0; i < UB; ++i) {
+      if (DROP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[i][e] = apply_bit(gq[i][e], inv_keep, mbh, i * 4 + e);
+      }
+      f32x4 o;
+      {
+        const f32x2 xa = (lo2(xh[i]) - mean) * rstd, xb = (hi2(xh[i]) - mean) * rstd;
+        f32x2 ga_ = lo2(gq[i]), gb_ = hi2(gq[i]);
+        if (p.act) {
+          const f32x2 ua = fma2(xa, lo2(ga), lo2(be)), ub = fma2(xb, hi2(ga), hi2(be));
+          const f32x2 sa = sigmoid_fast2(ua), sb = sigmoid_fast2(ub);
+          ga_ = ga_ * (sa * fma2(ua, 1.f - sa, f32x2{1.f, 1.f}));
+          gb_ = gb_ * (sb * fma2(ub, 1.f - sb, f32x2{1.f, 1.f}));
+        }
+        dg_lo = fma2(ga_, xa, dg_lo); dg_hi = fma2(gb_, xb, dg_hi);
+        db_lo += ga_; db_hi += gb_;
+        const f32x2 da = ga_ * lo2(ga), dbv = gb_ * hi2(ga);
+        const f32x2 oa = (da - m1 - xa * m2) * rstd, ob = (dbv - m1 - xb * m2) * rstd;
+        o = f32x4{oa[0], oa[1], ob[0], ob[1]};
+      }
+      if (PLANES) {
+        gn_st_planes(or_, o, bound, psc, ooff, ho + i * ostep);
+      } else {
+        if (NADD >= 1) { o[0] += ad1[i][0]; o[1] += ad1[i][1]; o[2] += ad1[i][2]; o[3] += ad1[i][3]; }
+        if (NADD >= 2) { o[0] += ad2[i][0]; o[1] += ad2[i][1]; o[2] += ad2[i][2]; o[3] += ad2[i][3]; }
+        gn_st4(or_, o, ooff, ho + i * ostep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = max(amax, __float_as_uint(o[e]) & 0x7fffffffu);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) csum[e] += o[e];
+    }
+  }
+  f32x4 dg = {dg_lo[0], dg_lo[1], dg_hi[0], dg_hi[1]}, db = {db_lo[0], db_lo[1], db_hi[0], db_hi[1]};
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      dg[e] += __shfl_xor(dg[e], o, 64); db[e] += __shfl_xor(db[e], o, 64); csum[e] += __shfl_xor(csum[e], o, 64);
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cred[wave * 32 + lane * 4 + e] = dg[e];
+      cred[128 + wave * 32 + lane * 4 + e] = db[e];
+      cred[256 + wave * 32 + lane * 4 + e] = csum[e];
+    }
+  }
+  if (!PLANES) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) amax = max(amax, (unsigned)__shfl_xor((int)amax, o, 64));
+    if (lane == 0) ured[wave] = amax;
+  }
+  __syncthreads();
+  if (tid < 96) {
+    const int k = tid >> 5, ch = tid & 31;
+    const float a = (cred[k * 128 + ch] + cred[k * 128 + 32 + ch]) + (cred[k * 128 + 64 + ch] + cred[k * 128 + 96 + ch]);
+    float* dstp = k == 0 ? p.dgamma_part : (k == 1 ? p.dbeta_part : p.dxsum_part);
+    if (dstp) dstp[((size_t)b * 4 + sp) * Ct + c0 + ch] = a;
+  }
+  if (b == 0 && sp == 0 && tid < 32) {     // (probe) the totals this kernel does not form: zeroed, so that a timing run stays finite
+    if (p.dgamma) p.dgamma[c0 + tid] = 0.f;
+    if (p.dbeta) p.dbeta[c0 + tid] = 0.f;
+    if (first && p.dxsum) { p.dxsum[c0 + tid] = 0.f; if (p.dxsum2) p.dxsum2[c0 + tid] = 0.f; }
+  }
+  unsigned* mout = first ? p.dx1max : p.dx2max;
+  if (mout) {
+    const int part = (cs / 32) * 4 + sp, nparts = (ld / 32) * 4;
+    if (tid == 0) mout[b * 16 + part] = PLANES ? __float_as_uint(bound) : max(max(ured[0], ured[1]), max(ured[2], ured[3]));
+    if (part == 0 && tid >= nparts && tid < 16) mout[b * 16 + tid] = 0u;
+  }
+}
+
 }  // namespace
 
 // seed_dev (optional, device memory): the dropout seed is `seed ^ seed_dev[0]`, read by the kernel when it runs -- a
@@ -806,4 +1381,91 @@ MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float*
   return mulan_groupnorm_bwd_dyn(dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part, B, hw,
                                  G, act, keep, seed, offset, nullptr, accumulate, dx1max, dx2max, add1, add2,
                                  dxsum_part, stream);
+}
+
+// ---- streaming forms (round 5): statistics / group sums handed in by the producers, see gn_fwd_stream_kernel.
+// Forward.  Exactly one of y (fp32, + ymax: the true maxima) and yplanes (split planes, + ymax: the bound) is written.
+// xstats1 (, xstats2 when C2 > 0): the partial sums the convolutions that produced x1 (, x2) left in their `ystats`
+// ([B][4][C / 4][2]: sum and sum of squares per image, 8-row tile, channel quad); mean / rstd [B, G] are then outputs.
+// xstats1 == NULL: mean / rstd are inputs (e.g. from mulan_groupnorm_stats).  keepbits (optional, keep < 1): the
+// keep-bits as drawn, in the layout of mulan_groupnorm_fwd_planes_keepbits.
+MULAN_API int mulan_groupnorm_fwd_stream(const float* x1, const float* x2, int C1, int C2, const float* gamma,
+                                         const float* beta, float* y, void* yplanes, float* mean, float* rstd,
+                                         const float* xstats1, const float* xstats2, int B, int hw, int G, float eps,
+                                         int act, float keep, unsigned long long seed, unsigned long long offset,
+                                         const unsigned long long* seed_dev, unsigned* ymax, unsigned* keepbits,
+                                         hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !mean || !rstd || (!y == !yplanes) || !(keep > 0.f) ||
+      (yplanes && !ymax) || (xstats1 && C2 > 0 && !xstats2) || (keepbits && !(keep < 1.f)))
+    return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || C1 % cpg != 0 || (ymax && Ct / 32 > 16))
+    return (int)hipErrorInvalidValue;
+  GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev,
+           static_cast<unsigned char*>(yplanes), keepbits, 0, xstats1, xstats2};
+  // tune[20] (dev A/B): quarters of a slab per block -- 0 / 4: 1024 threads, 2: 512, 1: 256 (the maxima array has 16
+  // entries per image: (slabs) x (z blocks) must fit)
+  int nsp = g_mulan_tune[20] == 1 ? 1 : (g_mulan_tune[20] == 2 ? 2 : 4);
+  while (ymax && !yplanes && (Ct / 32) * (4 / nsp) > 16) nsp *= 2;
+  const dim3 grid(B, Ct / 32, 4 / nsp);
+  if (nsp == 1) hipLaunchKernelGGL(gn_fwd_stream_kernel<1>, grid, dim3(256), 0, stream, a);
+  else if (nsp == 2) hipLaunchKernelGGL(gn_fwd_stream_kernel<2>, grid, dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL(gn_fwd_stream_kernel<4>, grid, dim3(1024), 0, stream, a);
+  MULAN_CHECK_LAUNCH();
+}
+
+// Backward (the arguments of mulan_groupnorm_bwd_fused / _fused_planes in one entry point).  gstats [B][4][(C1 + C2) / 4][2]:
+// the partial sums of g gamma and g gamma xhat (g = dy mask / keep act'(u)) per image, 8-row tile and channel quad, as the
+// input-gradient convolution that wrote dy left them (mulan_conv3x3_fwd_f16x3_gstats / _planes_in_gstats).  dx1planes
+// (optional; then C2 == 0, no add*, dymax required): dx1 as split planes instead of fp32, dx1max receives the bound.
+MULAN_API int mulan_groupnorm_bwd_stream(const float* dy, const unsigned* dymax, const float* x1, const float* x2, int C1,
+                                         int C2, const float* gamma, const float* beta, const float* mean,
+                                         const float* rstd, const float* gstats, float* dx1, float* dx2, void* dx1planes,
+                                         float* dgamma_part, float* dbeta_part, int B, int hw, int G, int act, float keep,
+                                         unsigned long long seed, unsigned long long offset,
+                                         const unsigned long long* seed_dev, unsigned* dx1max, unsigned* dx2max,
+                                         const float* add1, const float* add2, const float* add1b, float* dxsum_part,
+                                         float* dgamma, float* dbeta, float* dxsum, float* dxsum2, unsigned* tickets,
+                                         const unsigned* keepbits, hipStream_t stream) {
+  const int Ct = C1 + C2;
+  if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !gstats || !tickets || !dgamma || !dbeta || !dgamma_part ||
+      !dbeta_part || (dxsum && !dxsum_part) || (dxsum2 && !dxsum) || Ct / 32 > 16 || !(keep > 0.f) ||
+      (!dx1 == !dx1planes) || (C2 > 0 && !dx2) ||
+      (dx1planes && (C2 != 0 || add1 || add1b || !dymax || !dx1max || (size_t)B * HW * C1 * 4 >= 0x80000000ull)))
+    return (int)hipErrorInvalidValue;
+  const int cpg = Ct / G;
+  if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0) return (int)hipErrorInvalidValue;
+  GnBwdArgs a{dy, x1, x2, C1, C2, gamma, beta, mean, rstd, dx1, dx2, dgamma_part, dbeta_part,
+              B, G, act, keep, seed, offset, 0, dx1max, dx2max, add1, add2, dxsum_part, seed_dev, tickets, dgamma, dbeta,
+              dxsum, dxsum2, static_cast<unsigned char*>(dx1planes), dymax, keep < 1.f ? keepbits : nullptr, add1b, gstats};
+  // tune[21] (dev A/B): quarters of a slab per block (as tune[20]); tune[22] = 1 / 2: load batches of 4 / 2 pixels instead of 8.
+  // The per-block partial rows are [B * 4 / nsp][Ct]: dgamma_part / dbeta_part / dxsum_part must hold 4 B rows.
+  int nsp = g_mulan_tune[21] == 1 ? 1 : (g_mulan_tune[21] == 2 ? 2 : 4);
+  const int C12 = C1 > C2 ? C1 : C2;
+  if (g_mulan_tune[21] == 3 && (C12 / 32) * 4 <= 16) {
+    // (dev probe) the thin kernel: no reduction over the samples -- dgamma / dbeta / dxsum are NOT written
+    const dim3 grid(B, Ct / 32, 4);
+    const int nadd = add1b ? 2 : ((add1 || add2) ? 1 : 0);
+    const bool drop = keep < 1.f;
+#define MULAN_GN_THIN(PL, NA)                                                                                     \
+  if (drop) hipLaunchKernelGGL((gn_bwd_thin_kernel<PL, NA, true>), grid, dim3(256), 0, stream, a);                \
+  else hipLaunchKernelGGL((gn_bwd_thin_kernel<PL, NA, false>), grid, dim3(256), 0, stream, a);
+    if (dx1planes) { MULAN_GN_THIN(true, 0) }
+    else if (nadd == 2) { MULAN_GN_THIN(false, 2) }
+    else if (nadd == 1) { MULAN_GN_THIN(false, 1) }
+    else { MULAN_GN_THIN(false, 0) }
+#undef MULAN_GN_THIN
+    MULAN_CHECK_LAUNCH();
+  }
+  while ((dx1max || dx2max) && (C12 / 32) * (4 / nsp) > 16) nsp *= 2;
+  const dim3 grid(B, Ct / 32, 4 / nsp);
+  const int ub = g_mulan_tune[22];
+#define MULAN_GN_BWD_STREAM(NSP)                                                                                  \
+  if (ub == 1) hipLaunchKernelGGL((gn_bwd_stream_kernel<NSP, 4>), grid, dim3(256 * NSP), 0, stream, a);           \
+  else if (ub == 2) hipLaunchKernelGGL((gn_bwd_stream_kernel<NSP, 2>), grid, dim3(256 * NSP), 0, stream, a);      \
+  else hipLaunchKernelGGL((gn_bwd_stream_kernel<NSP, 8>), grid, dim3(256 * NSP), 0, stream, a);
+  if (nsp == 1) { MULAN_GN_BWD_STREAM(1) } else if (nsp == 2) { MULAN_GN_BWD_STREAM(2) } else { MULAN_GN_BWD_STREAM(4) }
+#undef MULAN_GN_BWD_STREAM
+  MULAN_CHECK_LAUNCH();
 }

@@ -59,6 +59,9 @@ SIGNATURES = {
     "mulan_groupnorm_bwd_fused": [P, P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, P, P, P, P, P, P, P, P, P, P, P, P, P],
     "mulan_groupnorm_bwd_fused_planes": [P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, F, U, U, P, P, P, P, P, P, P, P, P, P],
     "mulan_groupnorm_fwd_planes_keepbits": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P, P, P],
+    "mulan_groupnorm_fwd_stream": [P, P, I, I, P, P, P, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P, P, P],
+    "mulan_groupnorm_bwd_stream": [P, P, P, P, I, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, U, U, P, P, P, P, P, P, P,
+                                   P, P, P, P, P, P, P],
     "mulan_act_fwd": [P, P, Z, I, F, P],
     "mulan_act_bwd": [P, P, P, Z, I, P],
     "mulan_colsum": [P, P, I, I, I, I, I, P],

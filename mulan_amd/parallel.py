@@ -96,6 +96,7 @@ class GradReducer:
         self.capture = None         # while / after a capture: {"order": [bucket, ...], "events": {bucket: handle}}
         self.pending = [0] * len(self.buckets)
         self.ready_order = []       # bucket indices in the order they were launched in the last backward
+        self.eager_order = []       # ... in the order an eager (hook-driven) step launched them: allreduce_now follows it
         self.works = []
         self.launched = [False] * len(self.buckets)
         if self.enabled:
@@ -207,9 +208,11 @@ class GradReducer:
         # the node becomes a link of the weight-gradient branch (the branch that reaches this point last: the main chain
         # runs ahead of it), so it fires at its place in the backward pass; as a leaf HIP's executor ran it when the main
         # branch had drained (all buckets but the last released together 4.7 ms before the end of the graph)
-        if os.environ.get("MULAN_EVENT_NODE_CHAIN", "1") != "1":
-            chain = None
-        lib.check(L.mulan_event_record_external(ev, self.side.cuda_stream, chain), "mulan_event_record_external")
+        # (MULAN_EVENT_NODE_CHAIN=0: dev A/B of the EVENT node's placement only -- as a leaf instead of a link of the
+        # weight-gradient branch.  It must not move the signal kernel below: that one always goes behind the bucket's last
+        # weight gradient, or the all-reduce would read gradients the weight-gradient stream has not written yet.)
+        ev_chain = chain if os.environ.get("MULAN_EVENT_NODE_CHAIN", "1") == "1" else None
+        lib.check(L.mulan_event_record_external(ev, self.side.cuda_stream, ev_chain), "mulan_event_record_external")
         sig = self.capture["signals"]
         if sig is not None:
             # the hand-off that works (see allreduce_captured): a one-thread kernel node that stores this replay's tick
@@ -342,16 +345,24 @@ class GradReducer:
 
     def allreduce_now(self):
         """All buckets at once, after a graph-replayed backward (no hooks ran): same result as prepare() ... finish(),
-        without the overlap."""
+        without the overlap.  The buckets go out in the order an eager step launches them (`eager_order`, recorded by the
+        eager step every run starts with): a collective sequence must be the same on every rank, also when one rank runs
+        a step eagerly while the others replay theirs (a rank whose capture failed, bench.py's timed kernel step on rank 0
+        before round 5) -- found by the 8-rank shared-GPU test: gloo aborted on mismatched sizes, RCCL would hang."""
         if not self.enabled:
             return
         self.prepare()
+        for bi in self.eager_order:
+            if not self.launched[bi]:
+                self._launch(bi)
         self.finish()
 
     def finish(self):
         """Launch whatever did not fire (unused leaves), then make the compute stream wait for all buckets."""
         if not self.enabled:
             return
+        if not self.paused and len(self.ready_order) > len(self.eager_order):
+            self.eager_order = list(self.ready_order)      # (complete only once every hooked bucket has fired)
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)

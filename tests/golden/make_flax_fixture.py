@@ -8,7 +8,9 @@ What flax.serialization writes (flax 0.7.0, the version the reference pins; ldm/
   * ndarray       -> ext type 1 whose payload is packb((shape, dtype.name, tobytes('C')), use_bin_type=True);
   * numpy scalar  -> ext type 3, same payload with shape ();
   * arrays above 2**30 bytes -> {'__msgpack_chunked_array__': True, 'shape': {'0': d0, ..}, 'chunks': {'0': ext1, ..}};
-  * optax.MaskedNode() (a masked-out leaf of optax.masked) -> empty map.
+  * optax.MaskedNode() (a masked-out leaf of optax.masked) -> empty map;
+  * the optimizer state of ldm/experiment.py:160-170 (two optax.masked AdamW instances split by score_model / the rest):
+    {'0': {'inner_state': {'0': {count, mu, nu}, '1': {'inner_state': {}}, '2': {}}}, '1': {... the same shape}}.
 msgpack headers used: fixmap 0x80|n, fixarray 0x90|n, fixstr 0xa0|n, str8 0xd9, positive fixint, uint8 0xcc,
 uint16 0xcd, true 0xc3, bin8 0xc4, bin16 0xc5, fixext4/8/16 0xd6/0xd7/0xd8, ext8 0xc7, ext16 0xc8.
 Run in the build container: `python tests/golden/make_flax_fixture.py`.
@@ -114,8 +116,10 @@ def build_bytes():
 
     # the gamma network under its attribute names (model_mulan_epsilon.py:493-512; checkpoint.GAMMA_NET_ALIASES)
     alias = {"dense_1": "l1"}
-    decayed = lambda path: path[-1] != "bias"            # experiment.py:139-146: the first masked AdamW holds the decayed
-    not_decayed = lambda path: path[-1] == "bias"        # leaves, the second one the rest
+    # ldm/experiment.py:160-170: chain(masked(adamw, score_model leaves), masked(adamw, the rest)) -- the two optax.masked
+    # states split the tree by its TOP-LEVEL module, not by the decay mask (that one sits inside each adamw)
+    score = lambda path: path[0] == "score_model"
+    not_score = lambda path: path[0] != "score_model"
     # norm_out/scale (96 bytes) goes out chunked, 16 elements per chunk, in ema_params only
     def ema_leaf(v):
         return p_chunked(v, 16) if v.size == 24 else p_ndarray(v)
@@ -124,9 +128,12 @@ def build_bytes():
         return p_map([("count", p_ndarray(np.asarray(223, dtype=np.int32))),
                       ("mu", tree(t["opt_state"]["mu"], keep=keep, names=alias)),
                       ("nu", tree(t["opt_state"]["nu"], keep=keep, names=alias))])
+    # optax.adamw(mask=decay_mask_fn) = chain(scale_by_adam, add_decayed_weights(mask), scale(-lr)): ScaleByAdamState,
+    # MaskedState(inner_state=AddDecayedWeightsState()) -> {'inner_state': {}}, ScaleState() -> {}
     empty = p_map([])
-    opt = p_map([("0", p_map([("inner_state", p_map([("0", adam(decayed)), ("1", empty), ("2", empty)]))])),
-                 ("1", p_map([("inner_state", p_map([("0", adam(not_decayed)), ("1", empty), ("2", empty)]))]))])
+    masked_decay = p_map([("inner_state", empty)])
+    opt = p_map([("0", p_map([("inner_state", p_map([("0", adam(score)), ("1", masked_decay), ("2", empty)]))])),
+                 ("1", p_map([("inner_state", p_map([("0", adam(not_score)), ("1", masked_decay), ("2", empty)]))]))])
     return p_map([("step", p_npscalar(np.int32(223))),
                   ("params", p_map([("params", tree(t["params"], names=alias))])),       # one wrapping level, as Flax variables
                   ("ema_params", tree(t["ema_params"], leaf=ema_leaf, names=alias)),

@@ -657,8 +657,14 @@ def test_load_flax_reads_bytes_it_did_not_write():
     assert msgpack.packb(generic, use_bin_type=True) == raw
     assert isinstance(generic["step"], msgpack.ExtType) and generic["step"].code == 3
     assert generic["ema_params"]["score_model"]["norm_out"]["scale"]["__msgpack_chunked_array__"] is True
-    assert generic["opt_state"]["0"]["inner_state"]["0"]["mu"]["gamma"]["l1"]["bias"] == {}        # masked-out leaf
-    assert generic["opt_state"]["1"]["inner_state"]["0"]["mu"]["gamma"]["l1"]["kernel"] == {}
+    # ldm/experiment.py:160-170: masked AdamW number 0 holds the score_model leaves, number 1 the rest; a masked-out leaf
+    # is an empty map; each adamw's add_decayed_weights(mask=...) state is itself a MaskedState: {'inner_state': {}}
+    adam0, adam1 = generic["opt_state"]["0"]["inner_state"], generic["opt_state"]["1"]["inner_state"]
+    assert adam0["0"]["mu"]["gamma"]["l1"]["bias"] == {} and adam0["0"]["mu"]["gamma"]["l1"]["kernel"] == {}
+    assert adam1["0"]["mu"]["score_model"]["conv_out"]["kernel"] == {} and adam1["0"]["nu"]["score_model"]["norm_out"]["scale"] == {}
+    assert isinstance(adam0["0"]["mu"]["score_model"]["conv_out"]["kernel"], msgpack.ExtType)
+    assert isinstance(adam1["0"]["mu"]["gamma"]["l1"]["kernel"], msgpack.ExtType)
+    assert adam0["1"] == {"inner_state": {}} and adam1["1"] == {"inner_state": {}} and adam0["2"] == {} and adam1["2"] == {}
     got = ck.load_flax(path)
     want = fx.expected_tree()
     assert got["step"] == 223 and isinstance(got["step"], int)

@@ -12,6 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests.oracle_dev import run_oracle
 from oracle import torch_ref as tr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,8 +60,8 @@ def test_flax_checkpoint_through_eval_bpd_matches_oracle(tmp_path, config_file, 
     with torch.no_grad():
         for i in range(len(imgs)):
             x = torch.tensor(np.repeat(imgs[i:i + 1], T, axis=0))
-            o = tr.mulan_forward(half, ocfg, x, float(noise["t0"]), noise["gamma_raw"].double().cpu(),
-                                 noise["eps_0"].double().cpu().view(T, 32, 32, 3), noise["eps"].double().cpu().view(T, 32, 32, 3))
+            o = run_oracle(lambda P, *a: tr.mulan_forward(P, ocfg, *a), half, x, float(noise["t0"]), noise["gamma_raw"].double().cpu(),
+                           noise["eps_0"].double().cpu().view(T, 32, 32, 3), noise["eps"].double().cpu().view(T, 32, 32, 3))
             want.append(float(o["bpd"]))
     print(f"{config_file} E={E}: eval_bpd dense {got:.6f} vs oracle {np.mean(want):.6f}")
     assert abs(got - np.mean(want)) < 0.005, (got, want)

@@ -9,6 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests.oracle_dev import run_oracle
 from oracle import torch_ref as tr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,8 +53,10 @@ def _eval_noise(exp, B):
 
 def _oracle_bpd(ref_params, ocfg, x_u8, noise):
     B = x_u8.shape[0]
-    out = tr.mulan_forward(ref_params, ocfg, torch.as_tensor(x_u8), float(noise["t0"]), noise["gamma_raw"].double().cpu(),
-                           noise["eps_0"].double().cpu().view(B, 32, 32, 3), noise["eps"].double().cpu().view(B, 32, 32, 3))
+    with torch.no_grad():
+        out = run_oracle(lambda P, *a: tr.mulan_forward(P, ocfg, *a), ref_params, torch.as_tensor(x_u8), float(noise["t0"]),
+                         noise["gamma_raw"].double().cpu(), noise["eps_0"].double().cpu().view(B, 32, 32, 3),
+                         noise["eps"].double().cpu().view(B, 32, 32, 3))
     return float(out["bpd"])
 
 

@@ -552,3 +552,41 @@ def test_randn_moments(ops):
     assert np.array_equal(z, z2)
     z3 = ops.randn((1 << 20,), 1235, 0, "cuda").cpu().double().numpy()
     assert abs(np.corrcoef(z, z3)[0, 1]) < 5e-3
+
+
+def test_oracle_is_the_same_on_host_and_device(monkeypatch):
+    """tests/oracle_dev.run_oracle runs the float64 oracle's own torch code with its tensors on the GPU (the heavy parity
+    tests are bound by the oracle's host time).  IEEE double either way: forward terms and every parameter gradient of one
+    training-mode pass agree between host and device to 1e-9 of their scale -- seven orders below any bar a HIP kernel is
+    held to."""
+    from oracle import torch_ref as tr
+    from tests.oracle_dev import run_oracle
+    from tests.test_gpu_model import block_names, make_cfg, oracle_masks
+    from mulan_amd.rng import PRNGKey
+    _, ocfg = make_cfg("mulan_velocity", "vdm", True)
+    B = 2
+    rng = np.random.default_rng(5)
+    x = torch.tensor(rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8))
+    raw = torch.tensor(rng.gamma(1.0 / 15, size=(10, B, 50)))
+    e0, e = (torch.tensor(rng.standard_normal((B, 32, 32, 3))) for _ in range(2))
+    k_enc, k_score = PRNGKey(7).split(2)
+    masks = dict(enc_masks=oracle_masks(block_names(1, False), k_enc, B, 128, 0.9),
+                 score_masks=oracle_masks(block_names(1, True), k_score, B, 128, 0.9))
+    keep = float(np.float32(0.9))
+    res = {}
+    for dev_name in ("cpu", "cuda"):
+        monkeypatch.setenv("MULAN_ORACLE_DEVICE", dev_name)
+        params = tr.init_params(ocfg, seed=21, dtype=torch.float64)
+        for _, leaf in tr.tree_leaves(params):
+            leaf.requires_grad_(True)
+        out = run_oracle(lambda P, *a, **k: tr.mulan_forward(P, ocfg, *a, keep=keep, **k), params, x, 0.3, raw, e0, e,
+                         backward="bpd", **masks)
+        res[dev_name] = (out, {"/".join(p): l.grad.clone() for p, l in tr.tree_leaves(params) if l.grad is not None})
+    (oc, gc), (od, gd) = res["cpu"], res["cuda"]
+    for k in ("bpd", "loss_recon", "loss_klz", "loss_diff"):
+        assert float((oc[k] - od[k]).abs().max()) <= 1e-9 * float(oc[k].abs().max()), k
+    assert sorted(gc) == sorted(gd) and len(gc) > 50
+    gmax = max(float(v.abs().max()) for v in gc.values())
+    for k in gc:      # (1e-13 of the largest gradient: the key bias of the attention block has a gradient that is zero
+        #                 identically -- softmax ignores a constant added to a row of scores -- and holds rounding noise)
+        assert float((gc[k] - gd[k]).abs().max()) <= 1e-9 * float(gc[k].abs().max()) + 1e-13 * gmax, k

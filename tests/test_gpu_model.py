@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 from oracle import mulan_np as onp
 from oracle import torch_ref as tr
 
+from tests.oracle_dev import run_oracle
+
 
 def make_cfg(vdm_type="mulan_velocity", unet_type="vdm", vfe=False, n_layer=1, fwd_layers=1, E=128, with_attention=False):
     from mulan_amd.model import VDMConfig
@@ -77,9 +79,10 @@ def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=Fal
         enc_masks = oracle_masks(block_names(fwd_layers, False), k_enc, B, E, 0.9)
         score_masks = oracle_masks(block_names(n_layer, True), k_score, B, E, 0.9)
         rngs = {"dropout": dkey}
-    ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), t0, torch.tensor(raw),
-                           torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3),
-                           enc_masks=enc_masks, score_masks=score_masks, keep=keep)
+    # (the oracle's float64 pass -- and, in training mode, its backward pass -- through tests/oracle_dev.run_oracle)
+    ref = run_oracle(lambda P, *a, **k: tr.mulan_forward(P, ocfg, *a, keep=keep, **k), ref_params, torch.tensor(x), t0,
+                     torch.tensor(raw), torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3),
+                     enc_masks=enc_masks, score_masks=score_masks, backward="bpd" if train else None)
     out, aux = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs=rngs, deterministic=not train,
                          noise=noise, return_aux=True)
     rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
@@ -96,7 +99,6 @@ def run_case(vdm_type, unet_type, vfe, train, E=128, tol=1.0, with_attention=Fal
     assert abs(float(bpd) - float(ref["bpd"])) < 0.005, (float(bpd), float(ref["bpd"]))
     if not train:
         return
-    ref["bpd"].backward()
     bpd.backward()
     flax_grads = M.to_flax_layout(M.tree_map(lambda t: t.grad if t.grad is not None else torch.zeros_like(t), params))
     worst = []
@@ -282,8 +284,8 @@ def test_full_depth_forward_bpd_parity():
     f32 = lambda a: torch.tensor(a, dtype=torch.float32).cuda()
     noise = dict(t0=0.41, gamma_raw=f32(raw), eps_0=f32(e0), eps=f32(e))
     with torch.no_grad():
-        ref = tr.mulan_forward(ref_params, ocfg, torch.tensor(x), 0.41, torch.tensor(raw),
-                               torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3))
+        ref = run_oracle(lambda P, *a: tr.mulan_forward(P, ocfg, *a), ref_params, torch.tensor(x), 0.41, torch.tensor(raw),
+                         torch.tensor(e0).view(B, 32, 32, 3), torch.tensor(e).view(B, 32, 32, 3))
         out, aux = vdm.apply(params, torch.tensor(x).cuda(), None, None, step=0, rngs=None, deterministic=True,
                              noise=noise, return_aux=True)
     rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
@@ -446,8 +448,8 @@ def test_gradient_sink_equals_autograd_accumulation():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("graph,launcher,configs", [("", "self", True), ("0", "torchrun", False)])
-def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
+@pytest.mark.parametrize("graph,launcher,configs,world", [("", "self", True, 2), ("0", "torchrun", False, 2), ("", "self", True, 8)])
+def test_bench_ranks_share_one_gpu(graph, launcher, configs, world):
     """bench.py's N > 1 control flow (sharded batches, bucketed side-stream all-reduce, barriers, max-over-ranks timing,
     rank-0 JSON) with two ranks on the one GPU of this box.  RCCL refuses two ranks per device, so the collective
     backend is gloo over the device tensors here; the calls are the same torch.distributed ones.  graph = "": the
@@ -471,38 +473,47 @@ def test_bench_two_ranks_share_one_gpu(graph, launcher, configs):
     port = s.getsockname()[1]
     s.close()
     env = {**os.environ, "MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"}
-    for k in ("MULAN_HIP_GRAPH", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    for k in ("MULAN_HIP_GRAPH", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MULAN_GRAPH_OVERLAP"):
         env.pop(k, None)
     if graph:
         env["MULAN_HIP_GRAPH"] = graph
-    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--per-gpu-batch", "8",
-            "--also-steps", "2"] + (["--configs-small"] if configs else ["--no-also-configs"])
+    overlap = graph != "0" and world == 2
+    if overlap:
+        env["MULAN_GRAPH_OVERLAP"] = "1"       # opt-in (round 5): replay + signal hand-off; the 8-rank run keeps the default
+    # all three use --small-depth (1 or 2 ResnetBlocks per stage: the control flow, not the sizes -- the full depth runs in
+    # every other whole-model test and in every `python bench.py`); 8 ranks: 4 images per rank
+    per = 8 if world == 2 else 4
+    args = [os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--per-gpu-batch", str(per),
+            "--also-steps", "2"] + (["--configs-small", "--small-depth", "1"] if configs
+                                    else ["--no-also-configs", "--small-depth", "2"])
     if launcher == "self":
         cmd = [sys.executable] + args
     else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=840, env=env, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["n_gpus"] == world and out["config"]["global_batch"] == per * world and out["value"] > 0
     assert out["roofline"] is not None and out["cpu_baseline"] is None
+    assert out.get("test_depth") == (1 if configs else 2)
     if configs:
         c = out["configs"]
         assert set(c) == {"3", "4", "5", "sampler", "ode"}
-        assert c["3"]["global_batch"] == 32 and c["4"]["global_batch"] == 16 and c["3"]["value"] > 0 and c["4"]["value"] > 0
-        assert "sharded over 2 rank(s)" in c["5"]["workload"] and c["5"]["value"] > 0 and math.isfinite(c["5"]["bpd_random_init"])
+        # configs[2]: the GLOBAL batch 32 split over the ranks (512 // world at full size); configs[3]: 8 images per rank
+        assert c["3"]["global_batch"] == 32 and c["4"]["global_batch"] == 8 * world and c["3"]["value"] > 0 and c["4"]["value"] > 0
+        assert f"sharded over {world} rank(s)" in c["5"]["workload"] and c["5"]["value"] > 0 and math.isfinite(c["5"]["bpd_random_init"])
         assert c["sampler"]["finite"] and c["sampler"]["value"] > 0 and c["ode"]["finite"] and c["ode"]["nfev"] >= 8
     else:
         assert out["configs"] is None
     assert out["hip_graph"] == (graph != "0")
     assert out["collective"]["backend"] == "gloo" and out["collective"]["rccl_ranks"] == 0    # (nccl on a multi-GPU node)
     ov = out["collective"]["replay_overlap"]
-    if graph != "0":
+    if overlap:
         assert ov["handoff"] == "signal" and len(ov["marked"]) >= 2 and len(ov["released_ms_before_graph_end"]) == len(ov["marked"])
         assert max(ov["released_ms_before_graph_end"]) > 0.5          # some bucket was released before the graph ended
-    else:
+    else:      # eager overlapped step, or the default multi-rank replay: collectives behind the graph
         assert ov is None
 
 
@@ -526,6 +537,8 @@ def test_two_rank_replayed_step_overlaps_the_allreduce_and_equals_the_eager_step
     port = s.getsockname()[1]
     s.close()
     env = {**os.environ, "MULAN_BUCKET_MB": "16", "MULAN_OVERLAP_SIGNAL": "1" if handoff == "signal" else "0"}
+    if handoff == "event":       # the fallback hand-off: one model is enough (the signal form runs both)
+        env["MULAN_CHECK_MODELS"] = "mulan_epsilon"
     if torch.cuda.device_count() < 2:
         env.update({"MULAN_DIST_BACKEND": "gloo", "MULAN_FORCE_DEVICE": "0"})
     for k in ("MULAN_HIP_GRAPH", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MULAN_GRAPH_OVERLAP"):

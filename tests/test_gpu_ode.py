@@ -10,6 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests.oracle_dev import on_device, params_on_device
 from oracle import torch_ref as tr
 from tests.test_gpu_model import make_cfg
 
@@ -188,10 +189,11 @@ def test_reverse_ode_value_and_divergence(vdm_type, unet_type, vfe):
     assert _rel(ctx["kl"].cpu().numpy(), tr.gumbel_kl_loss(logits).numpy()) < 1e-4
     x = rng.standard_normal((B, 3072)).astype(np.float32)
     h = (rng.integers(0, 2, (B, 3072)) * 2.0 - 1.0).astype(np.float32)
+    dev_params = params_on_device(ref_params)
     for t in (0.0, 0.37, 1.0):
         drift, div = vdm.reverse_ode(params, torch.tensor(x).cuda(), ctx, t, torch.tensor(h).cuda())
         xr = torch.tensor(x, dtype=torch.float64).reshape(B, 32, 32, 3).requires_grad_(True)
-        f = tr.reverse_ode(ref_params, ocfg, xr, emb, t)
+        f = on_device(lambda xx, ee: tr.reverse_ode(dev_params, ocfg, xx, ee, t))(xr, emb)
         hr = torch.tensor(h, dtype=torch.float64).reshape(B, 32, 32, 3)
         (g,) = torch.autograd.grad((f * hr).sum(), xr)
         div_ref = (g * hr).reshape(B, -1).sum(dim=1).numpy()
@@ -266,9 +268,10 @@ def test_ode_likelihood_matches_oracle(vdm_type, vfe, deq):
     probe = ops.noise((B, 3072), 12, 0, "cuda", "rademacher")
     fn = get_ode_likelihood_fn(_FakeExperiment(vdm, params), rtol=1e-3, atol=1e-3, dequantization=deq)
     E, FL = ocfg["n_embd"], ocfg["forward_n_layer"]
-    oracle = lambda **kw: tr.ode_likelihood(
-        lambda x, emb, t: tr.reverse_ode(ref_params, ocfg, x, emb, t),
-        lambda im: tr.unet_encoder(tr.encode(im), ref_params["encoder_model"], E, FL),
+    dev_params = params_on_device(ref_params)       # the oracle's network evaluations on its device (tests/oracle_dev.py);
+    oracle = lambda **kw: tr.ode_likelihood(        # the integrator (scipy / the fixed grid) stays on the host
+        on_device(lambda x, emb, t: tr.reverse_ode(dev_params, ocfg, x, emb, t)),
+        on_device(lambda im: tr.unet_encoder(tr.encode(im), dev_params["encoder_model"], E, FL)),
         img, u.cpu().double(), lambda: probe.cpu().double(), dequantization=deq, rtol=1e-3, atol=1e-3, **kw)
     grid = [0.0, 0.04, 0.14, 0.32, 0.55, 0.8, 1.0]
     log_p, log_q, aux, info = fn(PRNGKey(0), img.cuda(), deterministic_noise=True, u=u, probes=lambda: probe, t_grid=grid)
@@ -312,7 +315,8 @@ def test_ode_sampler_matches_oracle():
     rng, _ = rng.split()
     rng, prior_rng = rng.split()
     prior = prior_rng.normal((n, 3072), "cuda")
-    z_ref, nfev_ref = tr.ode_sample(lambda x, e, t: tr.reverse_ode(ref_params, ocfg, x, e, t), emb.cpu().double(),
+    dev_params = params_on_device(ref_params)
+    z_ref, nfev_ref = tr.ode_sample(on_device(lambda x, e, t: tr.reverse_ode(dev_params, ocfg, x, e, t)), emb.cpu().double(),
                                     prior.cpu().double(), rtol=1e-4, atol=1e-4)
     assert abs(nfev - nfev_ref) <= 6, (nfev, nfev_ref)
     assert _rel(z.cpu().numpy(), z_ref.numpy()) < 2e-3

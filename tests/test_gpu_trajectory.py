@@ -31,10 +31,11 @@ pytestmark = pytest.mark.gpu
 from oracle import mulan_np as onp
 from oracle import torch_ref as tr
 
+from tests.oracle_dev import run_oracle
 from tests.test_gpu_model import block_names, oracle_masks
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-B, E, STEPS, WARMUP = 4, 128, 4, 2
+B, E, STEPS, WARMUP = 4, 128, 3, 2
 ONE_ELEMENT_BAR = 5e-2
 
 
@@ -121,9 +122,9 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
             d[p[-1]] = t
             leaves[p] = t
         si = step_inputs[k]
-        out = tr.mulan_forward(tree, ocfg, batches[k], si["t0"], si["raw"], si["e0"], si["e"],
-                               enc_masks=si["enc_masks"], score_masks=si["score_masks"], keep=keep)
-        out["bpd"].backward()
+        out = run_oracle(lambda P, *a, **kw: tr.mulan_forward(P, ocfg, *a, keep=keep, **kw), tree, batches[k], si["t0"],
+                         si["raw"], si["e0"], si["e"], enc_masks=si["enc_masks"], score_masks=si["score_masks"],
+                         backward="bpd")
         return float(out["bpd"].detach()), {p: (leaves[p].grad.numpy() if leaves[p].grad is not None
                                                 else np.zeros(tuple(leaves[p].shape))) for p in paths}
 

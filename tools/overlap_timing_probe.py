@@ -73,7 +73,6 @@ def main():
     dist.all_reduce = counted_all_reduce if a.rccl else standin_all_reduce
 
     def run(hip_graph, overlap):
-        E.GRAPH_OVERLAP = overlap
         config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
         config.data.dataset = "synthetic"
         config.training.batch_size_train = a.batch
@@ -81,7 +80,8 @@ def main():
         config.training.substeps = 1
         config.training.hip_graph = hip_graph
         exp = E.Experiment_VDM(config)
-        exp.world = a.ranks                           # the step applies 1 / N and keeps the optimizer outside the graph
+        exp.world = a.ranks
+        exp.graph_overlap = bool(overlap)             # (opt-in since round 5)                           # the step applies 1 / N and keeps the optimizer outside the graph
         g = torch.Generator().manual_seed(0)
         batch = {"images": torch.randint(0, 256, (a.batch, 32, 32, 3), generator=g, dtype=torch.uint8).cuda(),
                  "labels": torch.zeros(a.batch, dtype=torch.int32).cuda(),
