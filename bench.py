@@ -659,6 +659,11 @@ def main():
         if rank == 0:
             extra["sampler"] = sampler_workload(bs, 1000, 3 if a.configs_small else 20)
             extra["ode"] = ode_workload(bo)
+            if world == 1 and not a.configs_small:
+                # the reference samples / evaluates with the per-device batch: 16 images per GPU on 8 GPUs
+                # (ldm/experiment.py:96-102) -- short convolution tiles + replayed function evaluations (round 5)
+                extra["sampler_16"] = sampler_workload(16, 1000, 20)
+                extra["ode_16"] = ode_workload(16)
     if rank != 0:
         if world > 1:
             dist.barrier()

@@ -131,8 +131,9 @@ int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax,
  * mulan_conv3x3_fwd_f16x3_gn_in normalises, activates and splits x1 (, x2: virtual channel concat, C2 == C1) while it
  * fills its patches: the result is bit for bit that of mulan_groupnorm_fwd_planes + ..._planes_in, the normalised tensor
  * never reaches HBM (yplanes_out, optional: store it as the weight-gradient operand after all).  C1 + C2 <= 512.
- * Statistics handed from convolution to convolution: ystats (optional output, [B][H / 8][N / 4][2]) receives this
- * launch's partial sums of y and y^2 per image, 8-row tile and channel quad; given as xstats1 (, xstats2) to the next
+ * Statistics handed from convolution to convolution: ystats (optional output, [B][H / rows][N / 4][2], rows =
+ * mulan_conv3x3_f16x3_tile_rows) receives this launch's partial sums of y and y^2 per image, row tile and channel quad;
+ * given as xstats1 (, xstats2; xstats_tiles = their H / rows) to the next
  * launch they replace the statistics pass -- every block forms mean / rstd / bound itself and mean, rstd, bound become
  * outputs (same formulas, another summation order: agreement to fp32 rounding instead of bit for bit). */
 int mulan_groupnorm_stats(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
@@ -140,10 +141,15 @@ int mulan_groupnorm_stats(const float* x1, const float* x2, int C1, int C2, cons
                           mulan_stream_t stream);
 int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, int C1, int C2, const float* gamma,
                                   const float* beta, float* mean, float* rstd, int G, int act, float eps,
-                                  unsigned* bound, const float* xstats1, const float* xstats2, const void* wp,
-                                  const unsigned* wmax, const float* bias, const float* cbias, int cbias_mode,
-                                  const float* res, float* y, unsigned* ymax, float* ystats, void* yplanes_out, int B,
-                                  int H, int W, int N, mulan_stream_t stream);
+                                  unsigned* bound, const float* xstats1, const float* xstats2, int xstats_tiles,
+                                  const void* wp, const unsigned* wmax, const float* bias, const float* cbias,
+                                  int cbias_mode, const float* res, float* y, unsigned* ymax, float* ystats,
+                                  void* yplanes_out, int B, int H, int W, int N, mulan_stream_t stream);
+/* Image rows per block (8, 4 or 2) the two-blocks-per-CU convolution kernel uses for a launch of B images and N output
+ * channels (round 5: launches of fewer than 128 images get shorter tiles so that every CU still holds two blocks -- the
+ * 64 images per GPU of BASELINE configs[2] at 8 GPUs, the 16 of a sampling batch).  The statistics arrays follow the
+ * tile: ystats is [B][H / rows][N / 4][2], and the consumer is told the producer's count through xstats_tiles. */
+int mulan_conv3x3_f16x3_tile_rows(int B, int H, int N, int with_ymax);
 
 size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N);
 int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float* dy, const unsigned* dymax, float* dw,

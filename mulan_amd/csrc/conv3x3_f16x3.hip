@@ -1350,29 +1350,42 @@ MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsig
 //  * xstats1 == NULL: mean / rstd / bound are what mulan_groupnorm_stats left; the result is, bit for bit, that of
 //    mulan_groupnorm_fwd_planes + mulan_conv3x3_fwd_f16x3_planes_in.
 //  * xstats1 (, xstats2) given: the partial sums the convolutions that PRODUCED x1 (, x2) left through their `ystats`
-//    ([B][H / 8][C1 / 4][2]: sum and sum of squares per image, 8-row tile and channel quad): every block forms mean / rstd
+//    ([B][xstats_tiles][C1 / 4][2]: sum and sum of squares per image, row tile and channel quad; xstats_tiles = H / the
+//    producer's tile rows, mulan_conv3x3_f16x3_tile_rows): every block forms mean / rstd
 //    and the bound itself -- no pass over x in front of the convolution at all -- and mean / rstd / bound are OUTPUTS (for
 //    a later backward pass).  Same formulas, another summation order: statistics agree to fp32 rounding.
-//  * ystats (optional, [B][H / 8][N / 4][2]): this launch's partial sums of y for the next GroupNorm.
+//  * ystats (optional, [B][H / mulan_conv3x3_f16x3_tile_rows(B, H, N, ymax != NULL)][N / 4][2]): this launch's partial
+//    sums of y for the next GroupNorm.
 // The normalised tensor is not written unless yplanes_out (optional, mulan_conv3x3_planes_bytes(B, 32, 32, C1 + C2)
 // bytes) asks for it as the weight-gradient kernel's operand.
 MULAN_API int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, int C1, int C2, const float* gamma,
                                             const float* beta, float* mean, float* rstd, int G, int act, float eps,
-                                            unsigned* bound, const float* xstats1, const float* xstats2, const void* wp,
-                                            const unsigned* wmax, const float* bias, const float* cbias, int cbias_mode,
-                                            const float* res, float* y, unsigned* ymax, float* ystats, void* yplanes_out,
-                                            int B, int H, int W, int N, hipStream_t stream) {
+                                            unsigned* bound, const float* xstats1, const float* xstats2, int xstats_tiles,
+                                            const void* wp, const unsigned* wmax, const float* bias, const float* cbias,
+                                            int cbias_mode, const float* res, float* y, unsigned* ymax, float* ystats,
+                                            void* yplanes_out, int B, int H, int W, int N, hipStream_t stream) {
   const int C = C1 + (x2 ? C2 : 0);
   if (W != kW || B <= 0 || C <= 0 || N <= 0 || G <= 0 || !x1 || !gamma || !beta || !mean || !rstd || !bound || !wmax ||
       (x2 && C2 != C1) || C % G != 0 || (C / G) % 4 != 0 || C > 512 || !mulan_conv3x3_f16x3_v3_eligible(H, C, N) ||
       (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts) ||
-      (xstats1 && x2 && !xstats2) || (ystats && yplanes_out))
+      (xstats1 && x2 && !xstats2) || (ystats && yplanes_out) ||
+      (xstats1 && xstats_tiles != H / 8 && xstats_tiles != H / 4 && xstats_tiles != H / 2))
     return (int)hipErrorInvalidValue;
   ConvArgsH a{x1, bound, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
               cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(yplanes_out), ymax, nullptr,
               x2, mean, rstd, gamma, beta, act, G,
-              ystats, xstats1, xstats2, xstats1 ? mean : nullptr, xstats1 ? rstd : nullptr, xstats1 ? bound : nullptr, eps};
+              ystats, xstats1, xstats2, xstats1 ? mean : nullptr, xstats1 ? rstd : nullptr, xstats1 ? bound : nullptr, eps,
+              0, xstats_tiles};
   return mulan_launch_conv3x3_f16x3_v3(a, stream);
+}
+
+// Image rows per block (8, 4 or 2) of the two-blocks-per-CU convolution kernel for a launch of B images with N output
+// channels: the tallest tile that still gives the launch two blocks per CU.  `ystats` of mulan_conv3x3_fwd_f16x3_gn_in
+// holds H / rows row tiles per image ([B][H / rows][N / 4][2]): the caller sizes it with this function and hands the count
+// on as `xstats_tiles`.  with_ymax: the launch also writes the maxima array (16 partials per image limit the tile count).
+MULAN_API int mulan_conv3x3_f16x3_tile_rows(int B, int H, int N, int with_ymax) {
+  if (B <= 0 || H % 8 != 0 || N <= 0 || N % BN != 0) return 8;
+  return mulan_conv3x3_f16x3_v3_tile_rows(B, H, N, with_ymax != 0);
 }
 
 MULAN_API size_t mulan_conv3x3_wgrad_f16x3_workspace(int B, int H, int W, int C, int N) {

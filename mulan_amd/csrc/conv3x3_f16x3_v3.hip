@@ -29,17 +29,27 @@ namespace {
 
 using namespace f16x3;
 
-constexpr int TR3 = 8;
-constexpr int P3_ROWS = TR3 + 2;                    // 10
-constexpr int P3_PLANE = P3_ROWS * kPW * 32;        // 10880 B: one plane of one 16-channel chunk
-constexpr int P3_BUF = 2 * P3_PLANE;                // 21760
-constexpr int P3_DUMMY = 3 * P3_BUF;                // dummy target for the slots past the patch (512 B) / for the DMA of a row
-constexpr int SMEM3_B = 3 * P3_BUF + 1024;          // outside the image (1 KB).  66304: two blocks per CU fit the 160 KB
-constexpr int PV3 = 6;                              // float4 patch slots per thread and chunk (1360 of 1536 used)
+// Tile height TR (image rows per block): 8 (the shape of rounds 2-4: 16 pixel tiles per wave), 4 or 2.  With 8 rows a
+// launch has B * 4 * (N / 128) blocks: one dispatch round of two blocks per CU at B = 128, ONE block per CU at 64 images
+// per GPU (the 8-GPU operating point of BASELINE configs[2]: no co-resident partner, 0.487 against 0.533) and a quarter of
+// the chip at the 16 images per GPU of a sampling batch.  Shorter tiles (round 5) give those launches their two blocks
+// per CU back; the price is the halo (TR + 2 patch rows per TR rows of output) and half / a quarter of the MFMAs per
+// weight-fragment load.  Everything below is derived from TR.
 constexpr int GN_ENT = 48;                          // GroupNorm-fed fill: table entry (scale x 4, beta x 4, mean) per channel quad
 constexpr int GN_MAXC = 512;
-constexpr int GN_SLOT = SMEM3_B + GN_MAXC / 4 * GN_ENT;      // 16 floats behind the table: [0] bound, [4..11] block reduction
-constexpr int SMEM3_GN_B = GN_SLOT + 64;                      // 72000
+template <int TR> struct V3Geo {
+  static constexpr int ROWS = TR + 2;               // patch rows (halo above and below)
+  static constexpr int PLANE = ROWS * kPW * 32;     // one plane of one 16-channel chunk (TR = 8: 10880 B)
+  static constexpr int BUF = 2 * PLANE;
+  static constexpr int DUMMY = 3 * BUF;             // dummy target for the slots past the patch (512 B) / for the DMA of a row
+  static constexpr int SMEM = 3 * BUF + 1024;       // outside the image (1 KB).  TR = 8: 66304 -- two blocks per CU fit the 160 KB
+  static constexpr int PV = (ROWS * kPW * 4 + 255) / 256;   // float4 patch slots per thread and chunk (TR = 8: 6, 1360 of 1536 used)
+  static constexpr int NK = (PV + 1) / 2;           // ... in pairs (one register set each): 3, 2, 2
+  static constexpr int PPW = (2 * ROWS) / 4;        // LDS-DMA pieces (plane, row) per wave and chunk: 5, 3, 2
+  static constexpr int GN_SLOT = SMEM + GN_MAXC / 4 * GN_ENT;   // 16 floats behind the table: [0] bound, [4..11] block reduction
+  static constexpr int SMEM_GN = GN_SLOT + 64;      // TR = 8: 72000
+  static_assert(TR == 8 || TR == 4 || TR == 2, "tile height");
+};
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
@@ -79,10 +89,19 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const
 // chunk 2 j + 3 into buffer A in step 5, right behind the barrier that frees it).  The halo columns and the rows outside
 // the image are never written: the buffers are zeroed once at the start (a row outside the image is DMA'd into the dummy
 // area instead: no branch in the loop body).  The barriers of the loop wait for the DMAs (vmcnt) like for any LDS write.
-template <int ABL, bool PIN = false, int GNF = 0, bool DMA = false>
+template <int ABL, bool PIN = false, int GNF = 0, bool DMA = false, int TR = 8>
 __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   static_assert(!(PIN && GNF), "GroupNorm-fed fill reads fp32");
   static_assert(!DMA || PIN, "LDS-DMA fill: plane-fed instantiation only");
+  using Geo = V3Geo<TR>;
+  constexpr int TR3 = TR, NPT = 2 * TR;              // NPT: 16-pixel tiles per wave (two per image row)
+  constexpr int P3_ROWS = Geo::ROWS, P3_PLANE = Geo::PLANE, P3_BUF = Geo::BUF, P3_DUMMY = Geo::DUMMY, SMEM3_B = Geo::SMEM;
+  constexpr int PV3 = 2 * Geo::NK, NK = Geo::NK, PPW = Geo::PPW, GN_SLOT = Geo::GN_SLOT;
+  // places of the patch traffic inside a step of NPT pixel tiles: the two slots of a pair are stored behind tiles ST0 / ST1
+  // and fetched behind LD0 / LD1; the four weight fragments of the next step behind tiles WL0 .. WL0 + 3
+  constexpr int ST0 = NPT == 16 ? 6 : (NPT == 8 ? 3 : 0), ST1 = NPT == 16 ? 8 : (NPT == 8 ? 4 : 1);
+  constexpr int LD0 = NPT == 16 ? 10 : (NPT == 8 ? 5 : 2), LD1 = NPT == 16 ? 12 : (NPT == 8 ? 6 : 3);
+  constexpr int WL0 = NPT > 4 ? 1 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,9 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   const bool tl = p.stamps && tid == 0 && tl_blk < 2048;
   if (tl) p.stamps[64 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
 
-  f32x4v acc[16][2];                                 // [pixel tile][cout tile]
+  f32x4v acc[NPT][2];                                // [pixel tile][cout tile]
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < NPT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     } else {
       gn_bound = __uint_as_float(row_max16(p.xmax, b));
     }
-    const int qpg = cpg >> 2, nq1 = ldx >> 2, ntile = p.H / TR3;
+    const int qpg = cpg >> 2, nq1 = ldx >> 2, ntile = p.xstats_tiles > 0 ? p.xstats_tiles : p.H / 8;   // (the PRODUCER's tiles)
     const float inv_n = 1.f / (float)(p.H * kW * cpg);
     for (int e = tid; e < C / 4; e += 256) {
       const int c = e * 4, g = c / cpg;
@@ -282,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   auto dma_piece = [&](int pbuf, int cc, int k) {
     typedef __attribute__((address_space(3))) void* lds_p;
     typedef const __attribute__((address_space(1))) void* gbl_p;
-    const int ri = wave * 5 + k;
+    const int ri = wave * PPW + k;
     const int plane = ri / P3_ROWS, prow = ri - plane * P3_ROWS;
     const int hh = h0 + prow - 1;
     const bool inside = (unsigned)hh < (unsigned)p.H;                 // wave-uniform
@@ -341,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { dma_piece(bufA, 0, k); dma_piece(bufB, nchunks > 1 ? 1 : 0, k); }
+    for (int k = 0; k < PPW; ++k) { dma_piece(bufA, 0, k); dma_piece(bufB, nchunks > 1 ? 1 : 0, k); }
   } else {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -396,23 +415,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
       const int uBn = __builtin_amdgcn_readfirstlane(tile_index(jn, 2 * sn + 1));
       // patch traffic of this step (table above): steps 0-2 fill chunk 2 j + 2 into buffer C, steps 5-7 chunk 2 j + 3
       // into buffer A (free after the step-4 barrier)
-      const bool fill0 = s <= 2, fill1 = s >= 5 && s <= 7;
+      const bool fill0 = s < NK, fill1 = s >= 5 && s < 5 + NK;
       const int fk = fill0 ? s : s - 5;              // slot pair stored in this step
       const bool st_useB = (fk == 1);
       int lk = -1, lcc = 0;                          // slot pair fetched in this step and its chunk
-      if (s == 0) { lk = 2; lcc = cfill0; }
+      if (s == 0 && NK == 3) { lk = 2; lcc = cfill0; }
       else if (s == 3) { lk = 0; lcc = cfill1; }
       else if (s == 4) { lk = 1; lcc = cfill1; }
-      else if (s == 5) { lk = 2; lcc = cfill1; }
+      else if (s == 5 && NK == 3) { lk = 2; lcc = cfill1; }
       else if (s == 7) { lk = 0; lcc = min(2 * j + 4, nchunks - 1); }
       else if (s == 8) { lk = 1; lcc = min(2 * j + 4, nchunks - 1); }
       const bool ld_useB = (lk == 1);
       // The MFMAs are volatile asm statements: memory operations keep their place between them (this is the issue
       // order), the address / split arithmetic floats into the shadows.
 #pragma unroll
-      for (int pt = 0; pt < 16; ++pt) {
-        const int cur = (s * 16 + pt) % 3, nxt = (cur + 2) % 3;
-        const int xa = pt < 14 ? xaddr : xaddr_n, pn = pt < 14 ? pt + 2 : pt - 14;
+      for (int pt = 0; pt < NPT; ++pt) {
+        const int cur = (s * NPT + pt) % 3, nxt = (cur + 2) % 3;
+        const int xa = pt < NPT - 2 ? xaddr : xaddr_n, pn = pt < NPT - 2 ? pt + 2 : pt - (NPT - 2);
         const int xo = ((pn >> 1) * kPW + (pn & 1) * 16) * 32;
         // small terms first: w_l x_h, w_h x_l, w_h x_h; the two cout tiles alternate so that an MFMA never waits for the
         // accumulator of the one right in front of it
@@ -421,27 +440,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
         if (!(ABL & 1)) xf[nxt][0] = *reinterpret_cast<const f16x8*>(smem + xa + xo);
         mfma16<0>(acc[pt][1], wf[s & 1][1][1], xf[cur][0], false);
         mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][1], false);
-        if (!(ABL & 2) && pt >= 1 && pt <= 4) load_w1(wf[(s + 1) & 1], uAn, uBn, pt - 1, sel_s);
+        if (!(ABL & 2) && pt >= WL0 && pt < WL0 + 4) load_w1(wf[(s + 1) & 1], uAn, uBn, pt - WL0, sel_s);
         if constexpr (DMA) {
           // chunk 2 j + 2 -> buffer C in step 0 (free since the barrier that ended the pair before), chunk 2 j + 3 -> buffer A
           // in step 5 (free since the step-4 barrier): five pieces per wave, one behind every second pixel tile
           // (at the head of the step: the compiler's next wait for the weight fragments -- the in-order vmcnt counter makes it
           // a wait for these pieces too -- comes at the end of the step)
-          if (!(ABL & 4) && (s == 0 || s == 5) && pt < 5)
+          if (!(ABL & 4) && (s == 0 || s == 5) && pt < PPW)
             dma_piece(s == 0 ? bufC : bufA, s == 0 ? cfill0 : cfill1, pt);
         } else {
-        if (!(ABL & 4) && (pt == 6 || pt == 8) && (fill0 || fill1)) {
-          i32x4& r = st_useB ? stgB[pt == 8] : stgA[pt == 8];
+        if (!(ABL & 4) && (pt == ST0 || pt == ST1) && (fill0 || fill1)) {
+          i32x4& r = st_useB ? stgB[pt == ST1] : stgA[pt == ST1];
           asm volatile("" : "+v"(r));                // pins the split arithmetic here (it would float to the step's top)
-          store_slot(fill0 ? bufC : bufA, slot_of(t_l, 2 * fk + (pt == 8)), r, fill0 ? cfill0 : cfill1);
+          store_slot(fill0 ? bufC : bufA, slot_of(t_l, 2 * fk + (pt == ST1)), r, fill0 ? cfill0 : cfill1);
         }
-        if (!(ABL & 4) && (pt == 10 || pt == 12) && lk >= 0)
-          (ld_useB ? stgB[pt == 12] : stgA[pt == 12]) = load_slot(slot_of(t_l, 2 * lk + (pt == 12)), lcc);
+        if (!(ABL & 4) && (pt == LD0 || pt == LD1) && lk >= 0)
+          (ld_useB ? stgB[pt == LD1] : stgA[pt == LD1]) = load_slot(slot_of(t_l, 2 * lk + (pt == LD1)), lcc);
         }
         mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][1], false);
         if (!(ABL & 1)) xf[nxt][1] = *reinterpret_cast<const f16x8*>(smem + xa + xo + P3_PLANE);
         mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][0], false);
-        if (s == 8 && pt == 15) mfma16<2>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
+        if (s == 8 && pt == NPT - 1) mfma16<2>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
         else mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
       }
       xaddr = xaddr_n;
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   // one straight-line body per (residual, per-pixel FiLM bias) combination: the loads of all tiles can be in flight together
   auto finish = [&](auto has_res, auto has_cb2) {
 #pragma unroll
-    for (int pt = 0; pt < 16; ++pt) {
+    for (int pt = 0; pt < NPT; ++pt) {
       const size_t pixbase = ((((size_t)b * p.H + h0 + (pt >> 1)) * kW) + (pt & 1) * 16 + l15) * N + nb;
       f32x4 add[2];
 #pragma unroll
@@ -556,67 +575,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
 
 }  // namespace
 
-bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N) { return H % TR3 == 0 && C % 32 == 0 && N % BN == 0; }
+bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N) { return H % 8 == 0 && C % 32 == 0 && N % BN == 0; }
+
+// Tile height of a launch: the tallest of 8 / 4 / 2 rows that still gives every CU a block (256 blocks), as long as the
+// maxima array (16 partials per image: row tiles x cout blocks) holds.  Measured (profiles/r05_tile_rows_bench.log, the
+// train step of BASELINE configs[2] per GPU batch): 64 images -- 8 rows 43.4 ms, 4 rows 44.4 (two half blocks per CU do
+// not beat one whole block: the halo and the weight fragments per MFMA cost what the co-residence gains), 32 images --
+// 30.3 / 28.6 / 29.3 ms for 8 / 4 / 2 rows, 16 images -- 26.2 / 23.9 / 23.4 ms.  tune[23] = 8 / 4 / 2: dev override.
+int mulan_conv3x3_f16x3_v3_tile_rows(int B, int H, int N, bool with_ymax) {
+  const int nb = N / BN;
+  int tr = 8;
+  for (int t : {8, 4, 2}) {
+    if (with_ymax && (H / t) * nb > kMaxParts) break;
+    tr = t;
+    if (B * (H / t) * nb >= 256) break;
+  }
+  const int forced = g_mulan_tune[23];
+  if ((forced == 8 || forced == 4 || forced == 2) && !(with_ymax && (H / forced) * nb > kMaxParts)) tr = forced;
+  return tr;
+}
+
+namespace {
+template <int ABL, bool PIN, int GNF, bool DMA, int TR>
+int launch_v3(const ConvArgsH& a, hipStream_t stream) {
+  constexpr int smem = GNF ? V3Geo<TR>::SMEM_GN : V3Geo<TR>::SMEM;
+  static bool configured = false;                   // (one flag per instantiation)
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<ABL, PIN, GNF, DMA, TR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const dim3 grid(a.B * (a.H / TR), a.N / BN);
+  hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<ABL, PIN, GNF, DMA, TR>), grid, dim3(256), smem, stream, a);
+  return (int)hipGetLastError();
+}
+template <bool PIN, int GNF, bool DMA>
+int launch_v3_rows(const ConvArgsH& a, int tr, hipStream_t stream) {
+  if (tr == 4) return launch_v3<0, PIN, GNF, DMA, 4>(a, stream);
+  if (tr == 2) return launch_v3<0, PIN, GNF, DMA, 2>(a, stream);
+  return launch_v3<0, PIN, GNF, DMA, 8>(a, stream);
+}
+}  // namespace
 
 int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a_in, hipStream_t stream) {
   f16x3::ConvArgsH a = a_in;
-  const dim3 grid(a.B * (a.H / TR3), a.N / BN);
-  a.pair_cols = (grid.y > 1 && grid.x % 8 == 0 && g_mulan_tune[13] != 1) ? 1 : 0;    // tune[13] = 1: dev A/B, plain 2-D order
+  const int tr = mulan_conv3x3_f16x3_v3_tile_rows(a.B, a.H, a.N, a.ymax != nullptr);
+  const unsigned gx = (unsigned)(a.B * (a.H / tr)), gy = (unsigned)(a.N / BN);
+  a.pair_cols = (gy > 1 && gx % 8 == 0 && g_mulan_tune[13] != 1) ? 1 : 0;    // tune[13] = 1: dev A/B, plain 2-D order
   if (a.gn_mean) {   // GroupNorm-fed forward convolution: with (xs) / without the planes as a by-product
-#define MULAN_V3_GN_LAUNCH(GNF)                                                                                       \
-  {                                                                                                                   \
-    static bool configured = false;                                                                                   \
-    if (!configured) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, false, GNF>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_GN_B);                     \
-      if (e != hipSuccess) return (int)e;                                                                             \
-      configured = true;                                                                                              \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, false, GNF>), grid, dim3(256), SMEM3_GN_B, stream, a);             \
-  }
     if (a.C > GN_MAXC) return (int)hipErrorInvalidValue;
-    if (a.xs) MULAN_V3_GN_LAUNCH(2) else MULAN_V3_GN_LAUNCH(1)
-#undef MULAN_V3_GN_LAUNCH
-    return (int)hipGetLastError();
+    return a.xs ? launch_v3_rows<false, 2, false>(a, tr, stream) : launch_v3_rows<false, 1, false>(a, tr, stream);
   }
   if (a.xplanes) {   // plane-fed forward convolution
-    static bool configured_pin = false;
-    if (!configured_pin) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<0, true, 0, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);
-      if (e != hipSuccess) return (int)e;
-      configured_pin = true;
-    }
     if (g_mulan_tune[18] == 1)     // dev A/B: the register-staged patch fill of rounds 2-3
-      hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, true>), grid, dim3(256), SMEM3_B, stream, a);
-    else                           // LDS-DMA patch fill (round 4: 76.72 / 76.79 / 76.71 vs 77.02 / 76.75 / 76.93 ms per step)
-      hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<0, true, 0, true>), grid, dim3(256), SMEM3_B, stream, a);
-    return (int)hipGetLastError();
+      return launch_v3_rows<true, 0, false>(a, tr, stream);
+    // LDS-DMA patch fill (round 4: 76.72 / 76.79 / 76.71 vs 77.02 / 76.75 / 76.93 ms per step)
+    return launch_v3_rows<true, 0, true>(a, tr, stream);
   }
-#define MULAN_V3_LAUNCH(ABL)                                                                                          \
-  {                                                                                                                   \
-    static bool configured = false;                                                                                   \
-    if (!configured) {                                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<ABL>),                 \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM3_B);                        \
-      if (e != hipSuccess) return (int)e;                                                                             \
-      configured = true;                                                                                              \
-    }                                                                                                                 \
-    hipLaunchKernelGGL(conv3x3_f16x3_v3_kernel<ABL>, grid, dim3(256), SMEM3_B, stream, a);                            \
+  switch (tr == 8 ? g_mulan_tune[4] : 0) {   // dev-only ablations (tools/conv_ab.py --ablate), 8-row tiles
+    case 1: return launch_v3<1, false, 0, false, 8>(a, stream);
+    case 2: return launch_v3<2, false, 0, false, 8>(a, stream);
+    case 4: return launch_v3<4, false, 0, false, 8>(a, stream);
+    case 8: return launch_v3<8, false, 0, false, 8>(a, stream);
+    case 15: return launch_v3<15, false, 0, false, 8>(a, stream);
+    case 16: return launch_v3<16, false, 0, false, 8>(a, stream);
+    case 32: return launch_v3<32, false, 0, false, 8>(a, stream);
+    default: break;
   }
-  switch (g_mulan_tune[4]) {   // dev-only ablations (tools/conv_ab.py --ablate)
-    case 1: MULAN_V3_LAUNCH(1) break;
-    case 2: MULAN_V3_LAUNCH(2) break;
-    case 4: MULAN_V3_LAUNCH(4) break;
-    case 8: MULAN_V3_LAUNCH(8) break;
-    case 15: MULAN_V3_LAUNCH(15) break;
-    case 16: MULAN_V3_LAUNCH(16) break;
-    case 32: MULAN_V3_LAUNCH(32) break;
-    default: MULAN_V3_LAUNCH(0) break;
-  }
-#undef MULAN_V3_LAUNCH
-  return (int)hipGetLastError();
+  return launch_v3_rows<false, 0, false>(a, tr, stream);
 }

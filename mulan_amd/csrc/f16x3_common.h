@@ -66,6 +66,7 @@ struct ConvArgsH {
   float* ystats; const float* xstats; const float* xstats2; float* gn_mean_out; float* gn_rstd_out; unsigned* xmax_out;
   float gn_eps;
   int pair_cols;                // (set by the launcher) the cout blocks of a pixel tile run on one XCD, see the kernel
+  int xstats_tiles;             // row tiles per image in xstats / xstats2 (the PRODUCER's tile height: 4, 8 or 16; 0 = 4)
 };
 
 // sigmoid on the hardware exp2 and reciprocal: the expression of groupnorm.hip's sigmoid_fast, bit for bit
@@ -83,3 +84,5 @@ constexpr int kBufWord3 = 0x00020000;           // raw buffer resource (no swizz
 // conv3x3_f16x3_v3.hip: 16x16x32 MFMA, two co-resident blocks per CU; returns a hipError_t as int
 int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream);
 bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N);
+// image rows per block the launcher will use for this launch (8, 4 or 2): ystats has H / rows row tiles per image
+int mulan_conv3x3_f16x3_v3_tile_rows(int B, int H, int N, bool with_ymax);

@@ -208,6 +208,7 @@ def get_ode_likelihood_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, a
     returning the Hutchinson probe of each function evaluation) override the Philox draws and `t_grid` replaces the
     adaptive controller by fixed Dormand-Prince steps: parity tests pass them."""
     from . import ops
+    from .model import ode_function
     from .ode import solve_fixed, solve_rk45
     if method != 'RK45':
         raise NotImplementedError("the reference only ever passes method='RK45' (ldm/notebook_utils.py:264)")
@@ -215,6 +216,7 @@ def get_ode_likelihood_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, a
         raise AssertionError(dequantization)
     model, params, dev = experiment.model, experiment.orig_params, experiment.device
     packer = experiment.state.param_packer("ema") if params is experiment.state.ema_params else None
+    graphs = {}          # captured function evaluations, re-used from batch to batch (model.ode_function)
 
     def likelihood_fn(rng, data, deterministic_noise=False, u=None, probes=None, t_grid=None):
         rng, init_noise_rng = rng.split()
@@ -239,9 +241,10 @@ def get_ode_likelihood_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, a
             draw = probes if probes is not None else hutch.noise
             n_x = B * 3072
 
+            f = ode_function(model, params, ctx, B, dev, True, cache=graphs)   # a replayed HIP graph (model.GraphedOdeFunction)
+
             def ode_func(t, y32, out):
-                model.reverse_ode(params, y32[:n_x].view(B, 3072), ctx, t, draw(), drift_out=out[:n_x].view(B, 3072),
-                                  div_out=out[n_x:])
+                f(t, y32[:n_x].view(B, 3072), draw(), out[:n_x].view(B, 3072), out[n_x:])
 
             y0 = torch.cat([y.reshape(-1).double(), torch.zeros(B, device=dev, dtype=torch.float64)])
             sol = (solve_rk45(ode_func, y0, (0.0, 1.0), rtol=rtol, atol=atol) if t_grid is None
@@ -263,6 +266,7 @@ def get_sample_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5
     The reference evaluates the Hutchinson divergence at every step and throws it away; only the drift is computed
     here (so hutchinson_type / deterministic_noise have no effect on the result, as in the reference)."""
     from . import ops
+    from .model import ode_function
     from .ode import solve_fixed, solve_rk45
     if method != 'RK45':
         raise NotImplementedError("the reference only ever passes method='RK45'")
@@ -280,8 +284,10 @@ def get_sample_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5
         try:
             ctx = model.ode_context_from_embedding(params, emb)
 
+            f = ode_function(model, params, ctx, sample_size, dev, False)
+
             def ode_func(t, y32, out):
-                model.reverse_ode(params, y32.view(sample_size, 3072), ctx, t, None, drift_out=out.view(sample_size, 3072))
+                f(t, y32.view(sample_size, 3072), None, out.view(sample_size, 3072))
 
             y0 = prior.reshape(-1).double()
             sol = (solve_rk45(ode_func, y0, (1.0, 0.0), rtol=rtol, atol=atol) if t_grid is None

@@ -195,6 +195,83 @@ class GraphedReverseStep:
         return self.z_out.view(z.shape)
 
 
+ODE_GRAPH = os.environ.get("MULAN_ODE_GRAPH", "1") == "1"      # A/B switch: 0 = every function evaluation issued eagerly
+
+
+class GraphedOdeFunction:
+    """One function evaluation of the probability-flow ODE -- VDM.reverse_ode and, for the likelihood, the Hutchinson term
+    hutch^T (d drift / d x) hutch through the U-Net's input gradient (ldm/model_mulan_velocity.py:393-421,
+    ldm/notebook_utils.py:203-215) -- captured as a HIP graph and replayed at every stage of every Dormand-Prince step.
+    Eagerly an evaluation is ~1100 dependent launches that the host needs ~25 ms to issue whatever the batch (measured:
+    25.1 ms per evaluation at 16 AND at 64 images); replayed, the device's own time is left.  What changes between
+    evaluations reaches the kernels through static buffers: the state x, the probe, the time (a [B] tensor read by
+    mulan_poly_gamma).  Same kernels, same order: results are bit-identical to the eager evaluation
+    (tests/test_gpu_ode.py::test_replayed_ode_function_equals_the_eager_one).  The weights must stay as they are while the
+    object lives (the caller holds the ParamPacker refresh)."""
+
+    def __init__(self, model, params, ctx, B, device, with_div):
+        self.model, self.B, self.with_div, self.params = model, B, with_div, params
+        f32 = dict(device=device, dtype=torch.float32)
+        # the per-batch context (embedding, schedule coefficients) in buffers of its own: set_context() re-targets a
+        # captured graph at the next batch / importance sample instead of capturing again
+        self.ctx = dict(emb=ctx["emb"].detach().clone(), coeffs=tuple(c.detach().clone() for c in ctx["coeffs"]))
+        ctx = self.ctx
+        self.x, self.tt = torch.zeros((B, D), **f32), torch.full((B,), 0.5, **f32)
+        self.probe = torch.ones((B, D), **f32) if with_div else None
+        self.drift = torch.empty((B, D), **f32)
+        self.div = torch.empty((B,), **f32) if with_div else None
+        run = lambda: model.reverse_ode(params, self.x, ctx, None, self.probe, drift_out=self.drift, div_out=self.div,
+                                        tt=self.tt)
+        for _ in range(2):             # eager first: every kernel configured, the allocator warm
+            run()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            run()
+
+    def set_context(self, ctx):
+        self.ctx["emb"].copy_(ctx["emb"])
+        for dst, src in zip(self.ctx["coeffs"], ctx["coeffs"]):
+            dst.copy_(src)
+
+    def __call__(self, t, x, probe, drift_out, div_out=None):
+        self.x.copy_(x.reshape(self.B, D))
+        if self.with_div:
+            self.probe.copy_(probe.reshape(self.B, D))
+        self.tt.fill_(float(np.float32(t)))
+        self.graph.replay()
+        drift_out.copy_(self.drift.view_as(drift_out))
+        if self.with_div:
+            div_out.copy_(self.div.view_as(div_out))
+
+
+def ode_function(model, params, ctx, B, device, with_div, graph=None, cache=None):
+    """-> f(t, x [B, 3072], probe | None, drift_out, div_out | None): VDM.reverse_ode as the ODE solvers call it; a
+    replayed HIP graph by default (MULAN_ODE_GRAPH), eager where the capture fails (logged).  cache (a dict the caller
+    keeps while the weights stay as they are): the captured graph of a batch size is re-used for the next batch / the
+    next importance sample with its context re-targeted (the packed weights live in persistent buffers, ops.ParamPacker)"""
+    if graph is None:
+        graph = ODE_GRAPH
+    if graph and torch.device(device).type == "cuda":
+        key = (B, bool(with_div), id(params))
+        hit = cache.get(key) if cache is not None else None
+        if hit is not None:
+            hit.set_context(ctx)
+            return hit
+        try:
+            g = GraphedOdeFunction(model, params, ctx, B, device, with_div)
+            if cache is not None:
+                cache.clear()            # (one graph at a time: its pool holds a forward + backward pass of activations)
+                cache[key] = g
+            return g
+        except Exception as e:      # noqa: BLE001  the replay is an optimisation: fall back loudly
+            import logging
+            logging.getLogger("mulan").warning("HIP-graph capture of the ODE function evaluation failed (%s: %s); "
+                                               "evaluating eagerly", type(e).__name__, e)
+    return lambda t, x, probe, drift_out, div_out=None: model.reverse_ode(params, x, ctx, t, probe, drift_out=drift_out,
+                                                                          div_out=div_out)
+
+
 def resnet_block(p, x1, x2, cond, drop):
     """ResnetBlock.__call__ (ldm/model_vdm.py:618-657 / ldm/ldm_unet.py:18-61) on [x1|x2]."""
     # Each (norm + swish [+ dropout]) -> conv pair is one op: the normalised tensor goes from the GroupNorm kernel to the
@@ -560,13 +637,15 @@ class MulanVDM(_VDMBase):
             return 1 if self.config.velocity_from_epsilon else 0
         return 2
 
-    def reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_out=None):
+    def reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_out=None, tt=None):
         """VDM.reverse_ode at time t for x [B, 3072]; with `hutch` also the Hutchinson estimate
-        hutch^T (d drift / d x) hutch per sample (notebook_utils._get_value_div_fn): returns (drift, div | None)"""
+        hutch^T (d drift / d x) hutch per sample (notebook_utils._get_value_div_fn): returns (drift, div | None).
+        tt (optional, [B] fp32 device tensor): the time as a stream-ordered parameter (GraphedOdeFunction) instead of t"""
         cfg = self.config
         B = x.shape[0]
         a, b, c = ctx["coeffs"]
-        tt = torch.full((B,), float(np.float32(t)), device=x.device, dtype=torch.float32)
+        if tt is None:
+            tt = torch.full((B,), float(np.float32(t)), device=x.device, dtype=torch.float32)
         with torch.no_grad():
             _, _, gt, gp = ops.poly_gamma(a, b, c, tt, cfg.gamma_min, cfg.gamma_max)
             g_in = gt.view(B, HW, 3) if cfg.unet_type == 'ldm' else ops.rowmean(gt)

@@ -1298,8 +1298,10 @@ GN_FILL_STATS = _os.environ.get("MULAN_GN_FILL_STATS", "1") == "1"
 
 
 def _gn_stats_of(x, C):
+    """the partial sums the convolution that produced x left on it: [B, row tiles (4, 8 or 16), C / 4, 2], or None"""
     c = getattr(x, "_gnstats", None) if x is not None else None
-    if c is not None and c[1] == x._version and c[0].shape == (x.shape[0], H // 8, C // 4, 2):
+    if (c is not None and c[1] == x._version and c[0].dim() == 4 and c[0].shape[0] == x.shape[0] and
+            c[0].shape[1] in (H // 8, H // 4, H // 2) and tuple(c[0].shape[2:]) == (C // 4, 2)):
         return c[0]
     return None
 
@@ -1383,7 +1385,7 @@ class GnConv3x3Fn(torch.autograd.Function):
         want_planes = bool(ctx.needs_input_grad[4])
         st1 = _gn_stats_of(x1, C1) if GN_FILL_STATS and not want_planes else None
         st2 = _gn_stats_of(x2, C2) if (st1 is not None and x2 is not None) else None
-        if st1 is None or (x2 is not None and st2 is None):
+        if st1 is None or (x2 is not None and (st2 is None or st2.shape[1] != st1.shape[1])):
             st1 = st2 = None
             call("mulan_groupnorm_stats", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(bound), B,
                  HW, groups, float(eps), stream())
@@ -1394,11 +1396,14 @@ class GnConv3x3Fn(torch.autograd.Function):
         ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
         mode = 0 if cbias is None else (1 if cbias.dim() == 2 else 2)
         bias_c, cb_c, res_c = _c(bias), _c(cbias), _c(res)
-        ystats = (torch.empty((B, H // 8, N // 4, 2), device=dev, dtype=torch.float32)
-                  if GN_FILL_STATS and not want_planes else None)
+        ystats = None
+        if GN_FILL_STATS and not want_planes:     # one row of partial sums per row tile of THIS launch (8, 4 or 2 image rows)
+            rows = lib.load().mulan_conv3x3_f16x3_tile_rows(B, H, N, int(ymax is not None))
+            ystats = torch.empty((B, H // rows, N // 4, 2), device=dev, dtype=torch.float32)
         _timed("conv3x3_f16x3_kernel<gn_in>", 2.0 * B * HW * 9 * Ct * N,
                lambda: call("mulan_conv3x3_fwd_f16x3_gn_in", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean),
-                            ptr(rstd), groups, int(act), float(eps), ptr(bound), ptr(st1), ptr(st2), ptr(wp), ptr(wmax),
+                            ptr(rstd), groups, int(act), float(eps), ptr(bound), ptr(st1), ptr(st2),
+                            0 if st1 is None else int(st1.shape[1]), ptr(wp), ptr(wmax),
                             ptr(bias_c), ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), ptr(ystats),
                             ptr(ys) if want_planes else None, B, H, W, N, stream()))
         if ystats is not None:

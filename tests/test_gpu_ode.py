@@ -320,3 +320,39 @@ def test_ode_sampler_matches_oracle():
                                     prior.cpu().double(), rtol=1e-4, atol=1e-4)
     assert abs(nfev - nfev_ref) <= 6, (nfev, nfev_ref)
     assert _rel(z.cpu().numpy(), z_ref.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("vdm_type,unet_type,vfe", [("mulan_velocity", "vdm", True), ("mulan_epsilon", "ldm", False)])
+def test_replayed_ode_function_equals_the_eager_one(vdm_type, unet_type, vfe):
+    """model.GraphedOdeFunction: one function evaluation (U-Net forward + Hutchinson term through its input gradient) as a
+    replayed HIP graph -- state, probe and time reach the kernels through static buffers.  Drift and divergence are bit
+    for bit those of the eager VDM.reverse_ode at every time asked for, with the divergence (likelihood) and without
+    (sampler); the replayed solver run equals the eager one."""
+    from mulan_amd import model as M
+    from mulan_amd import ode
+    vdm, params, _, _ = _setup(vdm_type, unet_type, vfe)
+    rng = np.random.default_rng(3)
+    B = 3
+    img = torch.tensor(rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)).cuda()
+    ctx = vdm.ode_context(params, img)
+    f_div = M.GraphedOdeFunction(vdm, params, ctx, B, torch.device("cuda"), True)
+    f_plain = M.GraphedOdeFunction(vdm, params, ctx, B, torch.device("cuda"), False)
+    for t in (0.0, 0.123, 0.77, 1.0, 0.123):
+        x = torch.tensor(rng.standard_normal((B, 3072)).astype(np.float32)).cuda()
+        h = torch.tensor((rng.integers(0, 2, (B, 3072)) * 2.0 - 1.0).astype(np.float32)).cuda()
+        drift, div = vdm.reverse_ode(params, x, ctx, t, h)
+        d2, v2 = torch.empty_like(drift), torch.empty_like(div)
+        f_div(t, x, h, d2, v2)
+        assert torch.equal(drift, d2) and torch.equal(div, v2), t
+        only, _ = vdm.reverse_ode(params, x, ctx, t, None)
+        d3 = torch.empty_like(only)
+        f_plain(t, x, None, d3)
+        assert torch.equal(only, d3), t
+    # a whole (fixed-grid) solve through ode_function: replayed == eager
+    y0 = torch.tensor(rng.standard_normal(B * 3072)).cuda()
+    runs = []
+    for graph in (True, False):
+        f = M.ode_function(vdm, params, ctx, B, torch.device("cuda"), False, graph=graph)
+        sol = ode.solve_fixed(lambda t, y32, out: f(t, y32.view(B, 3072), None, out.view(B, 3072)), y0, [1.0, 0.6, 0.3, 0.0])
+        runs.append(sol.y.clone())
+    assert torch.equal(runs[0], runs[1])

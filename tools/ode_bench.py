@@ -39,9 +39,11 @@ def main():
     probe = ops.noise((B, 3072), 2, 0, exp.device, "rademacher")
     n_x = B * 3072
 
+    from mulan_amd.model import ode_function
+    fe = ode_function(model, st.ema_params, ctx, B, exp.device, True)      # replayed HIP graph (MULAN_ODE_GRAPH=0: eager)
+
     def f(t, y32, out):
-        model.reverse_ode(st.ema_params, y32[:n_x].view(B, 3072), ctx, t, probe, drift_out=out[:n_x].view(B, 3072),
-                          div_out=out[n_x:])
+        fe(t, y32[:n_x].view(B, 3072), probe, out[:n_x].view(B, 3072), out[n_x:])
 
     y0 = torch.cat([y.reshape(-1).double(), torch.zeros(B, device=exp.device, dtype=torch.float64)])
     solve_fixed(f, y0, [0.0, 0.01])                         # warm-up
