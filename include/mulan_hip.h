@@ -165,7 +165,7 @@ int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, const float*
 size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C);
 /* share_chip (0 / 1; the same value for the workspace query and the launch): 1 = the caller runs this launch beside
  * another stream's matrix-core kernels (the train step's weight-gradient stream beside the input-gradient chain): the
- * launch then uses about half as many blocks, so that both streams keep running side by side. */
+ * launch then uses about half as many blocks, so that both streams keep running side by side (profiles/DESIGN_r04.md 3.2). */
 size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip);
 int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
                                      float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,

@@ -64,7 +64,7 @@ SIDE_DEPTH = int(_os.environ.get("MULAN_SIDE_DEPTH", "6"))
 # state is involved): a weight-gradient block owns its CU, so 240 of them leave 16 CUs to the
 # main stream; with 120 the launch takes about as long as the main stream's kernels of the same layer (GroupNorm
 # backward + input-gradient convolution) and both streams keep running side by side: -2.9 % per step (scan 96 ... 240,
-# DESIGN 3.2).  MULAN_SIDE_WGRAD_SHARE=0 keeps 240.
+# profiles/DESIGN_r04.md 3.2).  MULAN_SIDE_WGRAD_SHARE=0 keeps 240.
 SIDE_WGRAD_SHARE = _os.environ.get("MULAN_SIDE_WGRAD_SHARE", "1") == "1"
 _SIDE = {"stream": None, "pending": None, "active": False}
 
@@ -1285,7 +1285,7 @@ KEEP_BITS = _os.environ.get("MULAN_KEEP_BITS", "1") == "1"
 # tensor never reaches HBM (with the statistics hand-over below: sampler step -15 %, ODE function evaluation -7.5 % at E = 128).  With N = 256 every input
 # element is normalised by two blocks and the fill's arithmetic costs more than the GroupNorm pass it saves (dense
 # evaluation at E = 256: +4.5 %), so those layers keep the plane hand-over; GN_FILL_MAX_N is that limit.
-# GN_FILL_TRAIN (A/B switch, off: the train step is 1.2 % slower with it): also in training, the convolution
+# GN_FILL_TRAIN (A/B switch, off: the train step is 1.2 % slower with it, profiles/DESIGN_r04.md 3.2): also in training, the convolution
 # then stores the planes for its weight gradient.
 GN_FILL = _os.environ.get("MULAN_GN_FILL", "1") == "1"
 GN_FILL_MAX_N = int(_os.environ.get("MULAN_GN_FILL_MAX_N", "128"))

@@ -159,7 +159,7 @@ class GradReducer:
     # (hipStreamWaitValue32) and all-reduces bucket k under the rest of the graph (the reference gets the same overlap
     # from XLA inside pmap(scan(train_step)), ldm/experiment.py:89-95,341).  An event-record node is planted as well
     # (mulan_event_record_external): the fallback where the device cannot wait on values -- on this runtime such nodes
-    # all fire together near the end of a multi-branch graph (tools/overlap_timing_probe.py).
+    # all fire together near the end of a multi-branch graph (profiles/DESIGN_r04.md 1, tools/overlap_timing_probe.py).
     def begin_capture(self):
         """call before capturing a train step (with paused = True)"""
         if not (self.enabled and self.side is not None):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How do the HBM-bound kernels of the backward pass scale with the number of CUs they may use, and can a GroupNorm
 backward on a CU-masked stream run beside a weight gradient that leaves those CUs alone?  (Feasibility probe for
-DESIGN 7.1: hipExtStreamCreateWithCUMask streams wrapped as torch ExternalStreams.)
+profiles/DESIGN_r04.md 7.1: hipExtStreamCreateWithCUMask streams wrapped as torch ExternalStreams.)
 Usage: python tools/cumask_probe.py [--batch 128]"""
 import argparse
 import ctypes

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Feasibility probe for DESIGN 7.6 (two half-batches in flight): does running the forward chain of ResnetBlock ops
+"""Feasibility probe for profiles/DESIGN_r04.md 7.6 (round-2 numbering) (two half-batches in flight): does running the forward chain of ResnetBlock ops
 (GroupNorm -> planes -> 3x3 convolution, ops.gn_conv3x3) as TWO independent half-batch chains on two HIP streams beat
 one full-batch chain?  The HBM-bound GroupNorm of one half could run beside the MFMA-bound convolution of the other.
 Both variants are captured into HIP graphs (no host launch limits) and replayed.  Also the backward-shaped chain

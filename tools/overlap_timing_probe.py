@@ -29,6 +29,12 @@ def main():
                     help="no stand-in: the process group is RCCL (backend nccl) with this one rank, so the capture, the "
                          "signal waits and the optimizer run beside ProcessGroupNCCL's own threads and streams (a "
                          "one-rank all-reduce moves nothing: a smoke run of the plumbing, not a timing)")
+    ap.add_argument("--footprint", type=int, default=0,
+                    help="K > 0: the stand-in is a kernel with RCCL's footprint -- K workgroups of 512 threads that stream 2 x the "
+                         "bucket through HBM, paced over the ring's duration (tools/footprint_kernel.hip) -- instead of one "
+                         "sleeping wave")
+    ap.add_argument("--footprint-lds", type=int, default=0, help="bytes of LDS each footprint workgroup holds (e.g. 98304: "
+                                                                 "no convolution block can share its CU)")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -52,11 +58,30 @@ def main():
 
     calls = {"n": 0, "us": 0.0}
 
+    fp_lib, fp_dst = None, {}
+    if a.footprint > 0:
+        import ctypes
+        import subprocess
+        so = "/tmp/libfootprint.so"
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-w", "-shared", "-fPIC", "-o", so,
+                        os.path.join(ROOT, "tools", "footprint_kernel.hip")], check=True)
+        fp_lib = ctypes.CDLL(so)
+        fp_lib.footprint_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_ulonglong,
+                                          ctypes.c_int, ctypes.c_void_p]
+
     def standin_all_reduce(t, op=None, group=None, async_op=False):
         nbytes = t.numel() * t.element_size()
         if nbytes >= (1 << 20):                     # a gradient bucket (the scalar metrics cost nothing)
             us = nbytes * 2.0 * (a.ranks - 1) / a.ranks / (a.gbps * 1e3)
-            torch.cuda._sleep(int(us * cyc_per_us))  # on the current (= collective) stream
+            if fp_lib is not None:                  # K workgroups stream the bucket twice over the ring's duration
+                dst = fp_dst.get(nbytes)
+                if dst is None:
+                    dst = fp_dst[nbytes] = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+                rc = fp_lib.footprint_copy(t.data_ptr(), dst.data_ptr(), nbytes, a.footprint, int(us * 1e3), a.footprint_lds,
+                                           torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, rc
+            else:
+                torch.cuda._sleep(int(us * cyc_per_us))  # on the current (= collective) stream
             calls["n"] += 1
             calls["us"] += us
         return Done() if async_op else None
