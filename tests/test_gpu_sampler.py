@@ -9,6 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests.oracle_dev import run_oracle
 from oracle import torch_ref as tr
 from tests.test_gpu_model import make_cfg
 
@@ -160,10 +161,10 @@ def test_sampler_loop_matches_oracle(vdm_type, unet_type):
     z_init = key.fold_in(1000).normal((B, 3072), "cuda")
     vdm, params, ref_params, ocfg = _mulan_setup(vdm_type, unet_type)
     _check_steps(vdm, params, key, z_init, T,
-                 lambda zi, eps: tr.mulan_sample_loop(ref_params, ocfg, zi, eps, trajectory=True))
+                 lambda zi, eps: run_oracle(lambda P, z_, e_: tr.mulan_sample_loop(P, ocfg, z_, e_, trajectory=True), ref_params, zi, eps))
     vdm, params, ref_params, ocfg = _mulan_setup(vdm_type, unet_type, damp=0.02)
     z, cond = _check_free_run(vdm, params, key, z_init, T,
-                              lambda zi, eps: tr.mulan_sample_loop(ref_params, ocfg, zi, eps, trajectory=True))
+                              lambda zi, eps: run_oracle(lambda P, z_, e_: tr.mulan_sample_loop(P, ocfg, z_, e_, trajectory=True), ref_params, zi, eps))
     # precomputed schedule coefficients (what sample_fn passes) give the identical trajectory
     coeffs = vdm.sample_coefficients(params, vdm.deterministic_embedding(B, "cuda"))
     z2 = z_init
@@ -195,7 +196,7 @@ def test_plain_vdm_sampler_loop_matches_oracle(gamma_type, reparam):
         params = M.tree_map(lambda t: t.cuda(), vdm.init(PRNGKey(0)))
         M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), ref_params), params)
         check(vdm, params, key, z_init, T,
-              lambda zi, eps: tr.plain_sample_loop(ref_params, ocfg, zi, eps, trajectory=True))
+              lambda zi, eps: run_oracle(lambda P, z_, e_: tr.plain_sample_loop(P, ocfg, z_, e_, trajectory=True), ref_params, zi, eps))
 
 
 def test_sample_softmax_draws_from_the_decoder_distribution():
