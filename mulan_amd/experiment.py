@@ -42,6 +42,12 @@ def restore_partial(state, state_restore_dict):
 # 78.8 ms, profiles/r04_overlap_timing_probe.log).  The default is what rounds 1-3 shipped and what plain
 # torch.distributed semantics cover: see Experiment.__init__.
 GRAPH_OVERLAP = os.environ.get("MULAN_GRAPH_OVERLAP", "0") == "1"
+# Several ranks, RCCL only (opt-in, round 5 experiment): the bucket all-reduces are CAPTURED INTO the graph -- the hooks
+# launch them during the capture as they do in the eager step, on the collective stream, so the graph itself carries every
+# dependency (bucket ready -> all-reduce -> optimizer): no signal words, no stream calibration, no release lag, and the
+# optimizer is part of the graph as on one rank.  torch's ProcessGroupNCCL supports capture; gloo does not.  Run on ONE
+# rank of RCCL only (tools/overlap_timing_probe.py --rccl): never on a multi-GPU box, hence opt-in.
+GRAPH_COLLECTIVES = os.environ.get("MULAN_GRAPH_COLLECTIVES", "0") == "1"
 
 
 def ops_kernel_timer_off():
@@ -91,13 +97,16 @@ class GraphedStep:
         self.dyn = torch.zeros(4, device=dev, dtype=torch.float32)
         self.h_seeds = torch.zeros(2, dtype=torch.int64).pin_memory()
         self.h_dyn = torch.zeros(5, dtype=torch.float32).pin_memory()       # lr, bc1, bc2, 0, t0
-        self.whole = exp.world == 1                  # optimizer inside the graph
+        # collectives inside the graph (see GRAPH_COLLECTIVES): RCCL process groups only
+        self.captured_collectives = bool(exp.world > 1 and exp.graph_collectives and exp.reducer.enabled and
+                                         exp.reducer.sync_ops)
+        self.whole = exp.world == 1 or self.captured_collectives      # optimizer inside the graph
         self.mode = ops.CONV_MODE
         self.copied = torch.cuda.Event()             # the pinned staging buffers have been read by the device
         self.graph = torch.cuda.CUDAGraph()
         self.metrics = None
         rngs = {'dropout_pair': (Key(0, dev=self.seeds[0:1]), Key(0, dev=self.seeds[1:2]))}
-        exp.reducer.paused = True
+        exp.reducer.paused = not self.captured_collectives
         try:
             self._fill(exp._train_rng, state, batch)         # valid contents while capturing (nothing executes)
             state.zero_grad()
@@ -107,7 +116,7 @@ class GraphedStep:
             # kernel node) per bucket instead (parallel.GradReducer._mark); after the replay the collectives wait for
             # those signals, i.e. they run under the rest of the replayed backward pass (MULAN_GRAPH_OVERLAP=0: behind
             # the whole graph)
-            if exp.graph_overlap:
+            if exp.graph_overlap and not self.captured_collectives:
                 exp.reducer.begin_capture()
             mode = "global"
             if exp.world > 1:
@@ -118,6 +127,8 @@ class GraphedStep:
                 mode = "thread_local"
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 state.zero_grad()
+                if self.captured_collectives:
+                    exp.reducer.prepare()
                 packer = state.param_packer()
                 if packer is not None:
                     packer.refresh()
@@ -125,18 +136,22 @@ class GraphedStep:
                                            noise=self.noise)
                 with ops.weight_gradient_stream():
                     bpd.backward()
-                exp.reducer.end_capture()
-                state.collect_grads()
+                if self.captured_collectives:
+                    state.collect_grads()
+                    exp.reducer.finish()                     # (captured: the compute stream waits for the collective stream)
+                else:
+                    exp.reducer.end_capture()
+                    state.collect_grads()
                 if packer is not None:
                     packer.invalidate()
                 if self.whole:
-                    state.apply_gradients(lr=0.0, ema_rate=exp.config.optimizer.ema_rate, grad_scale=1.0,
+                    state.apply_gradients(lr=0.0, ema_rate=exp.config.optimizer.ema_rate, grad_scale=1.0 / exp.world,
                                           clip_norm=exp.config.optimizer.get('gradient_clip_norm', None), dyn=self.dyn,
                                           count_step=False)
                 self.metrics = metrics
         finally:
             exp.reducer.paused = False
-        if not self.whole and exp.graph_overlap:
+        if not self.whole and exp.graph_overlap and not self.captured_collectives:
             # several ranks: make sure the collective stream is one on which the signals really release the
             # collectives early (parallel.GradReducer.calibrate_stream: a few trial replays, once per capture).  Any
             # failure here leaves the plain schedule: collectives behind the whole graph (allreduce_now), logged.
@@ -255,9 +270,10 @@ class Experiment(abc.ABC):
         # ~54 ms of launches), from there on the eager step whose bucketed all-reduce overlaps the backward pass.  The
         # replay WITH overlap (signal words, GRAPH_OVERLAP above) is opt-in until it has run on a multi-GPU RCCL box.
         self.graph_overlap = bool(config.training.get("graph_overlap", GRAPH_OVERLAP)) and self.world > 1
+        self.graph_collectives = bool(config.training.get("graph_collectives", GRAPH_COLLECTIVES)) and self.world > 1
         env = os.environ.get("MULAN_HIP_GRAPH", "")
         want = config.training.get("hip_graph", None)
-        if want is None and env not in ("0", "1") and self.world > 1 and not self.graph_overlap:
+        if want is None and env not in ("0", "1") and self.world > 1 and not (self.graph_overlap or self.graph_collectives):
             local = max(1, int(config.training.batch_size_train) // self.world)
             want = local * (float(config.model.sm_n_embd) / 128.0) ** 2 < 96
         # asked for explicitly (config or environment): a failed capture is an error; chosen by default: a warning and

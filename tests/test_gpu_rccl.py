@@ -62,3 +62,28 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-c", code % (ROOT, port)], capture_output=True, text=True, timeout=540, env=env,
                        cwd=ROOT)
     assert r.returncode == 0 and "RCCL_SMOKE ok nccl" in r.stdout, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.timeout(900)
+def test_rccl_collectives_captured_into_the_replayed_step():
+    """MULAN_GRAPH_COLLECTIVES (round 5, opt-in): the whole multi-rank train step as ONE HIP graph -- the bucket all-reduces
+    are captured where the eager step's hooks launch them, the optimizer follows inside the graph; no signal words, no
+    stream calibration.  ProcessGroupNCCL supports capture, gloo does not, so this runs on RCCL: with two ranks where two
+    GPUs are visible, else with one rank whose reducer is told it is one of two (the collective path, streams and the
+    1 / N of the optimizer are the real ones; the sum over one rank is the identity).  Four optimizer steps end
+    bit-identical to the eager overlapped step (tests/captured_collectives_check.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MULAN_DIST_BACKEND",
+                                                            "MULAN_HIP_GRAPH", "MULAN_GRAPH_OVERLAP")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    script = os.path.join(ROOT, "tests", "captured_collectives_check.py")
+    if torch.cuda.device_count() >= 2:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", "2", script]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s.getsockname()[1])
+        s.close()
+        cmd = [sys.executable, script]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=840, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "CAPTURED_COLLECTIVES_CHECK ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])

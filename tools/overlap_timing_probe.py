@@ -97,7 +97,7 @@ def main():
 
     dist.all_reduce = counted_all_reduce if a.rccl else standin_all_reduce
 
-    def run(hip_graph, overlap):
+    def run(hip_graph, overlap, collectives=False):
         config = load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py"))
         config.data.dataset = "synthetic"
         config.training.batch_size_train = a.batch
@@ -106,7 +106,8 @@ def main():
         config.training.hip_graph = hip_graph
         exp = E.Experiment_VDM(config)
         exp.world = a.ranks
-        exp.graph_overlap = bool(overlap)             # (opt-in since round 5)                           # the step applies 1 / N and keeps the optimizer outside the graph
+        exp.graph_overlap = bool(overlap)             # (opt-in since round 5)
+        exp.graph_collectives = bool(collectives)     # (--rccl only: the all-reduces captured into the graph)                           # the step applies 1 / N and keeps the optimizer outside the graph
         g = torch.Generator().manual_seed(0)
         batch = {"images": torch.randint(0, 256, (a.batch, 32, 32, 3), generator=g, dtype=torch.uint8).cuda(),
                  "labels": torch.zeros(a.batch, dtype=torch.int32).cuda(),
@@ -136,9 +137,12 @@ def main():
     print(f"stand-in collective: ring all-reduce over {a.ranks} ranks at {a.gbps:.0f} GB/s per link; "
           f"{cyc_per_us:.0f} sleep cycles per us", flush=True)
     for rep in range(1):
-        for name, hg, ov in (("replay + signal hand-off (shipped)", True, True), ("replay, collectives behind the graph", True, False),
-                             ("eager step, hooks launch the collectives", False, True)):
-            ms, (graphed, nb, marked, ncalls, coll_ms) = run(hg, ov)
+        variants = [("replay + signal hand-off (opt-in)", True, True, False), ("replay, collectives behind the graph", True, False, False),
+                    ("eager step, hooks launch the collectives", False, True, False)]
+        if a.rccl:
+            variants.append(("replay, collectives captured into the graph", True, False, True))
+        for name, hg, ov, cc in variants:
+            ms, (graphed, nb, marked, ncalls, coll_ms) = run(hg, ov, cc)
             print(f"{name:42s}: {ms:7.2f} ms per step   (graph {graphed}, {nb} buckets, {marked}, "
                   f"{ncalls:.0f} collectives = {coll_ms:.2f} ms of stand-in per step)", flush=True)
     parallel.world_size = real_world
