@@ -124,6 +124,14 @@ int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp
 int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp, const unsigned* wmax,
                                       const float* bias, const float* cbias, int cbias_mode, const float* res, float* y,
                                       unsigned* ymax, int B, int H, int W, int C, int N, mulan_stream_t stream);
+/* ... and (round 5) with the by-product the NEXT GroupNorm needs: ystats (optional) receives the partial sums of y and
+ * y^2 per (image, row tile of this launch, channel quad), [B][H / mulan_conv3x3_f16x3_tile_rows(B, H, N, ymax != NULL)]
+ * [N / 4][2] floats -- mulan_groupnorm_fwd_stream forms mean / rstd from them (norm2 behind conv1, the next block's
+ * norm1 behind conv2: ldm/model_vdm.py:622-644), so that pass needs no statistics phase. */
+int mulan_conv3x3_fwd_f16x3_planes_in_stats(const void* xplanes, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                            const float* bias, const float* cbias, int cbias_mode, const float* res,
+                                            float* y, unsigned* ymax, float* ystats, int B, int H, int W, int C, int N,
+                                            mulan_stream_t stream);
 /* GroupNorm (+ swish) normalised inside the convolution that consumes it (round 3; ResnetBlock norm1 + swish -> conv1,
  * norm2 + swish -> conv2 wherever no dropout is drawn: ldm/model_vdm.py:622-623,632-633,643-650 under eval_step /
  * sample / the likelihood evaluators).  mulan_groupnorm_stats reads x once and leaves mean / rstd [B, G] and the a-priori
@@ -338,10 +346,11 @@ int mulan_groupnorm_fwd_planes_keepbits(const float* x1, const float* x2, int C1
 /* Streaming forms (round 5; the same layers, model_vdm.py:622-623,632,643-644 and their autodiff): the reductions that
  * force the kernels above to hold a whole (sample, 32-channel slab) before they write -- mean / variance in the forward
  * pass, the two group sums of the backward pass -- arrive from the PRODUCER of the tensor instead: the convolution whose
- * epilogue wrote x leaves sum x, sum x^2 (`ystats` of mulan_conv3x3_fwd_f16x3_planes_in_stats), the input-gradient
- * convolution that wrote dy leaves sum g gamma, sum g gamma xhat (`gstats` of mulan_conv3x3_fwd_f16x3_gstats /
- * mulan_conv3x3_fwd_f16x3_planes_in_gstats), each per image, 8-row tile and channel quad: [B][4][C / 4][2] floats.  The
- * GroupNorm kernels are then plain streaming passes (forward 1 read + 1 write, backward 2 reads + 1 write).
+ * epilogue wrote x leaves sum x, sum x^2 (`ystats` of mulan_conv3x3_fwd_f16x3_planes_in_stats / _gn_in: per image, row
+ * tile of that launch and channel quad, [B][xstats_tiles][C / 4][2] floats), the producer of dy would leave sum g gamma,
+ * sum g gamma xhat (`gstats`, [B][4][C / 4][2]; no shipped kernel writes them: measured not to pay, DESIGN.md section
+ * 3.3).  The GroupNorm kernels are then plain streaming passes (forward 1 read + 1 write, backward 2 reads + 1 write).
+ * The training step runs _fwd_stream where it is the faster kernel (dropout layers, the 2 x 128-channel concat).
  * _fwd_stream: exactly one of y (fp32; ymax optional: true maxima) and yplanes (split planes; ymax required: the bound).
  * xstats1 (, xstats2 for C2 > 0) given: mean / rstd [B, G] are OUTPUTS; NULL: they are inputs.  keepbits (optional,
  * keep < 1): as mulan_groupnorm_fwd_planes_keepbits.
@@ -349,7 +358,7 @@ int mulan_groupnorm_fwd_planes_keepbits(const float* x1, const float* x2, int C1
  * dx1 as split planes (mulan_groupnorm_bwd_fused_planes), dymax required, dx1max receives the bound. */
 int mulan_groupnorm_fwd_stream(const float* x1, const float* x2, int C1, int C2, const float* gamma, const float* beta,
                                float* y, void* yplanes, float* mean, float* rstd, const float* xstats1,
-                               const float* xstats2, int B, int hw, int G, float eps, int act, float keep,
+                               const float* xstats2, int xstats_tiles, int B, int hw, int G, float eps, int act, float keep,
                                unsigned long long seed, unsigned long long offset, const unsigned long long* seed_dev,
                                unsigned* ymax, unsigned* keepbits, mulan_stream_t stream);
 int mulan_groupnorm_bwd_stream(const float* dy, const unsigned* dymax, const float* x1, const float* x2, int C1, int C2,

@@ -1332,16 +1332,29 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
 // [B][16] array that kernel filled with the bound the planes are scaled with).  Same epilogue and by-products as
 // mulan_conv3x3_fwd_f16x3, minus the plane output -- the input already is one, for the weight-gradient kernel too.
 // Needs the shapes of the two-blocks-per-CU kernel: H % 8 == 0, C % 32 == 0, N % 128 == 0.
-MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp,
-                                                const unsigned* wmax, const float* bias, const float* cbias,
-                                                int cbias_mode, const float* res, float* y, unsigned* ymax, int B, int H,
-                                                int W, int C, int N, hipStream_t stream) {
+// _stats: ystats (optional) receives the partial sums of y and y^2 per (image, row tile of this launch, channel quad),
+// [B][H / mulan_conv3x3_f16x3_tile_rows(B, H, N, ymax != NULL)][N / 4][2] -- what mulan_groupnorm_fwd_stream forms the
+// statistics of the NEXT GroupNorm from (norm2 behind conv1, the next block's norm1 behind conv2: model_vdm.py:622-644).
+MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in_stats(const void* xplanes, const unsigned* xmax, const void* wp,
+                                                      const unsigned* wmax, const float* bias, const float* cbias,
+                                                      int cbias_mode, const float* res, float* y, unsigned* ymax,
+                                                      float* ystats, int B, int H, int W, int C, int N,
+                                                      hipStream_t stream) {
   if (W != kW || B <= 0 || C <= 0 || N <= 0 || !xplanes || !xmax || !wmax || !mulan_conv3x3_f16x3_v3_eligible(H, C, N) ||
       (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts))
     return (int)hipErrorInvalidValue;
   ConvArgsH a{nullptr, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
               cbias ? cbias_mode : 0, g_mulan_debug_buffer, nullptr, ymax, static_cast<const unsigned char*>(xplanes)};
+  a.ystats = ystats;
   return mulan_launch_conv3x3_f16x3_v3(a, stream);
+}
+
+MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp,
+                                                const unsigned* wmax, const float* bias, const float* cbias,
+                                                int cbias_mode, const float* res, float* y, unsigned* ymax, int B, int H,
+                                                int W, int C, int N, hipStream_t stream) {
+  return mulan_conv3x3_fwd_f16x3_planes_in_stats(xplanes, xmax, wp, wmax, bias, cbias, cbias_mode, res, y, ymax, nullptr, B,
+                                                 H, W, C, N, stream);
 }
 
 // y = conv3x3(act(GroupNorm([x1 | x2]))) + bias + cbias + res with the normalisation done inside the convolution's patch

@@ -502,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
   }
   unsigned omax = 0;
-  float ys1[2] = {0.f, 0.f}, ys2[2] = {0.f, 0.f};    // (GNF = 1, ystats) sums of y and y^2 over this lane's pixels, per cout tile
+  float ys1[2] = {0.f, 0.f}, ys2[2] = {0.f, 0.f};    // (ystats) sums of y and y^2 over this lane's pixels, per cout tile
   // one straight-line body per (residual, per-pixel FiLM bias) combination: the loads of all tiles can be in flight together
-  auto finish = [&](auto has_res, auto has_cb2) {
+  auto finish = [&](auto has_res, auto has_cb2, auto has_ys) {
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) {
       const size_t pixbase = ((((size_t)b * p.H + h0 + (pt >> 1)) * kW) + (pt & 1) * 16 + l15) * N + nb;
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
           o[e] = (acc[pt][ct][e] * inv_x) * inv_w + add[ct][e];
           omax = max(omax, __float_as_uint(o[e]) & 0x7fffffffu);
         }
-        if constexpr (GNF == 1) {
+        if constexpr (decltype(has_ys)::value) {
           ys1[ct] += (o[0] + o[1]) + (o[2] + o[3]);
           ys2[ct] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
         }
@@ -543,9 +543,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   };
   using T = std::true_type;
   using F = std::false_type;
-  if (res) { if (p.cbias_mode == 2) finish(T{}, T{}); else finish(T{}, F{}); }
-  else { if (p.cbias_mode == 2) finish(F{}, T{}); else finish(F{}, F{}); }
-  if constexpr (GNF == 1) {
+  auto finish2 = [&](auto has_ys) {
+    if (res) { if (p.cbias_mode == 2) finish(T{}, T{}, has_ys); else finish(T{}, F{}, has_ys); }
+    else { if (p.cbias_mode == 2) finish(F{}, T{}, has_ys); else finish(F{}, F{}, has_ys); }
+  };
+  if constexpr (GNF == 1) finish2(T{});
+  else { if (p.ystats) finish2(T{}); else finish2(F{}); }
+  {
     if (p.ystats) {   // this lane's 4 couts of a tile are one channel quad: sum over the 16 pixel lanes, one writer per quad
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {

@@ -34,6 +34,7 @@ struct GnArgs {
   // (their `ystats`: [B][HW / 256][C1 / 4][2] = sum and sum of squares per image, 8-row tile and channel quad);
   // mean / rstd are then OUTPUTS (for the backward pass).  NULL: mean / rstd are inputs.
   const float* xstats1; const float* xstats2;
+  int xstats_tiles;                           // row tiles per image in xstats1 / xstats2 (the producer's tile height: 4, 8 or 16)
 };
 
 __device__ __forceinline__ void drop4(f32x4& v, float keep, unsigned long long seed, unsigned long long ctr) {
@@ -659,9 +660,8 @@ __device__ __forceinline__ void stats_from_partials(const GnArgs& p, int b, int 
   for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) {
     const bool first = qq < nq1;
     const int nq = first ? nq1 : nq2;
-    const float* st = (first ? p.xstats1 : p.xstats2) + ((size_t)b * (HW / 256) * nq + (first ? qq : qq - nq1)) * 2;
-#pragma unroll
-    for (int t = 0; t < HW / 256; ++t) { s1 += st[(size_t)t * nq * 2]; s2 += st[(size_t)t * nq * 2 + 1]; }
+    const float* st = (first ? p.xstats1 : p.xstats2) + ((size_t)b * p.xstats_tiles * nq + (first ? qq : qq - nq1)) * 2;
+    for (int t = 0; t < p.xstats_tiles; ++t) { s1 += st[(size_t)t * nq * 2]; s2 += st[(size_t)t * nq * 2 + 1]; }
   }
   const float inv_n = 1.f / (float)(HW * cpg);
   mean = s1 * inv_n;
@@ -1386,24 +1386,27 @@ MULAN_API int mulan_groupnorm_bwd(const float* dy, const float* x1, const float*
 // ---- streaming forms (round 5): statistics / group sums handed in by the producers, see gn_fwd_stream_kernel.
 // Forward.  Exactly one of y (fp32, + ymax: the true maxima) and yplanes (split planes, + ymax: the bound) is written.
 // xstats1 (, xstats2 when C2 > 0): the partial sums the convolutions that produced x1 (, x2) left in their `ystats`
-// ([B][4][C / 4][2]: sum and sum of squares per image, 8-row tile, channel quad); mean / rstd [B, G] are then outputs.
+// ([B][xstats_tiles][C / 4][2]: sum and sum of squares per image, row tile of the producing launch (4, 8 or 16 per image:
+// mulan_conv3x3_f16x3_tile_rows) and channel quad); mean / rstd [B, G] are then outputs.
 // xstats1 == NULL: mean / rstd are inputs (e.g. from mulan_groupnorm_stats).  keepbits (optional, keep < 1): the
 // keep-bits as drawn, in the layout of mulan_groupnorm_fwd_planes_keepbits.
 MULAN_API int mulan_groupnorm_fwd_stream(const float* x1, const float* x2, int C1, int C2, const float* gamma,
                                          const float* beta, float* y, void* yplanes, float* mean, float* rstd,
-                                         const float* xstats1, const float* xstats2, int B, int hw, int G, float eps,
-                                         int act, float keep, unsigned long long seed, unsigned long long offset,
+                                         const float* xstats1, const float* xstats2, int xstats_tiles, int B, int hw,
+                                         int G, float eps, int act, float keep, unsigned long long seed,
+                                         unsigned long long offset,
                                          const unsigned long long* seed_dev, unsigned* ymax, unsigned* keepbits,
                                          hipStream_t stream) {
   const int Ct = C1 + C2;
   if (hw != HW || B <= 0 || G <= 0 || Ct % G != 0 || !mean || !rstd || (!y == !yplanes) || !(keep > 0.f) ||
-      (yplanes && !ymax) || (xstats1 && C2 > 0 && !xstats2) || (keepbits && !(keep < 1.f)))
+      (yplanes && !ymax) || (xstats1 && C2 > 0 && !xstats2) || (keepbits && !(keep < 1.f)) ||
+      (xstats1 && xstats_tiles != 4 && xstats_tiles != 8 && xstats_tiles != 16))
     return (int)hipErrorInvalidValue;
   const int cpg = Ct / G;
   if (cpg % 4 != 0 || 32 % cpg != 0 || C1 % 32 != 0 || C2 % 32 != 0 || C1 % cpg != 0 || (ymax && Ct / 32 > 16))
     return (int)hipErrorInvalidValue;
   GnArgs a{x1, x2, C1, C2, gamma, beta, y, mean, rstd, B, G, eps, act, keep, seed, offset, ymax, seed_dev,
-           static_cast<unsigned char*>(yplanes), keepbits, 0, xstats1, xstats2};
+           static_cast<unsigned char*>(yplanes), keepbits, 0, xstats1, xstats2, xstats_tiles};
   // tune[20] (dev A/B): quarters of a slab per block -- 0 / 4: 1024 threads, 2: 512, 1: 256 (the maxima array has 16
   // entries per image: (slabs) x (z blocks) must fit)
   int nsp = g_mulan_tune[20] == 1 ? 1 : (g_mulan_tune[20] == 2 ? 2 : 4);
@@ -1417,7 +1420,7 @@ MULAN_API int mulan_groupnorm_fwd_stream(const float* x1, const float* x2, int C
 
 // Backward (the arguments of mulan_groupnorm_bwd_fused / _fused_planes in one entry point).  gstats [B][4][(C1 + C2) / 4][2]:
 // the partial sums of g gamma and g gamma xhat (g = dy mask / keep act'(u)) per image, 8-row tile and channel quad, as the
-// input-gradient convolution that wrote dy left them (mulan_conv3x3_fwd_f16x3_gstats / _planes_in_gstats).  dx1planes
+// producer of dy would leave them (no shipped kernel does: DESIGN.md section 3.3; tests and tools form them with torch).  dx1planes
 // (optional; then C2 == 0, no add*, dymax required): dx1 as split planes instead of fp32, dx1max receives the bound.
 MULAN_API int mulan_groupnorm_bwd_stream(const float* dy, const unsigned* dymax, const float* x1, const float* x2, int C1,
                                          int C2, const float* gamma, const float* beta, const float* mean,

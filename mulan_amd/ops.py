@@ -1295,6 +1295,18 @@ GN_FILL_TRAIN = _os.environ.get("MULAN_GN_FILL_TRAIN", "0") == "1"
 # no pass over the tensor between two convolutions of a forward-only chain.  A/B switch: 0 = mulan_groupnorm_stats in
 # front of every convolution (bit-identical to the plane hand-over; with the hand-over the statistics agree to rounding).
 GN_FILL_STATS = _os.environ.get("MULAN_GN_FILL_STATS", "1") == "1"
+# training step: GroupNorm forward as the streaming kernel on the statistics the producing convolution left, where that
+# kernel is the faster one (GnConv3x3Fn.forward): dropout layers and the 2 x 128-channel concat, at 32 <= images per launch
+# <= 96 -- the per-GPU batches of an 8-GPU job.  Measured in the train step of BASELINE configs[2]
+# (profiles/r05_gn_fwd_stream_in_step.log): 64 images 42.78 -> 42.50 ms, 32 images 28.52 -> 28.42, 16 images 23.42 -> 23.65,
+# 128 images 78.98 -> 79.08 (what the kernel gains alone, 4 us per launch, the statistics in the convolution epilogue cost
+# back).  MULAN_GN_FWD_STREAM=0: the slab kernel everywhere (the round-4 path); GN_FWD_STREAM_B: the batch window.
+GN_FWD_STREAM = _os.environ.get("MULAN_GN_FWD_STREAM", "1") == "1"
+GN_FWD_STREAM_B = tuple(int(v) for v in _os.environ.get("MULAN_GN_FWD_STREAM_B", "32,96").split(","))
+
+
+def _gn_fwd_stream_on(B):
+    return GN_FWD_STREAM and GN_FWD_STREAM_B[0] <= B <= GN_FWD_STREAM_B[1]
 
 
 def _gn_stats_of(x, C):
@@ -1355,7 +1367,24 @@ class GnConv3x3Fn(torch.autograd.Function):
         # dropout layer whose backward will write planes (x1_grad_planes): keep the 4 keep-bits per float4 as drawn (2 MB at
         # B = 128, C = 128), so that the backward kernel does not repeat the Philox rounds
         keepbits = None
-        if KEEP_BITS and float(keep) < 1.0 and ctx.x1_grad_planes and any(ctx.needs_input_grad[:5]):
+        want_bits = KEEP_BITS and float(keep) < 1.0 and ctx.x1_grad_planes and any(ctx.needs_input_grad[:5])
+        # the convolutions that produced x1 (, x2) left the partial sums of the statistics: the streaming kernel (no
+        # statistics phase, 62 registers) where it is the faster one -- dropout layers and the 2 x 128-channel concat
+        # (profiles/r05_gn_stream_bench.log: 31.8 vs 36.0 us and 52.4 vs 55.6 us at B = 128; 128 channels without
+        # dropout: 30.2 vs 27.7 us, the slab kernel stays), see GN_FWD_STREAM
+        st1 = st2 = None
+        if _gn_fwd_stream_on(B) and (float(keep) < 1.0 or C2 > 0) and Ct // 32 <= MAX_PARTS:
+            st1 = _gn_stats_of(x1, C1)
+            st2 = _gn_stats_of(x2, C2) if (st1 is not None and x2 is not None) else None
+            if st1 is None or (x2 is not None and (st2 is None or st2.shape[1] != st1.shape[1])):
+                st1 = st2 = None
+        if st1 is not None:
+            if want_bits:
+                keepbits = torch.empty(B * (Ct // 32) * 1024, device=dev, dtype=torch.int32)
+            call("mulan_groupnorm_fwd_stream", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), None, ptr(ys), ptr(mean),
+                 ptr(rstd), ptr(st1), ptr(st2), int(st1.shape[1]), B, HW, groups, float(eps), int(act), float(keep), sv,
+                 int(offset), ptr(sd), ptr(bound), ptr(keepbits), stream())
+        elif want_bits:
             keepbits = torch.empty(B * (Ct // 32) * 1024, device=dev, dtype=torch.int32)
             call("mulan_groupnorm_fwd_planes_keepbits", ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(ys), ptr(mean),
                  ptr(rstd), B, HW, groups, float(eps), int(act), float(keep), sv, int(offset), ptr(sd), ptr(bound),
@@ -1369,9 +1398,15 @@ class GnConv3x3Fn(torch.autograd.Function):
         ymax = torch.empty((B, MAX_PARTS), device=dev, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
         mode = 0 if cbias is None else (1 if cbias.dim() == 2 else 2)
         bias_c, cb_c, res_c = _c(bias), _c(cbias), _c(res)
+        ystats = None
+        if _gn_fwd_stream_on(B) and N // 32 <= MAX_PARTS:   # by-product for the GroupNorm behind this convolution (see above)
+            rows = lib.load().mulan_conv3x3_f16x3_tile_rows(B, H, N, int(ymax is not None))
+            ystats = torch.empty((B, H // rows, N // 4, 2), device=dev, dtype=torch.float32)
         _timed("conv3x3_f16x3_kernel<planes_in>", 2.0 * B * HW * 9 * Ct * N,
-               lambda: call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c),
-                            ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), B, H, W, Ct, N, stream()))
+               lambda: call("mulan_conv3x3_fwd_f16x3_planes_in_stats", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c),
+                            ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), ptr(ystats), B, H, W, Ct, N, stream()))
+        if ystats is not None:
+            y._gnstats = (ystats, y._version)
         return GnConv3x3Fn._finish_forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, mean, rstd, ys, bound, wmax, y, ymax,
                                            (groups, int(act), float(keep), seed, int(offset)), skip, mode)
 

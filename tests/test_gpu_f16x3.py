@@ -868,7 +868,7 @@ def test_gn_conv_plane_hand_over_matches_the_two_op_path(ops, monkeypatch, B, C1
 
     ref, ref_names = run(False)
     got, got_names = run(True)
-    assert "mulan_groupnorm_fwd_planes" in got_names and "mulan_conv3x3_fwd_f16x3_planes_in" in got_names
+    assert "mulan_groupnorm_fwd_planes" in got_names and "mulan_conv3x3_fwd_f16x3_planes_in_stats" in got_names
     assert "mulan_groupnorm_fwd_dyn" not in got_names and "mulan_groupnorm_fwd_planes" not in ref_names
     assert got_names.count("mulan_conv3x3_fwd_f16x3") == 1          # only the input-gradient launch is left on it
     labels = ["y"] + [n for n, t in zip(("x1", "x2", "gamma", "beta", "w", "bias", "cb", "res"),
@@ -921,7 +921,7 @@ def test_gn_normalised_inside_the_convolution_is_bit_identical(ops, monkeypatch,
         got, got_names = run(True, train)
         assert "mulan_groupnorm_fwd_planes" in ref_names and "mulan_groupnorm_stats" not in ref_names
         assert "mulan_groupnorm_stats" in got_names and "mulan_conv3x3_fwd_f16x3_gn_in" in got_names
-        assert "mulan_groupnorm_fwd_planes" not in got_names and "mulan_conv3x3_fwd_f16x3_planes_in" not in got_names
+        assert "mulan_groupnorm_fwd_planes" not in got_names and "mulan_conv3x3_fwd_f16x3_planes_in_stats" not in got_names
         assert len(ref) == len(got) == (2 + len(leaves) if train else 2 + (2 if C2 else 1))
         for i, (a_, r_) in enumerate(zip(got, ref)):
             assert torch.equal(a_, r_), (train, i, float((a_.float() - r_.float()).abs().max()))
@@ -994,6 +994,7 @@ def test_forward_only_model_uses_the_fill_path_with_identical_losses(ops, monkey
     def run(fill, hand_over=False):
         monkeypatch.setattr(ops, "GN_FILL", fill)
         monkeypatch.setattr(ops, "GN_FILL_STATS", hand_over)
+        monkeypatch.setattr(ops, "GN_FWD_STREAM", False)   # (the reference is the slab kernel: mulan_groupnorm_stats' summation order)
         names.clear()
         with torch.no_grad():
             out = vdm.apply(params, x, None, None, step=0, rngs={"sample": PRNGKey(5)}, deterministic=True)

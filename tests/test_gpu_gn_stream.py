@@ -17,7 +17,7 @@ def ops(monkeypatch):
     _ops.lib.load()
     monkeypatch.setattr(_ops, "CONV_MODE", "f16x3")
     yield _ops
-    for k in (20, 21, 22):
+    for k in (20, 21, 22, 23):
         _ops.call("mulan_set_tuning", k, 0)
 
 
@@ -74,7 +74,7 @@ def test_forward_stream_matches_slab_kernel(ops, C1, C2, keep, nsp):
                  keep, 77, 128, None, p(bound), ops.stream())
     xs1, xs2 = xstats_of(x1), (xstats_of(x2) if C2 else None)
     ops.call("mulan_groupnorm_fwd_stream", p(x1), p(x2), C1, C2, p(gamma), p(beta), None, p(ys2), p(mean2), p(rstd2), p(xs1),
-             p(xs2), B, HW, G, 1e-6, 1, keep, 77, 128, None, p(bound2), p(kb2) if keep < 1 else None, ops.stream())
+             p(xs2), 4, B, HW, G, 1e-6, 1, keep, 77, 128, None, p(bound2), p(kb2) if keep < 1 else None, ops.stream())
     torch.cuda.synchronize()
     # statistics from the partial sums: those of the slab kernel to fp32 rounding (another summation order)
     assert float((mean - mean2).abs().max()) <= 2e-6 * float(mean.abs().max() + 1)
@@ -91,7 +91,7 @@ def test_forward_stream_matches_slab_kernel(ops, C1, C2, keep, nsp):
     m1, m2 = (torch.empty(B, 16, device="cuda", dtype=torch.int32) for _ in range(2))
     ops.call("mulan_groupnorm_fwd_dyn", p(x1), p(x2), C1, C2, p(gamma), p(beta), p(y), p(mean), p(rstd), B, HW, G, 1e-6, 1, keep,
              77, 128, None, p(m1), ops.stream())
-    ops.call("mulan_groupnorm_fwd_stream", p(x1), p(x2), C1, C2, p(gamma), p(beta), p(y2), None, p(mean), p(rstd), None, None, B,
+    ops.call("mulan_groupnorm_fwd_stream", p(x1), p(x2), C1, C2, p(gamma), p(beta), p(y2), None, p(mean), p(rstd), None, None, 0, B,
              HW, G, 1e-6, 1, keep, 77, 128, None, p(m2), None, ops.stream())
     assert torch.equal(y == 0, y2 == 0)
     assert float((y - y2).abs().max()) <= 1e-6 * float(y.abs().max())
@@ -237,3 +237,55 @@ def test_backward_stream_planes_output(ops, keep, tune):
     a, r = decode_planes(got, m_got, B, C), decode_planes(slab, m_slab, B, C)
     scale = float(ref_dx.abs().max())
     assert float((a - ref_dx).abs().max()) / scale <= 2.0 * float((r - ref_dx).abs().max()) / scale + 1e-6
+
+
+@pytest.mark.parametrize("B,keep,concat", [(3, 0.9, False), (2, 1.0, True), (3, 0.9, True)])
+@pytest.mark.parametrize("rows", [8, 2])
+def test_training_chain_runs_the_streaming_forward_on_the_producers_statistics(ops, monkeypatch, B, keep, concat, rows):
+    """the shipped use (ops.GnConv3x3Fn, training): a plane-fed convolution leaves the partial sums of its output
+    (mulan_conv3x3_fwd_f16x3_planes_in_stats, at 8- and 2-row tiles), the GroupNorm behind it -- norm2 with dropout, or the
+    up path's norm1 over the concat of two such outputs -- runs mulan_groupnorm_fwd_stream on them; outputs and every
+    gradient against the slab-kernel path (MULAN_GN_FWD_STREAM=0) to the rounding of the statistics, the ystats against
+    float64 sums, the same dropout bits"""
+    ops.call("mulan_set_tuning", 23, rows)
+    torch.manual_seed(B + int(keep * 10) + rows)
+    E = 128
+    mk = lambda *s, scale=1.0: (torch.randn(*s, device="cuda") * scale).requires_grad_(True)
+    x, xb = mk(B, HW, E, scale=2.0), mk(B, HW, E)
+    g0, b0, w0, c0 = mk(E), mk(E, scale=0.3), mk(3, 3, E, E, scale=0.03), mk(E)
+    Ct = 2 * E if concat else E
+    g1, b1, w1, c1 = mk(Ct), mk(Ct, scale=0.3), mk(3, 3, Ct, E, scale=0.03), mk(E)
+    gy = torch.randn(B, HW, E, device="cuda")
+    leaves = [x, xb, g0, b0, w0, c0, g1, b1, w1, c1]
+    names, stats = [], []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+
+    monkeypatch.setattr(ops, "GN_FWD_STREAM_B", (1, 1 << 30))    # (the product path: 32 ... 96 images per launch)
+
+    def run(stream):
+        monkeypatch.setattr(ops, "GN_FWD_STREAM", stream)
+        for t in leaves:
+            t.grad = None
+        names.clear()
+        h = ops.gn_conv3x3(x, None, g0, b0, w0, c0, act=True)                    # leaf input: the slab kernel
+        h2 = ops.gn_conv3x3(xb, None, g0, b0, w0, c0, res=xb, act=True) if concat else None
+        st = getattr(h, "_gnstats", None)
+        stats.append(None if st is None else (st[0].clone(), h.detach().clone()))
+        y = ops.gn_conv3x3(h, h2, g1, b1, w1, c1, act=True, keep=keep, seed=11, offset=1 << 20, x1_grad_planes=not concat)
+        (y * gy).sum().backward()
+        return [y.detach().clone()] + [t.grad.clone() for t in leaves if t.grad is not None], list(names)
+
+    ref, ref_names = run(False)
+    got, got_names = run(True)
+    assert "mulan_groupnorm_fwd_stream" in got_names and "mulan_groupnorm_fwd_stream" not in ref_names
+    assert got_names.count("mulan_groupnorm_fwd_stream") == 1      # the leaf-fed GroupNorms have no statistics: slab kernel
+    assert stats[0] is None and stats[1] is not None
+    st, h = stats[1]
+    assert st.shape == (B, 32 // rows, E // 4, 2)
+    hd = h.double().view(B, 32 // rows, rows * 32, E // 4, 4)
+    want = torch.stack((hd.sum((2, 4)), (hd * hd).sum((2, 4))), -1)
+    assert float((st.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert len(got) == len(ref)
+    for i, (a, r) in enumerate(zip(got, ref)):
+        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-30, (i, float((a - r).abs().max()), float(r.abs().max()))

@@ -106,7 +106,7 @@ def main():
 
         def fwd_stream(s, i, keep, kb=False, y=None):
             call("mulan_groupnorm_fwd_stream", ptr(s["x1"]), ptr(s["x2"]), C1, C2, ptr(gamma), ptr(beta), ptr(y),
-                 None if y is not None else ptr(s["ys"]), ptr(mean2), ptr(rstd2), ptr(xs1[i]), ptr(xs2[i]), B, HW, G, 1e-6, 1,
+                 None if y is not None else ptr(s["ys"]), ptr(mean2), ptr(rstd2), ptr(xs1[i]), ptr(xs2[i]), 4, B, HW, G, 1e-6, 1,
                  keep, 123, 0, None, ptr(bound2), ptr(s["kb"]) if kb else None, stream())
 
         # ---- correctness of the streaming forward against the slab kernel (statistics: another summation order)
