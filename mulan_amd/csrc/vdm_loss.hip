@@ -91,11 +91,27 @@ __global__ void expm1_weight_bwd_kernel(const float* __restrict__ gt, const floa
 __device__ __forceinline__ float encode_u8(unsigned char x) { return 2.f * (((float)x + 0.5f) / 256.f) - 1.f; }
 __device__ __forceinline__ float bin_val(int j) { return 2.f * (((float)j + 0.5f) / 256.f) - 1.f; }
 
+// The bins whose softmax term exp(-0.5 u_j^2 - mx) is not exactly 0.0f in fp32, u_j = (z0 - bin_val(j)) istd: with the
+// reference's gamma_0 = -13.3 the bins are 6 standard deviations apart and 5-7 of the 256 terms are non-zero.  expf
+// returns 0 below -104.7; every bin with -0.5 u_j^2 - mx > -106 is inside [jlo, jhi] (one bin and 1e-4 of slack for the
+// rounding of this estimate), as is the nearest bin (the maximum), so the sums over the window in ascending j are, bit
+// for bit, the sums over all 256 bins: the skipped terms add +0.0f.  Wide noise, infinities and NaN give the full range.
+__device__ __forceinline__ void bin_window(float z0, float istd, int& jlo, int& jhi) {
+  const float pos = (z0 + 1.f) * 128.f - 0.5f;                 // z0 in bin units: bin_val(j) = (j + 0.5) / 128 - 1
+  const float s = istd * (1.f / 128.f);                        // u_j = (pos - j) s
+  const float dstar = fabsf(pos - fminf(fmaxf(rintf(pos), 0.f), 255.f));     // distance to the nearest bin
+  const float R = sqrtf(212.f / (s * s) + dstar * dstar) * 1.0001f + 1.5f;
+  jlo = (int)fmaxf(0.f, fminf(255.f, floorf(pos - R)));
+  jhi = (int)fminf(255.f, fmaxf(0.f, ceilf(pos + R)));
+  if (!(R < 1e6f) || !(fabsf(pos) < 1e6f)) { jlo = 0; jhi = 255; }
+}
+
 struct QsArgs {
   const unsigned char* x;                       // [B,D]
   const float* g0; const float* g1; const float* gt; int gstride;  // gstride D (per element) or 0 (per sample)
   const float* eps0; const float* eps;
   float* zt; float* gbar; float* recon; float* klz; float* var0; float* var1;   // [B,D], [B] x5
+  int all_bins;                                 // dev (tune[24]): sum over all 256 bins instead of the non-zero window
 };
 
 __global__ __launch_bounds__(256) void qsample_fwd_kernel(QsArgs p) {
@@ -112,13 +128,16 @@ __global__ __launch_bounds__(256) void qsample_fwd_kernel(QsArgs p) {
     // reconstruction: -log softmax_j(-0.5 ((z - v_j) e^{-g0/2})^2)[x]
     const float z0 = f + expf(0.5f * g0) * p.eps0[o];
     const float istd = expf(-0.5f * g0);
+    int jlo, jhi;
+    bin_window(z0, istd, jlo, jhi);
+    if (p.all_bins) { jlo = 0; jhi = 255; }
     float mx = -INFINITY;
-    for (int j = 0; j < 256; ++j) {
+    for (int j = jlo; j <= jhi; ++j) {
       const float u = (z0 - bin_val(j)) * istd;
       mx = fmaxf(mx, -0.5f * u * u);
     }
     float se = 0.f;
-    for (int j = 0; j < 256; ++j) {
+    for (int j = jlo; j <= jhi; ++j) {
       const float u = (z0 - bin_val(j)) * istd;
       se += expf(-0.5f * u * u - mx);
     }
@@ -154,6 +173,7 @@ struct QsBwdArgs {
   const float* drecon;  // [B] or null (with dg0)
   const float* dklz;    // [B] or null (with dg1)
   float* dgt; float* dg0; float* dg1;   // [B,D] per-element grads (dg0/dg1 optional)
+  int all_bins;
 };
 
 __global__ __launch_bounds__(256) void qsample_bwd_kernel(QsBwdArgs p) {
@@ -177,10 +197,13 @@ __global__ __launch_bounds__(256) void qsample_bwd_kernel(QsBwdArgs p) {
     if (p.dg0) {
       const float g0 = p.g0[og], e0 = p.eps0[o];
       const float z0 = f + expf(0.5f * g0) * e0, istd = expf(-0.5f * g0);
+      int jlo, jhi;
+      bin_window(z0, istd, jlo, jhi);
+      if (p.all_bins) { jlo = 0; jhi = 255; }
       float mx = -INFINITY;
-      for (int j = 0; j < 256; ++j) { const float u = (z0 - bin_val(j)) * istd; mx = fmaxf(mx, -0.5f * u * u); }
+      for (int j = jlo; j <= jhi; ++j) { const float u = (z0 - bin_val(j)) * istd; mx = fmaxf(mx, -0.5f * u * u); }
       float se = 0.f, sd = 0.f;
-      for (int j = 0; j < 256; ++j) {
+      for (int j = jlo; j <= jhi; ++j) {
         const float u = (z0 - bin_val(j)) * istd;
         const float w = expf(-0.5f * u * u - mx);
         se += w;
@@ -367,7 +390,8 @@ MULAN_API int mulan_qsample_fwd(const unsigned char* x, const float* g0, const f
                                 float* loss_recon, float* loss_klz, float* var0, float* var1, int B, int d,
                                 hipStream_t stream) {
   if (d != D || B <= 0) return (int)hipErrorInvalidValue;
-  QsArgs a{x, g0, g1, gt, per_element_gamma ? D : 0, eps0, eps, zt, gbar, loss_recon, loss_klz, var0, var1};
+  QsArgs a{x, g0, g1, gt, per_element_gamma ? D : 0, eps0, eps, zt, gbar, loss_recon, loss_klz, var0, var1,
+           g_mulan_tune[24]};
   hipLaunchKernelGGL(qsample_fwd_kernel, dim3(B), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
@@ -377,7 +401,8 @@ MULAN_API int mulan_qsample_bwd(const unsigned char* x, const float* g0, const f
                                 float* dg1, int B, int d, hipStream_t stream) {
   if (d != D || B <= 0) return (int)hipErrorInvalidValue;
   if ((dg0 && !drecon) || (dg1 && !dklz)) return (int)hipErrorInvalidValue;
-  QsBwdArgs a{x, g0, g1, gt, per_element_gamma ? D : 0, eps0, eps, dzt, dgbar, drecon, dklz, dgt, dg0, dg1};
+  QsBwdArgs a{x, g0, g1, gt, per_element_gamma ? D : 0, eps0, eps, dzt, dgbar, drecon, dklz, dgt, dg0, dg1,
+              g_mulan_tune[24]};
   hipLaunchKernelGGL(qsample_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }

@@ -444,6 +444,41 @@ def test_qsample(ops, per_elem):
     assert rel_err(d1.grad.cpu().numpy(), t1.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("g0_mean", [-13.3, -9.0, -6.0, -2.0, 3.0])
+def test_qsample_bin_window_is_the_sum_over_all_bins(ops, g0_mean):
+    """the reconstruction term's softmax over the 256 bins (ldm/model_vdm.py:269-296 under :100-108) is summed over the
+    bins whose term is not exactly 0.0f only (vdm_loss.hip bin_window): bit for bit the sum over all bins (dev switch
+    tune[24]) -- forward values and the gamma_0 gradient, from the reference's gamma_0 = -13.3 (bins 6 standard deviations
+    apart) to noise wider than the whole range, with outliers far outside [-1, 1]"""
+    rng = np.random.default_rng(int(-g0_mean * 10) + 200)
+    B = 5
+    x = rng.integers(0, 256, (B, 3072)).astype(np.uint8)
+    x[0, :16] = 0
+    x[0, 16:32] = 255
+    g0 = g0_mean + 0.7 * rng.standard_normal((B, 3072))
+    g1, gt = 5.0 + 0.5 * rng.standard_normal((B, 3072)), rng.uniform(-12, 4, (B, 3072))
+    e0, e = rng.standard_normal((B, 3072)), rng.standard_normal((B, 3072))
+    e0[0, :32] *= 50.0                                        # z_0 far outside the bins
+    e0[1, :8] = 0.0
+    dr = rng.standard_normal(B)
+
+    def run(all_bins):
+        ops.call("mulan_set_tuning", 24, all_bins)
+        d0, d1, dt = (dev(v).requires_grad_() for v in (g0, g1, gt))
+        out = ops.qsample(torch.tensor(x).cuda(), d0, d1, dt, dev(e0), dev(e))
+        (out[2] * dev(dr)).sum().backward()
+        return [o.detach().clone() for o in out] + [d0.grad.clone()]
+
+    try:
+        ref = run(1)
+        got = run(0)
+    finally:
+        ops.call("mulan_set_tuning", 24, 0)
+    assert bool(torch.isfinite(ref[2]).all())
+    for i, (a, r) in enumerate(zip(got, ref)):
+        assert torch.equal(a, r), (i, float((a - r).abs().max()))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("per_elem", [True, False])
 def test_diffusion_loss(ops, mode, per_elem):
