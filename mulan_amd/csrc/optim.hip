@@ -16,32 +16,51 @@ struct AdamArgs {
   const float* dyn;          // optional [3] on the device: lr, 1 - b1^t, 1 - b2^t (stream-ordered: graph replay)
 };
 
+// U float4 per array and thread in flight (U = 2: 10 loads of 16 B before the first use); NT: non-temporal loads and
+// stores (every byte is touched once per step; the arrays are 4 x 142 MB + the gradient, nothing of it is reused
+// before the next step's weight packing reads p)
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(AdamArgs a) {
   const size_t n4 = a.n >> 2;
   const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2, ome = 1.f - a.ema_rate;
   if (a.gscale_dev) a.gscale *= a.gscale_dev[0];
   if (a.dyn) { a.lr = a.dyn[0]; a.bc1 = a.dyn[1]; a.bc2 = a.dyn[2]; }
-  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x) {
-    const size_t i = q << 2;
-    f32x4 p = ld_stream4(a.p + i);
-    const f32x4 g = ld_stream4(a.g + i);
-    f32x4 m = ld_stream4(a.m + i);
-    f32x4 v = ld_stream4(a.v + i);
-    f32x4 e = ld_stream4(a.ema + i);
+  const auto ld = [](const float* q) -> f32x4 {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+    else return ld_stream4(q);
+  };
+  const auto st = [](float* q, f32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q));
+    else *reinterpret_cast<f32x4*>(q) = v;
+  };
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += stride * U) {
+    f32x4 p[U], g[U], m[U], v[U], e[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gk = g[k] * a.gscale;
-      m[k] = a.b1 * m[k] + omb1 * gk;
-      v[k] = a.b2 * v[k] + omb2 * gk * gk;
-      float u = (m[k] / a.bc1) / (sqrtf(v[k] / a.bc2) + a.eps);
-      if (i + k < a.n_decay) u += a.wd * p[k];
-      p[k] -= a.lr * u;
-      e[k] += ome * (p[k] - e[k]);
+    for (int u = 0; u < U; ++u) {
+      const size_t q = q0 + stride * u;
+      if (q < n4) {
+        const size_t i = q << 2;
+        p[u] = ld(a.p + i); g[u] = ld(a.g + i); m[u] = ld(a.m + i); v[u] = ld(a.v + i); e[u] = ld(a.ema + i);
+      }
     }
-    *reinterpret_cast<f32x4*>(a.p + i) = p;
-    *reinterpret_cast<f32x4*>(a.m + i) = m;
-    *reinterpret_cast<f32x4*>(a.v + i) = v;
-    *reinterpret_cast<f32x4*>(a.ema + i) = e;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t q = q0 + stride * u;
+      if (q >= n4) continue;
+      const size_t i = q << 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = g[u][k] * a.gscale;
+        m[u][k] = a.b1 * m[u][k] + omb1 * gk;
+        v[u][k] = a.b2 * v[u][k] + omb2 * gk * gk;
+        float up = (m[u][k] / a.bc1) / (sqrtf(v[u][k] / a.bc2) + a.eps);
+        if (i + k < a.n_decay) up += a.wd * p[u][k];
+        p[u][k] -= a.lr * up;
+        e[u][k] += ome * (p[u][k] - e[u][k]);
+      }
+      st(a.p + i, p[u]); st(a.m + i, m[u]); st(a.v + i, v[u]); st(a.ema + i, e[u]);
+    }
   }
   // tail (n not a multiple of 4)
   if (blockIdx.x == 0) {
@@ -120,10 +139,21 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, float* ema
   AdamArgs a{p, g, m, v, ema, n, n_decay, lr, b1, b2, eps, weight_decay,
              (float)(1.0 - pow((double)b1, st)), (float)(1.0 - pow((double)b2, st)), ema_rate, grad_scale,
              grad_scale_dev, dyn};
-  size_t blocks = ((n >> 2) + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  // tune[25] (dev A/B): 0 = as shipped (one float4 per array in flight, non-temporal); 1: plain loads / stores (the form of
+  // rounds 1-4); 2: two float4 in flight, plain; 3: two, non-temporal.  tune[26]: block cap (0 = 8192).  Alone at 35.6 M
+  // elements (tools/adamw_bench.py, profiles/r05_adamw_bench.log): 264 us plain / 2048 blocks -> 227 us (5.6 TB/s).  In
+  // the train step (71 M parameters, 2.56 GB per launch) the kernel was at the copy ceiling before: 438 -> 433 us.
+  const int var = g_mulan_tune[25];
+  const int U = (var == 2 || var == 3) ? 2 : 1;
+  size_t blocks = ((n >> 2) + 256 * U - 1) / (256 * U);
+  const size_t cap = g_mulan_tune[26] > 0 ? (size_t)g_mulan_tune[26] : 8192;
+  if (blocks > cap) blocks = cap;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  const dim3 grid((unsigned)blocks);
+  if (var == 1) hipLaunchKernelGGL((adamw_ema_kernel<1, false>), grid, dim3(256), 0, stream, a);
+  else if (var == 2) hipLaunchKernelGGL((adamw_ema_kernel<2, false>), grid, dim3(256), 0, stream, a);
+  else if (var == 3) hipLaunchKernelGGL((adamw_ema_kernel<2, true>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((adamw_ema_kernel<1, true>), grid, dim3(256), 0, stream, a);
   MULAN_CHECK_LAUNCH();
 }
 
