@@ -110,7 +110,7 @@ class TrainState:
         self._supers = []
         run = []
 
-        def flush():
+        def flush_params():
             if len(run) >= 2:
                 (path0, off0, shape), _ = run[0]
                 G, n = len(run), run[0][1].numel()
@@ -122,17 +122,35 @@ class TrainState:
                 self._supers.append((w, off0, G * n, [leaf for _, leaf in run]))
             run.clear()
 
-        for entry, leaf in zip(self.layout, self._leaves):
-            path, off_, shape = entry
-            ok = path[-2:] == ('cond_proj', 'kernel') and leaf.numel() % 4 == 0
-            if ok and run and (run[-1][0][0][0] != path[0] or run[-1][0][2] != shape or
-                               run[-1][0][1] + run[-1][1].numel() != off_):
-                flush()
-            if ok:
-                run.append((entry, leaf))
-            else:
-                flush()
-        flush()
+        def scan(leaves, flush):
+            for entry, leaf in zip(self.layout, leaves):
+                path, off_, shape = entry
+                ok = path[-2:] == ('cond_proj', 'kernel') and leaf.numel() % 4 == 0
+                if ok and run and (run[-1][0][0][0] != path[0] or run[-1][0][2] != shape or
+                                   run[-1][0][1] + run[-1][1].numel() != off_):
+                    flush()
+                if ok:
+                    run.append((entry, leaf))
+                else:
+                    flush()
+            flush()
+
+        scan(self._leaves, flush_params)
+        # ... and the same runs of the EMA parameters (evaluators, sampler, ODE likelihood: forward-only, no gradient
+        # sink): one batched GEMM per U-Net pass instead of a split-k GEMM + reduction per ResnetBlock
+        self._ema_groups = []
+
+        def flush_ema():
+            if len(run) >= 2:
+                (path0, off0, shape), _ = run[0]
+                G, n = len(run), run[0][1].numel()
+                grp = ops.CondProjGroup(self.ema[off0:off0 + G * n].view(G, *shape))
+                for i, (_, leaf) in enumerate(run):
+                    leaf._group = (grp, i)
+                self._ema_groups.append(grp)
+            run.clear()
+
+        scan([leaf for _, leaf in tree_leaves_in_layout(self.ema_params, self.layout)], flush_ema)
 
     def drop_graph_refs(self):
         """forget every cached autograd graph (the per-forward cache of the grouped FiLM projections): needed before a
@@ -140,6 +158,8 @@ class TrainState:
         for _, _, _, leaves in self._supers:
             for leaf in leaves:
                 leaf._group[0].clear()
+        for grp in self._ema_groups:
+            grp.clear()
 
     def reducer_leaves(self):
         """(tensor, offset, numel) per gradient-carrying tensor for parallel.GradReducer: grouped leaves are
