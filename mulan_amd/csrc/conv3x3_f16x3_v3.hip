@@ -49,6 +49,7 @@ template <int TR> struct V3Geo {
   static constexpr int GN_SLOT = SMEM + GN_MAXC / 4 * GN_ENT;   // 16 floats behind the table: [0] bound, [4..11] block reduction
   static constexpr int SMEM_GN = GN_SLOT + 64;      // TR = 8: 72000
   static_assert(TR == 8 || TR == 4 || TR == 2, "tile height");
+  static_assert(3 * BUF >= 16 * (GN_MAXC / 4) * 8, "the statistics prologue stages 16 tiles x C / 4 partial sums in the patch buffers");
 };
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -207,16 +208,39 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
     const int qpg = cpg >> 2, nq1 = ldx >> 2, ntile = p.xstats_tiles > 0 ? p.xstats_tiles : p.H / 8;   // (the PRODUCER's tiles)
     const float inv_n = 1.f / (float)(p.H * kW * cpg);
+    typedef float f32x2s __attribute__((ext_vector_type(2)));
+    f32x2s* part = reinterpret_cast<f32x2s*>(smem);    // [ntile][C / 4] (sum, sum of squares): the patch buffers are still free
+    if (p.xstats) {
+      // all partial sums of this image into LDS, every thread's loads in flight together.  (Summed straight from global
+      // memory by the C / 4 threads below, the ntile loads of a thread are a dependent chain of L2 round trips, 16 of
+      // them behind a launch with 2-row tiles: the sampler's reverse step at 16 images went 7.12 -> 7.01 ms with this;
+      // what is left of the prologue is 4-5 us of a 30-33 us block, profiles/r05_gnf_timeline.log.)
+      const int nq = C >> 2, total = ntile * nq;
+      for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+        f32x2s v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 256;
+          if (i < total) {
+            const int t = i / nq, qq = i - t * nq;
+            const float* src = qq < nq1 ? p.xstats + (((size_t)b * ntile + t) * nq1 + qq) * 2
+                                        : p.xstats2 + (((size_t)b * ntile + t) * nq1 + (qq - nq1)) * 2;
+            v[u] = *reinterpret_cast<const f32x2s*>(src);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i0 + u * 256 < total) part[i0 + u * 256] = v[u];
+      }
+      __syncthreads();
+    }
     for (int e = tid; e < C / 4; e += 256) {
       const int c = e * 4, g = c / cpg;
       float mean, rstd;
       if (p.xstats) {      // sums of the group's channel quads over the row tiles, in a fixed order
         float s1 = 0.f, s2 = 0.f;
-        for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) {
-          const float* src = qq < nq1 ? p.xstats + ((size_t)b * ntile * nq1 + qq) * 2
-                                      : p.xstats2 + ((size_t)b * ntile * nq1 + (qq - nq1)) * 2;
-          for (int t = 0; t < ntile; ++t) { s1 += src[(size_t)t * nq1 * 2]; s2 += src[(size_t)t * nq1 * 2 + 1]; }
-        }
+        for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq)
+          for (int t = 0; t < ntile; ++t) { const f32x2s v = part[t * (C >> 2) + qq]; s1 += v[0]; s2 += v[1]; }
         mean = s1 * inv_n;
         rstd = rsqrtf(fmaxf(0.f, s2 * inv_n - mean * mean) + p.gn_eps);
         if (p.gn_mean_out && by == 0 && h0 == 0 && (e % qpg) == 0) {

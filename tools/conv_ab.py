@@ -71,13 +71,14 @@ def main():
             launch()
             torch.cuda.synchronize()
             call("mulan_set_debug_buffer", None)
-            nblk = B * 4 * (N // 128)
+            rows = L.mulan_conv3x3_f16x3_tile_rows(B, 32, N, int(ymax is not None))    # tile height of this launch
+            nblk = B * (32 // rows) * (N // 128)
             t = buf[64:64 + 4 * nblk].cpu().numpy().reshape(nblk, 4).astype(np.float64) * 0.01
             t -= t[:, 0].min()
             cyc = buf[:32].cpu().numpy().astype(np.float64)
             loop_us = t[:32, 2] - t[:32, 1]
             print(f"  {name}: in-kernel clock over the main loop (blocks 0-31): {np.median(cyc / loop_us) * 1e-3:.3f} GHz; "
-                  f"loop cycles p50 {np.median(cyc):.0f} (MFMA issue cycles of one wave: {(C // 32) * 9 * 96 * 16})")
+                  f"loop cycles p50 {np.median(cyc):.0f} (MFMA issue cycles of one wave: {(C // 32) * 9 * 12 * rows * 16}, {rows} rows per block)")
             hi = ((np.arange(nblk) >> 8) & 1) == 1
             for nm, m in (("prio 1", hi), ("prio 0", ~hi)):
                 if not m.any():
