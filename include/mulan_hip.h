@@ -127,11 +127,14 @@ int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax,
 /* ... and (round 5) with the by-product the NEXT GroupNorm needs: ystats (optional) receives the partial sums of y and
  * y^2 per (image, row tile of this launch, channel quad), [B][H / mulan_conv3x3_f16x3_tile_rows(B, H, N, ymax != NULL)]
  * [N / 4][2] floats -- mulan_groupnorm_fwd_stream forms mean / rstd from them (norm2 behind conv1, the next block's
- * norm1 behind conv2: ldm/model_vdm.py:622-644), so that pass needs no statistics phase. */
+ * norm1 behind conv2: ldm/model_vdm.py:622-644), so that pass needs no statistics phase.  alone != 0: the caller
+ * vouches that no other stream's kernels share the chip with this launch (a forward pass, an evaluator); launches of at
+ * most 256 blocks then run as k-split blocks of eight waves that take a whole CU's LDS (two waves per SIMD where a
+ * 4-wave block would sit alone on its CU).  The GroupNorm-fed entry point below always may. */
 int mulan_conv3x3_fwd_f16x3_planes_in_stats(const void* xplanes, const unsigned* xmax, const void* wp, const unsigned* wmax,
                                             const float* bias, const float* cbias, int cbias_mode, const float* res,
-                                            float* y, unsigned* ymax, float* ystats, int B, int H, int W, int C, int N,
-                                            mulan_stream_t stream);
+                                            float* y, unsigned* ymax, float* ystats, int alone, int B, int H, int W,
+                                            int C, int N, mulan_stream_t stream);
 /* GroupNorm (+ swish) normalised inside the convolution that consumes it (round 3; ResnetBlock norm1 + swish -> conv1,
  * norm2 + swish -> conv2 wherever no dropout is drawn: ldm/model_vdm.py:622-623,632-633,643-650 under eval_step /
  * sample / the likelihood evaluators).  mulan_groupnorm_stats reads x once and leaves mean / rstd [B, G] and the a-priori

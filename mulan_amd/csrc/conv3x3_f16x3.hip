@@ -1335,10 +1335,12 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
 // _stats: ystats (optional) receives the partial sums of y and y^2 per (image, row tile of this launch, channel quad),
 // [B][H / mulan_conv3x3_f16x3_tile_rows(B, H, N, ymax != NULL)][N / 4][2] -- what mulan_groupnorm_fwd_stream forms the
 // statistics of the NEXT GroupNorm from (norm2 behind conv1, the next block's norm1 behind conv2: model_vdm.py:622-644).
+// alone != 0: the caller has no other stream's kernels on the chip during this launch (a forward pass, an evaluator):
+// launches of at most 256 blocks then run as k-split blocks of eight waves (conv3x3_f16x3_v3.hip, KS).
 MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in_stats(const void* xplanes, const unsigned* xmax, const void* wp,
                                                       const unsigned* wmax, const float* bias, const float* cbias,
                                                       int cbias_mode, const float* res, float* y, unsigned* ymax,
-                                                      float* ystats, int B, int H, int W, int C, int N,
+                                                      float* ystats, int alone, int B, int H, int W, int C, int N,
                                                       hipStream_t stream) {
   if (W != kW || B <= 0 || C <= 0 || N <= 0 || !xplanes || !xmax || !wmax || !mulan_conv3x3_f16x3_v3_eligible(H, C, N) ||
       (size_t)B * H * W * C * 4 >= 0x80000000ull || (ymax && (H / TR2) * (N / BN) > kMaxParts))
@@ -1346,6 +1348,7 @@ MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in_stats(const void* xplanes, const
   ConvArgsH a{nullptr, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
               cbias ? cbias_mode : 0, g_mulan_debug_buffer, nullptr, ymax, static_cast<const unsigned char*>(xplanes)};
   a.ystats = ystats;
+  a.alone = alone;
   return mulan_launch_conv3x3_f16x3_v3(a, stream);
 }
 
@@ -1353,8 +1356,8 @@ MULAN_API int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsig
                                                 const unsigned* wmax, const float* bias, const float* cbias,
                                                 int cbias_mode, const float* res, float* y, unsigned* ymax, int B, int H,
                                                 int W, int C, int N, hipStream_t stream) {
-  return mulan_conv3x3_fwd_f16x3_planes_in_stats(xplanes, xmax, wp, wmax, bias, cbias, cbias_mode, res, y, ymax, nullptr, B,
-                                                 H, W, C, N, stream);
+  return mulan_conv3x3_fwd_f16x3_planes_in_stats(xplanes, xmax, wp, wmax, bias, cbias, cbias_mode, res, y, ymax, nullptr, 0,
+                                                 B, H, W, C, N, stream);
 }
 
 // y = conv3x3(act(GroupNorm([x1 | x2]))) + bias + cbias + res with the normalisation done inside the convolution's patch
@@ -1388,7 +1391,7 @@ MULAN_API int mulan_conv3x3_fwd_f16x3_gn_in(const float* x1, const float* x2, in
               cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(yplanes_out), ymax, nullptr,
               x2, mean, rstd, gamma, beta, act, G,
               ystats, xstats1, xstats2, xstats1 ? mean : nullptr, xstats1 ? rstd : nullptr, xstats1 ? bound : nullptr, eps,
-              0, xstats_tiles};
+              0, xstats_tiles, 1};       // alone: forward-only paths (and the forward pass of a train step)
   return mulan_launch_conv3x3_f16x3_v3(a, stream);
 }
 

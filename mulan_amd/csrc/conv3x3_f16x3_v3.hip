@@ -90,10 +90,19 @@ __device__ __forceinline__ void mfma16(f32x4v& acc, const f16x3::f16x8& a, const
 // chunk 2 j + 3 into buffer A in step 5, right behind the barrier that frees it).  The halo columns and the rows outside
 // the image are never written: the buffers are zeroed once at the start (a row outside the image is DMA'd into the dummy
 // area instead: no branch in the loop body).  The barriers of the loop wait for the DMAs (vmcnt) like for any LDS write.
-template <int ABL, bool PIN = false, int GNF = 0, bool DMA = false, int TR = 8>
-__global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
+// KS (round 5): k-split.  KS = 2: the block is two groups of four waves; group g runs the loop above over its half of the
+// chunk pairs in its own LDS region (patches, GroupNorm table), the barriers are shared (both groups execute the same
+// schedule), and at the end the groups swap halves of their accumulators through LDS and each finishes half of the pixel
+// tiles.  For launches of at most 256 blocks -- one block per CU, one wave per SIMD, nothing to fill the stalls of the
+// main loop (3 x the MFMA issue time at 16 images, profiles/r05_gnf_timeline.log): two waves per SIMD without a second
+// patch fill, without more LDS reads per MFMA (an 8-wave block of 16-cout waves would read every pixel fragment twice)
+// and without traffic through memory (a split-k PAIR of blocks would exchange the 32 MB output tile through HBM).  The
+// sum of an output element is (first half of the channels) + (second half): deterministic, not the bits of KS = 1.
+template <int ABL, bool PIN = false, int GNF = 0, bool DMA = false, int TR = 8, int KS = 1>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   static_assert(!(PIN && GNF), "GroupNorm-fed fill reads fp32");
   static_assert(!DMA || PIN, "LDS-DMA fill: plane-fed instantiation only");
+  static_assert(KS == 1 || (KS == 2 && ABL == 0), "k-split: one or two groups of four waves");
   using Geo = V3Geo<TR>;
   constexpr int TR3 = TR, NPT = 2 * TR;              // NPT: 16-pixel tiles per wave (two per image row)
   constexpr int P3_ROWS = Geo::ROWS, P3_PLANE = Geo::PLANE, P3_BUF = Geo::BUF, P3_DUMMY = Geo::DUMMY, SMEM3_B = Geo::SMEM;
@@ -103,8 +112,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   constexpr int ST0 = NPT == 16 ? 6 : (NPT == 8 ? 3 : 0), ST1 = NPT == 16 ? 8 : (NPT == 8 ? 4 : 1);
   constexpr int LD0 = NPT == 16 ? 10 : (NPT == 8 ? 5 : 2), LD1 = NPT == 16 ? 12 : (NPT == 8 ? 6 : 3);
   constexpr int WL0 = NPT > 4 ? 1 : 0;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_blk[];
+  constexpr int REGION = GNF ? Geo::SMEM_GN : Geo::SMEM;      // LDS of one group
+  static_assert(KS == 1 || KS * REGION >= NPT * 8192 + 512, "k-split: the accumulator exchange + the tail reductions fit the two regions");
+  // (KS = 2) tid / wave: within the group; everything below that is indexed by them or lives in `smem` is per group
+  const int tid_b = threadIdx.x;
+  const int kgrp = KS == 2 ? __builtin_amdgcn_readfirstlane(tid_b >> 8) : 0;
+  unsigned char* const smem = smem_blk + kgrp * REGION;
+  const int tid = KS == 2 ? (tid_b & 255) : tid_b, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, grp = lane >> 4, sel = lane >> 5, khalf = grp & 1;
   const int tiles_per_img = p.H / TR3;
@@ -120,16 +135,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   const int n0 = by * BN;
   const int C = p.C, N = p.N;
   const int nchunks = C / CK, npairs = nchunks / 2;
+  const int j0 = KS == 2 ? kgrp * (npairs / 2) : 0, j1 = KS == 2 ? j0 + npairs / 2 : npairs;   // this group's chunk pairs
   const int ldx = (GNF && p.x2) ? C / 2 : C;          // channels per pixel of the tensor(s) behind x (, x2)
   const int nch1 = ldx / CK;
   // every second block of a CU runs ahead (blocks i and i + 256 share a CU under breadth-first dispatch)
-  if (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+  if (KS == 1 && (((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
   float sx, inv_x, sw, inv_w;
   scale_of(row_max16(p.xmax, b), sx, inv_x);
   scale_of(row_max16(p.wmax, 0), sw, inv_w);
   // dev-only timeline (mulan_set_debug_buffer; tools/conv_ab.py --timeline): per block start / loop start / loop end / end
   const unsigned tl_blk = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool tl = p.stamps && tid == 0 && tl_blk < 2048;
+  const bool tl = p.stamps && tid_b == 0 && tl_blk < 2048;
   if (tl) p.stamps[64 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
 
   f32x4v acc[NPT][2];                                // [pixel tile][cout tile]
@@ -384,18 +400,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PPW; ++k) { dma_piece(bufA, 0, k); dma_piece(bufB, nchunks > 1 ? 1 : 0, k); }
+    for (int k = 0; k < PPW; ++k) { dma_piece(bufA, 2 * j0, k); dma_piece(bufB, nchunks > 1 ? 2 * j0 + 1 : 0, k); }
   } else {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       i32x4 r[PV3];
 #pragma unroll
-      for (int s = 0; s < PV3; ++s) r[s] = load_slot(slot_of(tid, s), c);
+      for (int s = 0; s < PV3; ++s) r[s] = load_slot(slot_of(tid, s), 2 * j0 + c);
 #pragma unroll
-      for (int s = 0; s < PV3; ++s) store_slot(c ? bufB : bufA, slot_of(tid, s), r[s], c);
+      for (int s = 0; s < PV3; ++s) store_slot(c ? bufB : bufA, slot_of(tid, s), r[s], 2 * j0 + c);
     }
   }
-  load_w(wf[0], tile_index(0, 0), tile_index(0, 1));
+  load_w(wf[0], tile_index(j0, 0), tile_index(j0, 1));
   // patch slots in flight: two register sets (A, B) of two slots each, fetched two steps before they are split and
   // stored (the fetch is an HBM / Infinity-Cache access; one step is ~1.5 k cycles of MFMA issue):
   //   step:   0        1        2        3        4        5        6        7        8
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   //   fetch:  A k2 c0  -        -        A k0 c1  B k1 c1  A k2 c1  -        A k0 c0' B k1 c0'
   // (k: slot pair, c0 / c1: the two chunks being filled, c0': the first chunk of the next pair's fill)
   if constexpr (!DMA) {
-    const int c2 = nchunks > 2 ? 2 : nchunks - 1;
+    const int c2 = min(2 * j0 + 2, nchunks - 1);
     stgA[0] = load_slot(slot_of(tid, 0), c2);
     stgA[1] = load_slot(slot_of(tid, 1), c2);
     stgB[0] = load_slot(slot_of(tid, 2), c2);
@@ -416,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
 
   if (tl) p.stamps[65 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
   const unsigned long long cyc0 = tl ? __builtin_amdgcn_s_memtime() : 0ull;
-  for (int j = 0; j < npairs; ++j) {
+  for (int j = j0; j < j1; ++j) {
     int t_l = tid;
     asm volatile("" : "+v"(t_l));                    // launder: slot geometry is recomputed inside the loop
     const int cfill0 = min(2 * j + 2, nchunks - 1), cfill1 = min(2 * j + 3, nchunks - 1);
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
       // past the end: a harmless reload of the last step.  (The lane's unit selector is laundered per step so that the
       // nine selected tap offsets are formed where they are used instead of living in registers across the loop.)
       const bool last = (s == 8);
-      const bool over = last && (j + 1 >= npairs);
+      const bool over = last && (j + 1 >= j1);
       const int jn = last ? (over ? j : j + 1) : j;
       const int sn = last ? (over ? 8 : 0) : s + 1;
       const int nA = (last && !over) ? bufC : bufA, nB = (last && !over) ? bufA : bufB;
@@ -511,6 +527,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   if (GNF != 0 && p.xstats) scale_of(__float_as_uint(*reinterpret_cast<const float*>(smem + GN_SLOT)), sx, inv_x);
   else scale_of(row_max16(p.xmax, b), sx, inv_x);    // (re-derived here: nothing of it lives across the main loop)
   scale_of(row_max16(p.wmax, 0), sw, inv_w);
+  constexpr int HPT = NPT / 2;
+  if constexpr (KS == 2) {
+    // the groups swap halves: group 0 keeps pixel tiles [0, HPT) and receives group 1's sums for them, group 1 the rest.
+    // Slot (pixel tile, cout tile, thread of the group): the receiver is the same thread of the other group (same wave,
+    // same lane -> the same couts and pixels).  The exchange overlays both regions (the bound above is read already).
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, HPT> IH;
+    f32x4v* xch = reinterpret_cast<f32x4v*>(smem_blk);
+    auto send = [&](auto lo) {
+#pragma unroll
+      for (int i = 0; i < HPT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) xch[((decltype(lo)::value + i) * 2 + ct) * 256 + tid] = acc[decltype(lo)::value + i][ct];
+    };
+    auto recv = [&](auto lo) {
+#pragma unroll
+      for (int i = 0; i < HPT; ++i)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4v o = xch[((decltype(lo)::value + i) * 2 + ct) * 256 + tid];
+          f32x4v& a = acc[decltype(lo)::value + i][ct];
+          a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3];
+        }
+    };
+    __syncthreads();                                   // every wave is through its last LDS read and has its scales
+    if (kgrp == 0) send(IH{}); else send(I0{});
+    __syncthreads();
+    if (kgrp == 0) recv(I0{}); else recv(IH{});
+  }
   const float* __restrict__ res = p.res;
   const float* __restrict__ cbp = p.cbias;
   float* __restrict__ yout = p.y;
@@ -528,9 +573,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   unsigned omax = 0;
   float ys1[2] = {0.f, 0.f}, ys2[2] = {0.f, 0.f};    // (ystats) sums of y and y^2 over this lane's pixels, per cout tile
   // one straight-line body per (residual, per-pixel FiLM bias) combination: the loads of all tiles can be in flight together
-  auto finish = [&](auto has_res, auto has_cb2, auto has_ys) {
+  auto finish = [&](auto has_res, auto has_cb2, auto has_ys, auto lo, auto hi) {
 #pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) {
+    for (int pt = decltype(lo)::value; pt < decltype(hi)::value; ++pt) {
       const size_t pixbase = ((((size_t)b * p.H + h0 + (pt >> 1)) * kW) + (pt & 1) * 16 + l15) * N + nb;
       f32x4 add[2];
 #pragma unroll
@@ -567,36 +612,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3_v3_kernel(ConvArgsH p) {
   };
   using T = std::true_type;
   using F = std::false_type;
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, HPT> PH;
+  typedef std::integral_constant<int, NPT> PN;
+  auto finish3 = [&](auto has_ys, auto lo, auto hi) {
+    if (res) { if (p.cbias_mode == 2) finish(T{}, T{}, has_ys, lo, hi); else finish(T{}, F{}, has_ys, lo, hi); }
+    else { if (p.cbias_mode == 2) finish(F{}, T{}, has_ys, lo, hi); else finish(F{}, F{}, has_ys, lo, hi); }
+  };
   auto finish2 = [&](auto has_ys) {
-    if (res) { if (p.cbias_mode == 2) finish(T{}, T{}, has_ys); else finish(T{}, F{}, has_ys); }
-    else { if (p.cbias_mode == 2) finish(F{}, T{}, has_ys); else finish(F{}, F{}, has_ys); }
+    if constexpr (KS == 2) { if (kgrp == 0) finish3(has_ys, P0{}, PH{}); else finish3(has_ys, PH{}, PN{}); }
+    else finish3(has_ys, P0{}, PN{});
   };
   if constexpr (GNF == 1) finish2(T{});
   else { if (p.ystats) finish2(T{}); else finish2(F{}); }
-  {
-    if (p.ystats) {   // this lane's 4 couts of a tile are one channel quad: sum over the 16 pixel lanes, one writer per quad
+  if (p.ystats) {   // this lane's 4 couts of a tile are one channel quad: sum over the 16 pixel lanes
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { ys1[ct] += __shfl_xor(ys1[ct], o, 64); ys2[ct] += __shfl_xor(ys2[ct], o, 64); }
-        if (l15 == 0) {
-          const int quad = (nb + ct * 16) >> 2;
-          float* d = p.ystats + (((size_t)b * tiles_per_img + h0 / TR3) * (N >> 2) + quad) * 2;
-          d[0] = ys1[ct]; d[1] = ys2[ct];
-        }
-      }
-    }
+      for (int o = 1; o < 16; o <<= 1) { ys1[ct] += __shfl_xor(ys1[ct], o, 64); ys2[ct] += __shfl_xor(ys2[ct], o, 64); }
   }
-  if (p.ymax) {   // this block is partial maximum number (row tile, cout block) of image b; unused entries zeroed
-    const int part = (h0 / TR3) * gridDim.y + by, nparts = tiles_per_img * gridDim.y;
+  if (p.ymax) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) omax = max(omax, (unsigned)__shfl_xor((int)omax, o, 64));
+  }
+  const int part = (h0 / TR3) * gridDim.y + by, nparts = tiles_per_img * gridDim.y;
+  if constexpr (KS == 2) {
+    // both groups' parts of the two reductions through the tail of the block's LDS (behind the accumulator exchange)
+    unsigned* ured = reinterpret_cast<unsigned*>(smem_blk + NPT * 8192);
+    float* ysx = reinterpret_cast<float*>(smem_blk + NPT * 8192 + 64);          // [wave][grp][ct][2]
+    if (p.ymax && lane == 0) ured[kgrp * 4 + wave] = omax;
+    if (p.ystats && kgrp == 1 && l15 == 0) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) { ysx[((wave * 4 + grp) * 2 + ct) * 2] = ys1[ct]; ysx[((wave * 4 + grp) * 2 + ct) * 2 + 1] = ys2[ct]; }
+    }
     __syncthreads();
-    unsigned* ured = reinterpret_cast<unsigned*>(smem);
-    if (lane == 0) ured[wave] = omax;
-    __syncthreads();
-    if (tid == 0) p.ymax[b * 16 + part] = max(max(ured[0], ured[1]), max(ured[2], ured[3]));
-    if (part == 0 && tid >= nparts && tid < 16) p.ymax[b * 16 + tid] = 0u;
+    if (p.ystats && kgrp == 0 && l15 == 0) {          // one writer per quad: (rows of group 0) + (rows of group 1)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int quad = (nb + ct * 16) >> 2;
+        float* d = p.ystats + (((size_t)b * tiles_per_img + h0 / TR3) * (N >> 2) + quad) * 2;
+        d[0] = ys1[ct] + ysx[((wave * 4 + grp) * 2 + ct) * 2]; d[1] = ys2[ct] + ysx[((wave * 4 + grp) * 2 + ct) * 2 + 1];
+      }
+    }
+    if (p.ymax) {
+      if (tid_b == 0) {
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = max(m, ured[i]);
+        p.ymax[b * 16 + part] = m;
+      }
+      if (part == 0 && tid_b >= nparts && tid_b < 16) p.ymax[b * 16 + tid_b] = 0u;
+    }
+  } else {
+    if (p.ystats && l15 == 0) {                        // one writer per quad
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int quad = (nb + ct * 16) >> 2;
+        float* d = p.ystats + (((size_t)b * tiles_per_img + h0 / TR3) * (N >> 2) + quad) * 2;
+        d[0] = ys1[ct]; d[1] = ys2[ct];
+      }
+    }
+    if (p.ymax) {   // this block is partial maximum number (row tile, cout block) of image b; unused entries zeroed
+      __syncthreads();
+      unsigned* ured = reinterpret_cast<unsigned*>(smem);
+      if (lane == 0) ured[wave] = omax;
+      __syncthreads();
+      if (tid == 0) p.ymax[b * 16 + part] = max(max(ured[0], ured[1]), max(ured[2], ured[3]));
+      if (part == 0 && tid >= nparts && tid < 16) p.ymax[b * 16 + tid] = 0u;
+    }
   }
   if (tl) p.stamps[67 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
 }
@@ -623,23 +706,42 @@ int mulan_conv3x3_f16x3_v3_tile_rows(int B, int H, int N, bool with_ymax) {
   return tr;
 }
 
+// k-split of a launch (see the kernel): 2 for launches of at most 256 blocks whose caller says that no other stream's
+// kernels share the chip (`alone`: a k-split block takes 130 KB of a CU's LDS, the weight-gradient blocks of the train
+// step's second stream would queue behind it), with an even number of chunk pairs.  tune[27]: 1 = never, 2 = whenever the
+// shape allows (dev / tests).
+int mulan_conv3x3_f16x3_v3_ksplit(int B, int H, int C, int N, bool with_ymax, int alone) {
+  const int tr = mulan_conv3x3_f16x3_v3_tile_rows(B, H, N, with_ymax);
+  const bool shape_ok = (C / 32) % 2 == 0 && C >= 64;
+  if (!shape_ok || g_mulan_tune[27] == 1) return 1;
+  if (g_mulan_tune[27] == 2) return 2;
+  // 8-row tiles stay whole: measured at 64 images (profiles/r05_ksplit.log) the exchange of 128 accumulator registers
+  // and the two patch prologues cost more (epilogue 12 -> 19 us, prologue 5.6 -> 8.6) than the main loop gains (46 -> 45)
+  return (alone && tr < 8 && B * (H / tr) * (N / BN) <= 256) ? 2 : 1;
+}
+
 namespace {
-template <int ABL, bool PIN, int GNF, bool DMA, int TR>
+template <int ABL, bool PIN, int GNF, bool DMA, int TR, int KS = 1>
 int launch_v3(const ConvArgsH& a, hipStream_t stream) {
-  constexpr int smem = GNF ? V3Geo<TR>::SMEM_GN : V3Geo<TR>::SMEM;
+  constexpr int smem = KS * (GNF ? V3Geo<TR>::SMEM_GN : V3Geo<TR>::SMEM);
   static bool configured = false;                   // (one flag per instantiation)
   if (!configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<ABL, PIN, GNF, DMA, TR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_f16x3_v3_kernel<ABL, PIN, GNF, DMA, TR, KS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     configured = true;
   }
   const dim3 grid(a.B * (a.H / TR), a.N / BN);
-  hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<ABL, PIN, GNF, DMA, TR>), grid, dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_f16x3_v3_kernel<ABL, PIN, GNF, DMA, TR, KS>), grid, dim3(256 * KS), smem, stream, a);
   return (int)hipGetLastError();
 }
 template <bool PIN, int GNF, bool DMA>
-int launch_v3_rows(const ConvArgsH& a, int tr, hipStream_t stream) {
+int launch_v3_rows(const ConvArgsH& a, int tr, int ks, hipStream_t stream) {
+  if (ks == 2) {
+    if (tr == 4) return launch_v3<0, PIN, GNF, DMA, 4, 2>(a, stream);
+    if (tr == 2) return launch_v3<0, PIN, GNF, DMA, 2, 2>(a, stream);
+    return launch_v3<0, PIN, GNF, DMA, 8, 2>(a, stream);
+  }
   if (tr == 4) return launch_v3<0, PIN, GNF, DMA, 4>(a, stream);
   if (tr == 2) return launch_v3<0, PIN, GNF, DMA, 2>(a, stream);
   return launch_v3<0, PIN, GNF, DMA, 8>(a, stream);
@@ -651,15 +753,16 @@ int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a_in, hipStream_t stre
   const int tr = mulan_conv3x3_f16x3_v3_tile_rows(a.B, a.H, a.N, a.ymax != nullptr);
   const unsigned gx = (unsigned)(a.B * (a.H / tr)), gy = (unsigned)(a.N / BN);
   a.pair_cols = (gy > 1 && gx % 8 == 0 && g_mulan_tune[13] != 1) ? 1 : 0;    // tune[13] = 1: dev A/B, plain 2-D order
+  const int ks = mulan_conv3x3_f16x3_v3_ksplit(a.B, a.H, a.C, a.N, a.ymax != nullptr, a.alone);
   if (a.gn_mean) {   // GroupNorm-fed forward convolution: with (xs) / without the planes as a by-product
     if (a.C > GN_MAXC) return (int)hipErrorInvalidValue;
-    return a.xs ? launch_v3_rows<false, 2, false>(a, tr, stream) : launch_v3_rows<false, 1, false>(a, tr, stream);
+    return a.xs ? launch_v3_rows<false, 2, false>(a, tr, ks, stream) : launch_v3_rows<false, 1, false>(a, tr, ks, stream);
   }
   if (a.xplanes) {   // plane-fed forward convolution
     if (g_mulan_tune[18] == 1)     // dev A/B: the register-staged patch fill of rounds 2-3
-      return launch_v3_rows<true, 0, false>(a, tr, stream);
+      return launch_v3_rows<true, 0, false>(a, tr, 1, stream);
     // LDS-DMA patch fill (round 4: 76.72 / 76.79 / 76.71 vs 77.02 / 76.75 / 76.93 ms per step)
-    return launch_v3_rows<true, 0, true>(a, tr, stream);
+    return launch_v3_rows<true, 0, true>(a, tr, ks, stream);
   }
   switch (tr == 8 ? g_mulan_tune[4] : 0) {   // dev-only ablations (tools/conv_ab.py --ablate), 8-row tiles
     case 1: return launch_v3<1, false, 0, false, 8>(a, stream);
@@ -671,5 +774,5 @@ int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a_in, hipStream_t stre
     case 32: return launch_v3<32, false, 0, false, 8>(a, stream);
     default: break;
   }
-  return launch_v3_rows<false, 0, false>(a, tr, stream);
+  return launch_v3_rows<false, 0, false>(a, tr, ks, stream);
 }

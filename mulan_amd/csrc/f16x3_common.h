@@ -67,6 +67,8 @@ struct ConvArgsH {
   float gn_eps;
   int pair_cols;                // (set by the launcher) the cout blocks of a pixel tile run on one XCD, see the kernel
   int xstats_tiles;             // row tiles per image in xstats / xstats2 (the PRODUCER's tile height: 4, 8 or 16; 0 = 4)
+  int alone;                    // the caller vouches that no other stream's kernels share the chip with this launch
+                                // (forward passes, evaluators): small launches may then take a whole CU's LDS per block
 };
 
 // sigmoid on the hardware exp2 and reciprocal: the expression of groupnorm.hip's sigmoid_fast, bit for bit
@@ -86,3 +88,5 @@ int mulan_launch_conv3x3_f16x3_v3(const f16x3::ConvArgsH& a, hipStream_t stream)
 bool mulan_conv3x3_f16x3_v3_eligible(int H, int C, int N);
 // image rows per block the launcher will use for this launch (8, 4 or 2): ystats has H / rows row tiles per image
 int mulan_conv3x3_f16x3_v3_tile_rows(int B, int H, int N, bool with_ymax);
+// 1 or 2: k-split groups per block the launcher will use (conv3x3_f16x3_v3.hip)
+int mulan_conv3x3_f16x3_v3_ksplit(int B, int H, int C, int N, bool with_ymax, int alone);

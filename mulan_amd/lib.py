@@ -53,7 +53,7 @@ SIGNATURES = {
     "mulan_groupnorm_fwd_dyn": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P, P],
     "mulan_groupnorm_fwd_planes": [P, P, I, I, P, P, P, P, P, I, I, I, F, I, F, U, U, P, P, P],
     "mulan_conv3x3_fwd_f16x3_planes_in": [P, P, P, P, P, P, I, P, P, P, I, I, I, I, I, P],
-    "mulan_conv3x3_fwd_f16x3_planes_in_stats": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],
+    "mulan_conv3x3_fwd_f16x3_planes_in_stats": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_groupnorm_stats": [P, P, I, I, P, P, P, P, P, I, I, I, F, P],
     "mulan_conv3x3_fwd_f16x3_gn_in": [P, P, I, I, P, P, P, P, I, I, F, P, P, P, I, P, P, P, P, I, P, P, P, P, P, I, I, I, I, P],
     "mulan_conv3x3_f16x3_tile_rows": [I, I, I, I],

@@ -66,7 +66,7 @@ SIDE_DEPTH = int(_os.environ.get("MULAN_SIDE_DEPTH", "6"))
 # backward + input-gradient convolution) and both streams keep running side by side: -2.9 % per step (scan 96 ... 240,
 # profiles/DESIGN_r04.md 3.2).  MULAN_SIDE_WGRAD_SHARE=0 keeps 240.
 SIDE_WGRAD_SHARE = _os.environ.get("MULAN_SIDE_WGRAD_SHARE", "1") == "1"
-_SIDE = {"stream": None, "pending": None, "active": False}
+_SIDE = {"stream": None, "pending": None, "active": False, "scope": False}
 
 
 class weight_gradient_stream:
@@ -75,10 +75,12 @@ class weight_gradient_stream:
 
     def __enter__(self):
         _SIDE["active"] = SIDE_STREAM
+        _SIDE["scope"] = True
         return self
 
     def __exit__(self, *exc):
         _SIDE["active"] = False
+        _SIDE["scope"] = False
         side_join()
         return False
 
@@ -459,9 +461,13 @@ def conv3x3_dgrad_planes_raw(dys, dymax, w, wmax=None, want_max=False):
     wp, wmax = _pack_weights(w, C, N, 1, wmax)
     dxmax = (torch.empty((B, MAX_PARTS), device=dys.device, dtype=torch.int32)
              if want_max and (H // 8) * (C // 128) <= MAX_PARTS else None)
+    # alone: no weight-gradient stream beside this launch (the ODE evaluator's vector-Jacobian product, not the backward
+    # pass of a train step -- with or without MULAN_SIDE_STREAM, so that both modes sum in the same order): small launches
+    # may then run as k-split blocks (conv3x3_f16x3_v3.hip)
+    alone = 0 if _SIDE["scope"] else 1
     _timed("conv3x3_f16x3_kernel<planes_in,dgrad>", 2.0 * B * HW * 9 * C * N,
-           lambda: call("mulan_conv3x3_fwd_f16x3_planes_in", ptr(dys), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
-                        ptr(dx), ptr(dxmax), B, H, W, N, C, stream()))
+           lambda: call("mulan_conv3x3_fwd_f16x3_planes_in_stats", ptr(dys), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0,
+                        None, ptr(dx), ptr(dxmax), None, alone, B, H, W, N, C, stream()))
     if dxmax is not None:
         dx._absmax = (dxmax, dx._version)
     return dx
@@ -1404,7 +1410,7 @@ class GnConv3x3Fn(torch.autograd.Function):
             ystats = torch.empty((B, H // rows, N // 4, 2), device=dev, dtype=torch.float32)
         _timed("conv3x3_f16x3_kernel<planes_in>", 2.0 * B * HW * 9 * Ct * N,
                lambda: call("mulan_conv3x3_fwd_f16x3_planes_in_stats", ptr(ys), ptr(bound), ptr(wp), ptr(wmax), ptr(bias_c),
-                            ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), ptr(ystats), B, H, W, Ct, N, stream()))
+                            ptr(cb_c), mode, ptr(res_c), ptr(y), ptr(ymax), ptr(ystats), 1, B, H, W, Ct, N, stream()))
         if ystats is not None:
             y._gnstats = (ystats, y._version)
         return GnConv3x3Fn._finish_forward(ctx, x1, x2, gamma, beta, w, bias, cbias, res, mean, rstd, ys, bound, wmax, y, ymax,

@@ -20,6 +20,7 @@ def ops(monkeypatch):
     monkeypatch.setattr(_ops, "CONV_MODE", "f16x3")
     yield _ops
     _ops.call("mulan_set_tuning", 23, 0)
+    _ops.call("mulan_set_tuning", 27, 0)
 
 
 def dev(a):
@@ -37,10 +38,12 @@ def test_tile_rows_policy(ops):
 
 
 @pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (1, 128, 256), (3, 32, 128)])
-@pytest.mark.parametrize("rows", [4, 2])
-def test_short_tiles_exact_on_integers(ops, B, C, N, rows):
-    """fp32-input instantiation (+ bias, per-sample FiLM bias, residual) and its input gradient against the numpy oracle"""
+@pytest.mark.parametrize("rows,ks", [(4, 1), (2, 1), (8, 2), (4, 2), (2, 2)])
+def test_short_tiles_exact_on_integers(ops, B, C, N, rows, ks):
+    """fp32-input instantiation (+ bias, per-sample FiLM bias, residual) and its input gradient against the numpy oracle;
+    ks = 2: as k-split blocks (two groups of four waves, each over half of the channels: tune[27] = 2)"""
     ops.call("mulan_set_tuning", 23, rows)
+    ops.call("mulan_set_tuning", 27, 2 if ks == 2 else 1)
     rng = np.random.default_rng(B + C + N + rows)
     x = rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64)
     w = rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64)
@@ -69,6 +72,7 @@ def test_every_tile_height_gives_the_same_numbers(ops, B, C, N):
 
     def run(rows):
         ops.call("mulan_set_tuning", 23, rows)
+        ops.call("mulan_set_tuning", 27, 1)              # (4-wave blocks at every height; the k-split blocks: below)
         y, xs = ops.conv3x3_raw(x, w, bias, cb, res, planes=True)
         ymax = y._absmax[0].view(B, 16).amax(1).clone()
         xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
@@ -116,3 +120,52 @@ def test_statistics_hand_over_between_tile_heights(ops, monkeypatch):
         assert n_ref == 4 and n_got == 1
         for i, (a, r) in enumerate(zip(got, ref)):
             assert float((a - r).abs().max()) <= 3e-6 * float(r.abs().max()), (tiles, i)
+
+
+@pytest.mark.parametrize("B,C,N", [(3, 128, 128), (2, 256, 128), (2, 128, 256)])
+@pytest.mark.parametrize("rows", [8, 4, 2])
+def test_k_split_blocks_agree_with_four_wave_blocks(ops, monkeypatch, B, C, N, rows):
+    """k-split blocks (round 5: launches of at most 256 blocks without a second stream on the chip run as two groups of
+    four waves over half of the channels each, sums exchanged through LDS) against the 4-wave blocks on random data: the
+    fp32-input launch (output to fp32 rounding of the two half sums, planes bit-identical, maxima = max |y| of its own
+    output), a training-mode GroupNorm -> convolution node with the statistics by-product (plane-fed forward and input
+    gradient), and a forward-only chain with the normalisation in the patch fill and the statistics handed over"""
+    torch.manual_seed(B * C + N + rows)
+    x = torch.randn(B, 1024, C, device="cuda") * 1.7
+    w = torch.randn(3, 3, C, N, device="cuda") * 0.05
+    bias, cb, res = torch.randn(N, device="cuda"), torch.randn(B, N, device="cuda"), torch.randn(B, 1024, N, device="cuda")
+    gamma, beta = torch.randn(C, device="cuda") * 0.4 + 1, torch.randn(C, device="cuda") * 0.2
+    g2, b2, w2 = torch.randn(N, device="cuda") * 0.4 + 1, torch.randn(N, device="cuda") * 0.2, torch.randn(3, 3, N, N, device="cuda") * 0.04
+    monkeypatch.setattr(ops, "GN_FWD_STREAM_B", (1, 1 << 30))
+    names = []
+    real = ops.call
+    monkeypatch.setattr(ops, "call", lambda n, *a: (names.append(n), real(n, *a))[1])
+    L = ops.lib.load()
+
+    def run(ks):
+        real("mulan_set_tuning", 23, rows)
+        real("mulan_set_tuning", 27, 2 if ks == 2 else 1)
+        names.clear()
+        y, xs = ops.conv3x3_raw(x, w, bias, cb, res, planes=True)
+        ymax = y._absmax[0].view(B, 16).amax(1).clone()
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        z = ops.gn_conv3x3(xg, None, gamma, beta, wg, bias, cbias=cb, keep=0.9, seed=5, offset=64)
+        st = z._gnstats[0].clone()
+        (z * res).sum().backward()
+        with torch.no_grad():                                    # GroupNorm-fed fill, statistics from the launch in front
+            f1 = ops.gn_conv3x3(x, None, gamma, beta, w, bias, cbias=cb)
+            f2 = ops.gn_conv3x3(f1, None, g2, b2, w2, None, res=f1) if N == 128 else f1
+        return [y.clone(), z.detach().clone(), xg.grad.clone(), wg.grad.clone(), st, f1.clone(), f2.clone()], xs.clone(), ymax, list(names)
+
+    ref, ref_xs, ref_max, _ = run(1)
+    got, got_xs, got_max, got_names = run(2)
+    used_rows = L.mulan_conv3x3_f16x3_tile_rows(B, 32, N, 1)
+    assert used_rows == (rows if (32 // rows) * (N // 128) <= 16 else 4)
+    assert "mulan_conv3x3_fwd_f16x3_planes_in_stats" in got_names
+    assert ("mulan_conv3x3_fwd_f16x3_gn_in" in got_names) == (N == 128)      # (N = 256 keeps the plane hand-over: ops.GN_FILL_MAX_N)
+    assert torch.equal(got_xs, ref_xs)
+    assert torch.equal(got_max, got[0].abs().amax((1, 2)).view(torch.int32))
+    for i, (a, r) in enumerate(zip(got, ref)):
+        tol = (2e-6 if i in (0, 1, 4) else 2e-5) * float(r.abs().max())
+        assert float((a - r).abs().max()) <= tol, (i, float((a - r).abs().max()), float(r.abs().max()))
+    assert not torch.equal(got[0], ref[0])                        # (it did run the other summation order)

@@ -1175,7 +1175,7 @@ def test_grad_planes_hand_over_matches_the_fp32_path(ops, monkeypatch, B, C, E, 
     got, got_names = run(True)
     assert "mulan_groupnorm_bwd_fused_planes" in got_names and "mulan_groupnorm_bwd_fused_planes" not in ref_names
     assert got_names.count("mulan_conv3x3_fwd_f16x3") == ref_names.count("mulan_conv3x3_fwd_f16x3") - 1
-    assert got_names.count("mulan_conv3x3_fwd_f16x3_planes_in") == ref_names.count("mulan_conv3x3_fwd_f16x3_planes_in") + 1
+    assert got_names.count("mulan_conv3x3_fwd_f16x3_planes_in_stats") == ref_names.count("mulan_conv3x3_fwd_f16x3_planes_in_stats") + 1
     assert torch.equal(got[0], ref[0])
     labels = ["y"] + [n for n, t in zip(("x", "g1", "b1", "g2", "b2", "w1", "c1b", "w2", "c2b", "cb", "wn"),
                                          (x, g1, b1, g2, b2, w1, c1b, w2, c2b, cb, wn)) if t is not None]
