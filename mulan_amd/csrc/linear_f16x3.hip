@@ -64,15 +64,18 @@ constexpr int kBufWord3 = 0x00020000;          // raw buffer resource; out-of-ra
 // with at least 256 output columns -- the rows are read, split and staged once for 256 columns instead of twice (E = 256:
 // the kernel is bound by that work, not by HBM; E = 128: the two-output input gradient of nin_shortcut reads dy once).
 // The weight fragments of k step t + 1 are fetched while step t is multiplied (a ring of two: 64 registers at NT = 4).
-template <int NT>
+// MT (round 5): row tiles per wave.  MT = 2: 128 rows per block; MT = 1: 64 rows per block, for launches that would
+// otherwise leave CUs without a block (M = 16 K rows at a 16-image sampling batch: 128 blocks of 128 rows).  Every output
+// element is the same sum in the same order at either value.
+template <int NT, int MT = 2>
 __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
-  constexpr int MT = 2;
+  constexpr int TMB = 64 * MT;                   // rows per block
   constexpr int TNB = NT * 64;                   // columns per block
   __shared__ __attribute__((aligned(16))) unsigned char smem[LIN_SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int r0 = blockIdx.x * TM, n0 = blockIdx.y * TNB;
+  const int r0 = blockIdx.x * TMB, n0 = blockIdx.y * TNB;
   const int K = p.K1 + p.K2, N = p.N1 + p.N2;
   const int nst = K / SK;
   const int b = r0 / p.rows_per_img;
@@ -90,16 +93,16 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // activation staging: 128 rows x 8 float4 per stage, 4 slots per thread (slot = tid + 256 i: quad = slot & 7)
+  // activation staging: TMB rows x 8 float4 per stage, 2 MT slots per thread (slot = tid + 256 i: quad = slot & 7)
   const int aq = tid & 7, arow = tid >> 3;                     // + 32 i rows
-  f32x4 areg[4];
+  f32x4 areg[2 * MT];
   auto gload_a = [&](int s) {
     const int c = s * SK;
     const float* src; int ld, cl;
     if (c < p.K1) { src = p.x1; ld = p.K1; cl = c; } else { src = p.x2; ld = p.K2; cl = c - p.K1; }
     const float* base = src + (size_t)(r0 + arow) * ld + cl + aq * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) areg[i] = ld_stream4(base + (size_t)(32 * i) * ld);
+    for (int i = 0; i < 2 * MT; ++i) areg[i] = ld_stream4(base + (size_t)(32 * i) * ld);
   };
   // plane output window: this block's image (only the first column block writes; nothing when not requested)
   const __amdgpu_buffer_rsrc_t xs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
   const int pix0 = r0 - b * p.rows_per_img + arow;
   auto store_a = [&](unsigned char* buf, int s) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2 * MT; ++i) {
       f16x4 hi, lo;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
-          af[mt][pl] = *reinterpret_cast<const f16x8*>(buf + (wm * 64 + mt * 32 + li) * ROWB + pl * 64 + j * 32 + lh * 16);
+          af[mt][pl] = *reinterpret_cast<const f16x8*>(buf + (wm * (32 * MT) + mt * 32 + li) * ROWB + pl * 64 + j * 32 + lh * 16);
 #pragma unroll
       for (int term = 0; term < 3; ++term) {
         constexpr int PA[3] = {1, 0, 0};
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void linear_f16x3_kernel(LinArgs p) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[mfma32_row(r, lane) * TS + nt * 32 + li] = (acc[mt][nh * 2 + nt][r] * inv_x) * inv_w;
-    const size_t rowbase = (size_t)(r0 + wm * 64 + mt * 32) * ldo + col0 + nb;
+    const size_t rowbase = (size_t)(r0 + wm * (32 * MT) + mt * 32) * ldo + col0 + nb;
     f32x4 add[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) add[it] = bias4;
@@ -272,10 +275,17 @@ static int linear_f16x3_launch(const float* x1, const unsigned* x1max, const flo
   if (xs && (size_t)M * (K1 + K2) * 4 >= 0x80000000ull) return (int)hipErrorInvalidValue;
   LinArgs a{x1, K2 > 0 ? x2 : nullptr, x1max, x2max, static_cast<const unsigned char*>(wp), wmax, bias, res, y1, y2,
             M, K1, K2, N1, N2, rows_per_img, static_cast<unsigned char*>(xs), wp_img_stride, wmax_per_img};
-  if ((N1 + N2) % 256 == 0 && g_mulan_tune[11] != 1)       // tune[11] = 1: dev A/B, 128-column blocks everywhere
-    hipLaunchKernelGGL(linear_f16x3_kernel<4>, dim3(M / TM, (N1 + N2) / 256), dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL(linear_f16x3_kernel<2>, dim3(M / TM, (N1 + N2) / TN), dim3(256), 0, stream, a);
+  const bool wide = (N1 + N2) % 256 == 0 && g_mulan_tune[11] != 1;   // tune[11] = 1: dev A/B, 128-column blocks everywhere
+  const int colblocks = wide ? (N1 + N2) / 256 : (N1 + N2) / TN;
+  // fewer 128-row blocks than CUs: 64-row blocks (tune[28] = 1: dev A/B, 128 rows everywhere)
+  const bool shortb = (M / TM) * colblocks < 256 && g_mulan_tune[28] != 1;
+  if (wide) {
+    if (shortb) hipLaunchKernelGGL((linear_f16x3_kernel<4, 1>), dim3(M / 64, colblocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((linear_f16x3_kernel<4, 2>), dim3(M / TM, colblocks), dim3(256), 0, stream, a);
+  } else {
+    if (shortb) hipLaunchKernelGGL((linear_f16x3_kernel<2, 1>), dim3(M / 64, colblocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((linear_f16x3_kernel<2, 2>), dim3(M / TM, colblocks), dim3(256), 0, stream, a);
+  }
   MULAN_CHECK_LAUNCH();
 }
 

@@ -244,6 +244,30 @@ def test_f16x3_linear_exact_on_integers_and_accuracy(ops, B, K1, K2, N):
                 assert float((np.abs(got_dx[b] - dxr[b]) / magd).max()) < 2e-6, b
 
 
+@pytest.mark.parametrize("B,K1,K2,N", [(3, 128, 128, 128), (2, 256, 0, 256), (5, 128, 0, 128)])
+def test_f16x3_linear_row_tile_variants_are_bit_identical(ops, B, K1, K2, N):
+    """64-row blocks (round 5: launches with fewer 128-row blocks than CUs -- a 16-image sampling batch) against 128-row
+    blocks (dev switch tune[28] = 1): the same sum in the same order for every output element, the same plane by-product"""
+    torch.manual_seed(B + K1 + N)
+    x1 = torch.randn(B, 1024, K1, device="cuda") * 2
+    x2 = torch.randn(B, 1024, K2, device="cuda") if K2 else None
+    w = torch.randn(K1 + K2, N, device="cuda") / 16
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(B, 1024, N, device="cuda")
+    wp, wmax = ops.linear_pack(w, False)
+    outs = []
+    try:
+        for v in (1, 0):
+            ops.call("mulan_set_tuning", 28, v)
+            r = ops.linear_f16x3_raw(x1, x2, wp, wmax, N, 0, bias=bias, res=res, planes=True)
+            outs.append([t.clone() for t in r if torch.is_tensor(t)])
+    finally:
+        ops.call("mulan_set_tuning", 28, 0)
+    assert len(outs[0]) == len(outs[1]) >= 2
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+
+
 def test_f16x3_linear_autograd_matches_fp32_gemm(ops, monkeypatch):
     torch.manual_seed(1)
     B, K, N = 2, 128, 128
