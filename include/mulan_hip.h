@@ -119,6 +119,13 @@ int mulan_conv3x3_pack_f16x3(const float* w, void* wp, const unsigned* wmax, int
 int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
                             const float* bias, const float* cbias, int cbias_mode, const float* res, float* y, void* xs,
                             unsigned* ymax, int B, int H, int W, int C, int N, mulan_stream_t stream);
+/* ... with the caller's word on what else runs (round 5): alone != 0 = no other stream's kernels share the chip with this
+ * launch (a forward pass, an evaluator, the vector-Jacobian product of the ODE likelihood, notebook_utils.py:193-373);
+ * launches of at most 256 short-tile blocks then run as k-split blocks of eight waves.  mulan_conv3x3_fwd_f16x3 = alone 0. */
+int mulan_conv3x3_fwd_f16x3_alone(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                  const float* bias, const float* cbias, int cbias_mode, const float* res, float* y,
+                                  void* xs, unsigned* ymax, int alone, int B, int H, int W, int C, int N,
+                                  mulan_stream_t stream);
 /* The forward convolution fed with the split planes of its input (written by mulan_groupnorm_fwd_planes; xmax = the
  * [B][16] array that call filled).  H % 8 == 0, C % 32 == 0, N % 128 == 0.  ldm/model_vdm.py:633-656. */
 int mulan_conv3x3_fwd_f16x3_planes_in(const void* xplanes, const unsigned* xmax, const void* wp, const unsigned* wmax,

@@ -1291,10 +1291,13 @@ MULAN_API size_t mulan_conv3x3_planes_bytes(int B, int H, int W, int C) { return
 
 // xs (optional, mulan_conv3x3_planes_bytes): receives the split planes of x, the input format of
 // mulan_conv3x3_wgrad_f16x3_planes.
-MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
-                                      const float* bias, const float* cbias, int cbias_mode, const float* res,
-                                      float* y, void* xs, unsigned* ymax, int B, int H, int W, int C, int N,
-                                      hipStream_t stream) {
+// _alone: the same launch with the caller's word that no other stream's kernels share the chip (alone != 0: a forward
+// pass, an evaluator, the ODE likelihood's vector-Jacobian product): small launches may then run as k-split blocks
+// (conv3x3_f16x3_v3.hip, KS).  mulan_conv3x3_fwd_f16x3 = alone 0.
+static int conv3x3_fwd_f16x3_impl(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                  const float* bias, const float* cbias, int cbias_mode, const float* res, float* y,
+                                  void* xs, unsigned* ymax, int alone, int B, int H, int W, int C, int N,
+                                  hipStream_t stream) {
   if (W != kW || H % TROWS != 0 || B <= 0 || C % CK != 0 || C <= 0 || N % BN != 0 || N <= 0 || !xmax || !wmax)
     return (int)hipErrorInvalidValue;
   static bool configured = false;
@@ -1306,6 +1309,7 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
   }
   ConvArgsH a{x, xmax, static_cast<const unsigned char*>(wp), wmax, bias, cbias, res, y, B, H, C, N,
               cbias ? cbias_mode : 0, g_mulan_debug_buffer, static_cast<unsigned char*>(xs), ymax};
+  a.alone = alone;
   if (xs && (H % TR2 != 0 || (size_t)B * H * W * C * 4 >= 0x80000000ull)) return (int)hipErrorInvalidValue;
   if (ymax && (H % TR2 != 0 || (H / TR2) * (N / BN) > kMaxParts)) return (int)hipErrorInvalidValue;
   // default: the 16x16x32 / two-blocks-per-CU kernel (conv3x3_f16x3_v3.hip); tune[3] = 2 / 1: dev A/B switches to the
@@ -1326,6 +1330,20 @@ MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, cons
   dim3 grid(B * (H / TROWS), N / BN);
   hipLaunchKernelGGL(conv3x3_f16x3_kernel, grid, dim3(256), SMEM_B, stream, a);
   MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_conv3x3_fwd_f16x3(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                      const float* bias, const float* cbias, int cbias_mode, const float* res,
+                                      float* y, void* xs, unsigned* ymax, int B, int H, int W, int C, int N,
+                                      hipStream_t stream) {
+  return conv3x3_fwd_f16x3_impl(x, xmax, wp, wmax, bias, cbias, cbias_mode, res, y, xs, ymax, 0, B, H, W, C, N, stream);
+}
+MULAN_API int mulan_conv3x3_fwd_f16x3_alone(const float* x, const unsigned* xmax, const void* wp, const unsigned* wmax,
+                                            const float* bias, const float* cbias, int cbias_mode, const float* res,
+                                            float* y, void* xs, unsigned* ymax, int alone, int B, int H, int W, int C,
+                                            int N, hipStream_t stream) {
+  return conv3x3_fwd_f16x3_impl(x, xmax, wp, wmax, bias, cbias, cbias_mode, res, y, xs, ymax, alone, B, H, W, C, N,
+                                stream);
 }
 
 // The forward convolution fed with the split planes of its input (mulan_groupnorm_fwd_planes writes them; xmax is the

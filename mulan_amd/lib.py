@@ -32,6 +32,7 @@ SIGNATURES = {
     "mulan_conv3x3_pack_f16x3_bytes": [I, I],
     "mulan_conv3x3_pack_f16x3": [P, P, P, I, I, I, P],
     "mulan_conv3x3_fwd_f16x3": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],
+    "mulan_conv3x3_fwd_f16x3_alone": [P, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_conv3x3_planes_bytes": [I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3_planes_workspace": [I, I, I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],

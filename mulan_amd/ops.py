@@ -85,6 +85,14 @@ class weight_gradient_stream:
         return False
 
 
+def _alone():
+    """the `alone` argument of the convolution entry points: 1 unless the launch is part of the backward pass of a train
+    step (a weight_gradient_stream() scope, with or without MULAN_SIDE_STREAM, so that both modes sum in the same order):
+    forward passes, evaluators and the ODE likelihood's vector-Jacobian products have the chip to themselves, and small
+    launches may then run as k-split blocks (conv3x3_f16x3_v3.hip)"""
+    return 0 if _SIDE["scope"] else 1
+
+
 def _share_chip():
     """the share_chip argument of the plane-fed weight-gradient launches: 1 inside a weight_gradient_stream() scope"""
     return int(bool(_SIDE["active"] and SIDE_WGRAD_SHARE))
@@ -406,8 +414,8 @@ def conv3x3_raw(x, w, bias=None, cbias=None, res=None, xmax=None, planes=False, 
         # by-product: the maxima of y, left on the tensor for whichever f16x3 kernel reads it next
         ymax = torch.empty((B, MAX_PARTS), device=x.device, dtype=torch.int32) if (H // 8) * (N // 128) <= MAX_PARTS else None
         _timed("conv3x3_f16x3_kernel", flops,
-               lambda: call("mulan_conv3x3_fwd_f16x3", ptr(x), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cbias), mode,
-                            ptr(res), ptr(y), ptr(xs), ptr(ymax), B, H, W, C, N, stream()))
+               lambda: call("mulan_conv3x3_fwd_f16x3_alone", ptr(x), ptr(xmax), ptr(wp), ptr(wmax), ptr(bias), ptr(cbias), mode,
+                            ptr(res), ptr(y), ptr(xs), ptr(ymax), _alone(), B, H, W, C, N, stream()))
         if ymax is not None:
             y._absmax = (ymax, y._version)
         if planes:
@@ -436,8 +444,8 @@ def conv3x3_dgrad_raw(dy, w, dymax=None, planes=False, wmax=None, want_max=False
             dxmax = (torch.empty((B, MAX_PARTS), device=dy.device, dtype=torch.int32)
                      if want_max and (H // 8) * (C // 128) <= MAX_PARTS else None)
             _timed("conv3x3_f16x3_kernel", flops,
-                   lambda: call("mulan_conv3x3_fwd_f16x3", ptr(dy), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
-                                ptr(dx), ptr(dys), ptr(dxmax), B, H, W, N, C, stream()))
+                   lambda: call("mulan_conv3x3_fwd_f16x3_alone", ptr(dy), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0, None,
+                                ptr(dx), ptr(dys), ptr(dxmax), _alone(), B, H, W, N, C, stream()))
             if dxmax is not None:
                 dx._absmax = (dxmax, dx._version)
             if planes:
@@ -464,7 +472,7 @@ def conv3x3_dgrad_planes_raw(dys, dymax, w, wmax=None, want_max=False):
     # alone: no weight-gradient stream beside this launch (the ODE evaluator's vector-Jacobian product, not the backward
     # pass of a train step -- with or without MULAN_SIDE_STREAM, so that both modes sum in the same order): small launches
     # may then run as k-split blocks (conv3x3_f16x3_v3.hip)
-    alone = 0 if _SIDE["scope"] else 1
+    alone = _alone()
     _timed("conv3x3_f16x3_kernel<planes_in,dgrad>", 2.0 * B * HW * 9 * C * N,
            lambda: call("mulan_conv3x3_fwd_f16x3_planes_in_stats", ptr(dys), ptr(dymax), ptr(wp), ptr(wmax), None, None, 0,
                         None, ptr(dx), ptr(dxmax), None, alone, B, H, W, N, C, stream()))

@@ -894,7 +894,7 @@ def test_gn_conv_plane_hand_over_matches_the_two_op_path(ops, monkeypatch, B, C1
     got, got_names = run(True)
     assert "mulan_groupnorm_fwd_planes" in got_names and "mulan_conv3x3_fwd_f16x3_planes_in_stats" in got_names
     assert "mulan_groupnorm_fwd_dyn" not in got_names and "mulan_groupnorm_fwd_planes" not in ref_names
-    assert got_names.count("mulan_conv3x3_fwd_f16x3") == 1          # only the input-gradient launch is left on it
+    assert got_names.count("mulan_conv3x3_fwd_f16x3_alone") == 1    # only the input-gradient launch is left on it
     labels = ["y"] + [n for n, t in zip(("x1", "x2", "gamma", "beta", "w", "bias", "cb", "res"),
                                          (x1, x2, gamma, beta, w, bias, cb, res)) if t is not None]
     for a, r, nm in zip(got, ref, labels):
@@ -1198,7 +1198,7 @@ def test_grad_planes_hand_over_matches_the_fp32_path(ops, monkeypatch, B, C, E, 
     ref, ref_names = run(False)
     got, got_names = run(True)
     assert "mulan_groupnorm_bwd_fused_planes" in got_names and "mulan_groupnorm_bwd_fused_planes" not in ref_names
-    assert got_names.count("mulan_conv3x3_fwd_f16x3") == ref_names.count("mulan_conv3x3_fwd_f16x3") - 1
+    assert got_names.count("mulan_conv3x3_fwd_f16x3_alone") == ref_names.count("mulan_conv3x3_fwd_f16x3_alone") - 1
     assert got_names.count("mulan_conv3x3_fwd_f16x3_planes_in_stats") == ref_names.count("mulan_conv3x3_fwd_f16x3_planes_in_stats") + 1
     assert torch.equal(got[0], ref[0])
     labels = ["y"] + [n for n, t in zip(("x", "g1", "b1", "g2", "b2", "w1", "c1b", "w2", "c2b", "cb", "wn"),
