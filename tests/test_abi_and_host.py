@@ -510,8 +510,24 @@ def test_plane_hand_over_gating_and_backward_scope(monkeypatch):
     with ops.weight_gradient_stream():
         assert ops._SIDE["active"] and ops._share_chip() == 0
     monkeypatch.setattr(ops, "SIDE_STREAM", False)
+    assert ops._alone() == 1                 # forward passes / evaluators: small convolution launches may take whole CUs
     with ops.weight_gradient_stream():
         assert not ops._SIDE["active"] and ops._share_chip() == 0
+        assert ops._alone() == 0             # the backward pass of a train step, with or without the second stream
+    assert ops._alone() == 1
+    monkeypatch.setattr(ops, "SIDE_STREAM", True)
+    with ops.weight_gradient_stream():
+        assert ops._alone() == 0
+    with pytest.raises(RuntimeError):
+        with ops.weight_gradient_stream():
+            raise RuntimeError("backward failed")
+    assert ops._alone() == 1
+    # round 5: the streaming GroupNorm forward runs in the window of images per launch where the step measured faster
+    monkeypatch.setattr(ops, "GN_FWD_STREAM", True)
+    monkeypatch.setattr(ops, "GN_FWD_STREAM_B", (32, 96))
+    assert [ops._gn_fwd_stream_on(b) for b in (16, 31, 32, 64, 96, 97, 128)] == [False, False, True, True, True, False, False]
+    monkeypatch.setattr(ops, "GN_FWD_STREAM", False)
+    assert not ops._gn_fwd_stream_on(64)
     assert not any(c[0] == "mulan_set_tuning" for c in calls)       # the product path never touches the dev switches
 
 
