@@ -35,6 +35,7 @@ using namespace f16x3;
 // the chip at the 16 images per GPU of a sampling batch.  Shorter tiles (round 5) give those launches their two blocks
 // per CU back; the price is the halo (TR + 2 patch rows per TR rows of output) and half / a quarter of the MFMAs per
 // weight-fragment load.  Everything below is derived from TR.
+constexpr int WDS = 3;                              // weight-fragment ring of the short-tile instantiations (3 or 9: see the kernel)
 constexpr int GN_ENT = 48;                          // GroupNorm-fed fill: table entry (scale x 4, beta x 4, mean) per channel quad
 constexpr int GN_MAXC = 512;
 template <int TR> struct V3Geo {
@@ -358,7 +359,12 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
   const unsigned wlane = (unsigned)((n0 + wave * 32 + l15) * 64 + khalf * 16);
   const int unit_stride = N * 64;                    // bytes between (tap, chunk) tiles of the packed weights
 
-  f16x8 wf[2][2][2];                                 // [buffer][cout tile][plane]
+  // weight-fragment ring: the fragments of step s + WD - 1 are fetched during step s.  8-row tiles: one step ahead (a step
+  // is 1.5 k cycles of MFMA issue).  Short tiles: a step is 380 / 770 cycles, less than an L2 round trip: two steps ahead
+  // (a ring of 3 divides the nine steps of a chunk pair: no copy at the pair boundary).  Sampler at 16 images 5.15 ->
+  // 4.94 ms per reverse step.  A ring of 9 (8 steps ahead, 144 registers) spills to scratch: 7.7 ms.
+  constexpr int WD = TR == 8 ? 2 : WDS;
+  f16x8 wf[WD][2][2];                                // [ring slot][cout tile][plane]
   f16x8 xf[3][2];                                    // [ring slot][plane]: fragments are read two pixel tiles ahead
   auto load_w = [&](f16x8 (&w)[2][2], int uA, int uB) {        // uA / uB: tile index tap * nchunks + chunk of lanes < 32 / >= 32
     const int umin = min(uA, uB);                                // (offsets stay non-negative: the range check is unsigned)
@@ -411,7 +417,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
       for (int s = 0; s < PV3; ++s) store_slot(c ? bufB : bufA, slot_of(tid, s), r[s], 2 * j0 + c);
     }
   }
-  load_w(wf[0], tile_index(j0, 0), tile_index(j0, 1));
+#pragma unroll
+  for (int d = 0; d < WD - 1; ++d) load_w(wf[d], tile_index(j0, 2 * d), tile_index(j0, 2 * d + 1));    // (WD <= 9: steps of pair j0)
   // patch slots in flight: two register sets (A, B) of two slots each, fetched two steps before they are split and
   // stored (the fetch is an HBM / Infinity-Cache access; one step is ~1.5 k cycles of MFMA issue):
   //   step:   0        1        2        3        4        5        6        7        8
@@ -451,8 +458,13 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
       const int xaddr_n = xlane + (sel_s ? x_unit_off(nA, nB, 2 * sn + 1) : x_unit_off(nA, nB, 2 * sn));
       // (wave-uniform by construction; said explicitly, because with the GroupNorm-fed fill the compiler otherwise forms
       // them in vector registers and wraps every weight load in a waterfall loop -- branches inside the loop body)
-      const int uAn = __builtin_amdgcn_readfirstlane(tile_index(jn, 2 * sn));
-      const int uBn = __builtin_amdgcn_readfirstlane(tile_index(jn, 2 * sn + 1));
+      // the weight fragments fetched in this step: those of step s + WD - 1 (past this group's last step: a harmless
+      // reload of the last one)
+      const int w_ahead = s + WD - 1;
+      const bool w_over = j + w_ahead / 9 >= j1;
+      const int wj = w_over ? j1 - 1 : j + w_ahead / 9, ws = w_over ? 8 : w_ahead % 9;
+      const int uAn = __builtin_amdgcn_readfirstlane(tile_index(wj, 2 * ws));
+      const int uBn = __builtin_amdgcn_readfirstlane(tile_index(wj, 2 * ws + 1));
       // patch traffic of this step (table above): steps 0-2 fill chunk 2 j + 2 into buffer C, steps 5-7 chunk 2 j + 3
       // into buffer A (free after the step-4 barrier)
       const bool fill0 = s < NK, fill1 = s >= 5 && s < 5 + NK;
@@ -475,12 +487,12 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
         const int xo = ((pn >> 1) * kPW + (pn & 1) * 16) * 32;
         // small terms first: w_l x_h, w_h x_l, w_h x_h; the two cout tiles alternate so that an MFMA never waits for the
         // accumulator of the one right in front of it
-        if (pt == 0) mfma16<1>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
-        else mfma16<0>(acc[pt][0], wf[s & 1][0][1], xf[cur][0], false);
+        if (pt == 0) mfma16<1>(acc[pt][0], wf[s % WD][0][1], xf[cur][0], false);
+        else mfma16<0>(acc[pt][0], wf[s % WD][0][1], xf[cur][0], false);
         if (!(ABL & 1)) xf[nxt][0] = *reinterpret_cast<const f16x8*>(smem + xa + xo);
-        mfma16<0>(acc[pt][1], wf[s & 1][1][1], xf[cur][0], false);
-        mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][1], false);
-        if (!(ABL & 2) && pt >= WL0 && pt < WL0 + 4) load_w1(wf[(s + 1) & 1], uAn, uBn, pt - WL0, sel_s);
+        mfma16<0>(acc[pt][1], wf[s % WD][1][1], xf[cur][0], false);
+        mfma16<0>(acc[pt][0], wf[s % WD][0][0], xf[cur][1], false);
+        if (!(ABL & 2) && pt >= WL0 && pt < WL0 + 4) load_w1(wf[(s + WD - 1) % WD], uAn, uBn, pt - WL0, sel_s);
         if constexpr (DMA) {
           // chunk 2 j + 2 -> buffer C in step 0 (free since the barrier that ended the pair before), chunk 2 j + 3 -> buffer A
           // in step 5 (free since the step-4 barrier): five pieces per wave, one behind every second pixel tile
@@ -497,11 +509,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
         if (!(ABL & 4) && (pt == LD0 || pt == LD1) && lk >= 0)
           (ld_useB ? stgB[pt == LD1] : stgA[pt == LD1]) = load_slot(slot_of(t_l, 2 * lk + (pt == LD1)), lcc);
         }
-        mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][1], false);
+        mfma16<0>(acc[pt][1], wf[s % WD][1][0], xf[cur][1], false);
         if (!(ABL & 1)) xf[nxt][1] = *reinterpret_cast<const f16x8*>(smem + xa + xo + P3_PLANE);
-        mfma16<0>(acc[pt][0], wf[s & 1][0][0], xf[cur][0], false);
-        if (s == 8 && pt == NPT - 1) mfma16<2>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
-        else mfma16<0>(acc[pt][1], wf[s & 1][1][0], xf[cur][0], false);
+        mfma16<0>(acc[pt][0], wf[s % WD][0][0], xf[cur][0], false);
+        if (s == 8 && pt == NPT - 1) mfma16<2>(acc[pt][1], wf[s % WD][1][0], xf[cur][0], false);
+        else mfma16<0>(acc[pt][1], wf[s % WD][1][0], xf[cur][0], false);
       }
       xaddr = xaddr_n;
       if (!(ABL & 8) && (s == 4 || s == 8)) {
@@ -515,10 +527,13 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
     }
     const int t = bufA; bufA = bufC; bufC = bufB; bufB = t;      // (A, B, C) <- (C, A, B)
     // nine steps per pair: the weights fetched during step 8 sit in buffer 1, the next pair starts on buffer 0
+    // (a ring of 3 or 9 slots divides the nine steps: nothing to move)
+    if constexpr (WD == 2) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) wf[0][ct][pl] = wf[1][ct][pl];
+        for (int pl = 0; pl < 2; ++pl) wf[0][ct][pl] = wf[1][ct][pl];
+    }
   }
   if (tl) p.stamps[66 + 4 * tl_blk] = __builtin_amdgcn_s_memrealtime();
   if (tl && tl_blk < 32) p.stamps[tl_blk] = __builtin_amdgcn_s_memtime() - cyc0;   // core cycles spent in the main loop
