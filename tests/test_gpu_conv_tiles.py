@@ -37,7 +37,7 @@ def test_tile_rows_policy(ops):
     assert rows(8, 256) == 4 and rows(8, 256, 0) == 2            # 16 row tiles x 2 cout blocks do not fit the 16 maxima entries
 
 
-@pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (1, 128, 256), (3, 32, 128)])
+@pytest.mark.parametrize("B,C,N", [(2, 128, 128), (1, 256, 128), (1, 128, 256), (3, 32, 128), (2, 64, 128), (1, 192, 128)])
 @pytest.mark.parametrize("rows,ks", [(4, 1), (2, 1), (8, 2), (4, 2), (2, 2)])
 def test_short_tiles_exact_on_integers(ops, B, C, N, rows, ks):
     """fp32-input instantiation (+ bias, per-sample FiLM bias, residual) and its input gradient against the numpy oracle;
