@@ -1147,6 +1147,497 @@ int wgrad_splits_p(int B, int H, int C, int N, int share_chip) {   // 3 kh block
   return S;
 }
 
+// ---- the 3-tap plane-fed weight gradient as a block of EIGHT waves (round 6).
+// Same block tile as conv3x3_wgrad_f16x3_planes_kernel<3> (one kernel row kh of 128 ci x 128 co over a range of row
+// pairs), same LDS image, same staging scheme (pair p multiplied, p + 1 in registers, p + 2 in flight), same order of
+// summation per output element -- but a wave owns 32 ci x 64 co x 3 taps (96 accumulators, <= 256 registers), so TWO
+// waves share every SIMD: the four-wave block issues 144 MFMAs per row pair in 5.76 k cycles (4.6 k would be back to
+// back: what a wave loses after each barrier and on every fragment wait nobody fills, profiles/r03_wgrad_block_timeline.log);
+// here the partner wave's MFMAs fill those slots.  Price: 10 fragment reads per 18 MFMAs instead of 16 per 36.
+// The halo columns of the x rows (always zero) are written once in the prologue instead of being staged with every
+// pair: 2048 + 2048 sixteen-byte units per pair = 4 + 4 per thread, no partial slots.
+// Grid: one dimension, decoded so that the blocks of one pixel range (3 kh x tiles) run on one XCD (block L runs on
+// XCD L % 8) for ANY split count -- the launcher can use 255 of the 256 CUs (S = 85 at one tile) instead of 240.
+constexpr int W8_THREADS = 512;
+
+__device__ __forceinline__ void w8_decode(int L, int S, int tiles, int& s, int& kh, int& tile) {
+  const int nslot = 3 * tiles, full = S & ~7;
+  int slot;
+  if (L < full * nslot) {
+    const int g = L / (8 * nslot), rem = L - g * 8 * nslot;
+    slot = rem >> 3;
+    s = g * 8 + (rem & 7);
+  } else {
+    const int l2 = L - full * nslot, G = S - full;
+    slot = l2 / G;
+    s = full + (l2 - slot * G);
+  }
+  tile = slot / 3;
+  kh = slot - tile * 3;
+}
+
+template <int ABL = 0>
+__global__ __launch_bounds__(W8_THREADS) void conv3x3_wgrad_f16x3_w8_kernel(WgradArgsP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wci = wave >> 1, wco = wave & 1;
+  const int C = p.C, N = p.N;
+  const int ntn = N / WG3_T;
+  int bs, kh, tile;
+  w8_decode(blockIdx.x, p.S, (C / WG3_T) * ntn, bs, kh, tile);
+  const int c0 = (tile / ntn) * WG3_T, n0 = (tile % ntn) * WG3_T;
+  const int nchc = C / 16, nchn = N / 16;
+  const int pairs_per_img = p.H / WG_ROWS;
+  const int total_pairs = p.B * pairs_per_img;
+  const int pair_begin = (int)((long long)bs * total_pairs / p.S);
+  const int pair_end = (int)((long long)(bs + 1) * total_pairs / p.S);
+
+  f32x16 acc[3][2];   // [kw][co tile]
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+  // Staging.  Unit i (0..3) of a thread: 16 bytes = 8 channels of one plane of one pixel;
+  //   tid & 3 -> (plane, channel half), chunk = (tid >> 8) + 2 i, pixel = (tid >> 2) & 63 of the pair's 64.
+  // A wave's 16 pixels lie in ONE image row (wrow), so everything that changes from pair to pair is wave-uniform:
+  // the row's byte offset goes into the scalar offset of the buffer load, the lane part is a constant, and a row
+  // outside the image is one OR of bit 31 into that constant (>= num_records: the load returns zeros).  A load
+  // costs its own issue slot and two scalar adds -- the first form of this kernel spent ~15 instructions per load on
+  // per-lane address arithmetic, clustered in one MFMA gap: ~600 of 5650 cycles per row pair (profiles/r06_w8_ablation.log).
+  i32x4 xreg[4], dreg[4];
+  const __amdgpu_buffer_rsrc_t xs_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.xs), 0, 0x80000000, kBufWord3);
+  const __amdgpu_buffer_rsrc_t ds_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.dys), 0, 0x80000000, kBufWord3);
+  const int u = tid & 3, upl = u >> 1, uh = u & 1;
+  const int spix = (tid >> 2) & 63, scc = (tid >> 8) & 1;
+  const int wrow = (wave & 3) >> 1;                                    // image row of this wave's units inside the pair
+  const unsigned vlane = (unsigned)(((scc * 1024 + (spix & 31)) * 2 + upl) * 32 + uh * 16);
+  const int xdst0 = upl * X3_PLANE + (wrow * kPW + (spix & 31) + 1) * 64 + scc * 32 + uh * 16;
+  const int ddst0 = 2 * X3_PLANE + upl * D3_PLANE + spix * 64 + scc * 32 + uh * 16;
+  const unsigned xtile = (unsigned)((c0 >> 4) * 65536), dtile = (unsigned)((n0 >> 4) * 65536);
+  // fetch pointer (the pair whose loads are being issued): image fb, pair fr inside it; scalar offsets and lane word
+  int fb = 0, fr = 0;
+  unsigned sx = 0, sd = 0, vx = vlane;
+  auto set_fetch = [&](int b, int r) {
+    fb = b; fr = r;
+    const int hx = r * WG_ROWS + kh - 1 + wrow;                        // image row of this wave's x units
+    sx = (unsigned)(b * nchc) * 65536u + xtile + (unsigned)(hx * (kW * 64));
+    sd = (unsigned)(b * nchn) * 65536u + dtile + (unsigned)((r * WG_ROWS + wrow) * (kW * 64));
+    vx = vlane | ((unsigned)hx >= (unsigned)p.H ? 0x80000000u : 0u);
+  };
+  auto gload_x1 = [&](int i) {
+    if (ABL & 2) return;
+    xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xs_rsrc, vx, sx + (unsigned)i * 131072u, 0);
+  };
+  auto gload_d1 = [&](int i) {
+    if (ABL & 2) return;
+    dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(ds_rsrc, vlane, sd + (unsigned)i * 131072u, 0);
+  };
+  auto store_x = [&](unsigned char* buf, int i) {
+    if (!(ABL & 1)) *reinterpret_cast<i32x4*>(buf + xdst0 + i * X3_HALF) = xreg[i];
+  };
+  auto store_d = [&](unsigned char* buf, int i) {
+    if (!(ABL & 1)) *reinterpret_cast<i32x4*>(buf + ddst0 + i * D3_HALF) = dreg[i];
+  };
+
+  const int grp_q = (lane & 15) >> 2, grp_p = lane & 3, cb16 = ((lane >> 4) & 1) * 16;
+  const int lane_off = (8 * lh + grp_q) * 64 + (cb16 + 4 * grp_p) * 2;
+  const int xa_off = wci * X3_HALF + lane_off;
+  const int db_off = 2 * X3_PLANE + (wco * 2) * D3_HALF + lane_off;
+
+  const bool stamp = p.stamps && blockIdx.x == 0 && threadIdx.x == 0;
+  if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
+  if (tid < 256) {   // the zero halo columns (pixel columns 0 and 33) of both rows, planes, halves and buffers
+    const int rec = tid >> 2;
+    const int zb = rec >> 5, zpl = (rec >> 4) & 1, zh = (rec >> 2) & 3, zr = (rec >> 1) & 1, zc = (rec & 1) * (kPW - 1);
+    const i32x4 z = {0, 0, 0, 0};
+    *reinterpret_cast<i32x4*>(smem + zb * WG3_BUF + zpl * X3_PLANE + zh * X3_HALF + (zr * kPW + zc) * 64 + (tid & 3) * 16) = z;
+  }
+  const int last = pair_end - 1;
+  int b_acc = pair_begin < pair_end ? pair_begin / pairs_per_img : 0;
+  auto advance_fetch = [&]() {                         // to the next pair of this block's range; stays on the last one
+    if (fb * pairs_per_img + fr < last) {
+      int r = fr + 1, b = fb;
+      if (r == pairs_per_img) { r = 0; ++b; }
+      set_fetch(b, r);
+    }
+  };
+  if (pair_begin < pair_end) {
+    set_fetch(b_acc, pair_begin - b_acc * pairs_per_img);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_x1(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_d1(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_x(smem, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_d(smem, i);
+    advance_fetch();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_x1(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_d1(i);
+  }
+  __syncthreads();
+  if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
+  int b_now = b_acc, r_now = pair_begin - b_acc * pairs_per_img;     // the pair being multiplied
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    if (stamp && pr - pair_begin < 20) p.stamps[2 + pr - pair_begin] = __builtin_amdgcn_s_memtime();
+    const int cur = (pr - pair_begin) & 1;
+    const unsigned char* bc = smem + cur * WG3_BUF;
+    unsigned char* bn = smem + (cur ^ 1) * WG3_BUF;
+    advance_fetch();                                   // -> pair pr + 2 (the registers hold pr + 1)
+    if (b_now != b_acc) {                              // next image: move the accumulators to its units (exact powers of two)
+      const int d = (clamped_exp(row_max16(p.xmax, b_acc)) - clamped_exp(row_max16(p.xmax, b_now))) +
+                    (clamped_exp(row_max16(p.dymax, b_acc)) - clamped_exp(row_max16(p.dymax, b_now)));
+      if (d != 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = ldexpf(acc[t][j][r], d);
+      }
+      b_acc = b_now;
+    }
+    if (++r_now == pairs_per_img) { r_now = 0; ++b_now; }
+    const unsigned char* xa = bc + xa_off;
+    const unsigned char* db = bc + db_off;
+    f16x8 af[2][2], bfr[2][2][2];                      // [buffer][plane], [buffer][co tile][plane]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) bfr[0][j][pl] = tr_read8h(db + pl * D3_PLANE + j * D3_HALF);
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) af[0][pl] = tr_read8h(xa + pl * X3_PLANE);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {                     // q = ks * 3 + kw; k step ks = 16 pixels of row ks >> 1
+      const int ks = q / 3, kw = q - ks * 3;
+      if (q + 1 < 12) {
+        const int ks1 = (q + 1) / 3, kw1 = (q + 1) - ks1 * 3;
+        const int rr = ks1 >> 1, w0 = (ks1 & 1) * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          af[(q + 1) & 1][pl] = tr_read8h(xa + pl * X3_PLANE + (rr * kPW + w0 + kw1) * 64);
+      }
+      if (kw == 1 && ks + 1 < 4) {
+        const int rr = (ks + 1) >> 1, w0 = ((ks + 1) & 1) * 16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl)
+            bfr[(ks + 1) & 1][j][pl] = tr_read8h(db + pl * D3_PLANE + j * D3_HALF + (rr * kW + w0) * 64);
+      }
+      // staging: x unit ks in stage 3 ks, dy unit ks in stage 3 ks + 1; each register refilled at once with pair p + 2
+      // (ABL: timing probes, wrong numbers: bit 0 = no LDS stores, bit 1 = no global loads, 16 = two 16x16x32 MFMAs per 32x32x16)
+      if (kw == 0) { store_x(bn, ks); gload_x1(ks); }
+      if (kw == 1) { store_d(bn, ks); gload_d1(ks); }
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr ((ABL & 16) != 0) {         // (timing probe, wrong numbers) two 16x16x32 MFMAs on the same fragments
+            f32x16& a16 = acc[kw][j];
+            f32x4 c0 = {a16[0], a16[1], a16[2], a16[3]}, c1 = {a16[4], a16[5], a16[6], a16[7]};
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[q & 1][PA[term]], bfr[ks & 1][j][PB[term]], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[q & 1][PA[term]], bfr[ks & 1][j][PB[term]], c1, 0, 0, 0);
+            a16[0] = c0[0]; a16[1] = c0[1]; a16[2] = c0[2]; a16[3] = c0[3];
+            a16[4] = c1[0]; a16[5] = c1[1]; a16[6] = c1[2]; a16[7] = c1[3];
+          } else {
+            acc[kw][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q & 1][PA[term]], bfr[ks & 1][j][PB[term]], acc[kw][j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < ((ABL & 16) ? 12 : 6); ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (ABL & 16) ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (ABL & 16) ? 1 : 2, 0);
+        if (g == ((ABL & 16) ? 3 : 1)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (g == ((ABL & 16) ? 7 : 3)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
+  float sdummy, inv_x, inv_g;
+  scale_of(row_max16(p.xmax, b_acc), sdummy, inv_x);
+  scale_of(row_max16(p.dymax, b_acc), sdummy, inv_g);
+  float* slab = p.slab + (size_t)bs * 9 * C * N;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wco * 64 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = c0 + wci * 32 + mfma32_row(r, lane);
+        slab[((size_t)(kh * 3 + kw) * C + c) * N + n] = (acc[kw][j][r] * inv_x) * inv_g;
+      }
+    }
+  if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// ---- the eight-wave block on v_mfma_f32_16x16x32_f16 (round 6): the shipped form.
+// The timing probe of the 32x32x16 block above (every MFMA replaced by two 16x16x32 on the same fragments) ran the train
+// step 4.5 ms shorter (76.4 -> 72.9 ms): under the chip's power limit the 16x16 shape holds a 12-15 % higher clock for the
+// same matrix work (MI355X_MICROARCH.md, clock note 7), and the energy it does not draw is there for the kernels on the
+// other stream.  K = 32 of one MFMA is one whole image row of 32 pixels: a row pair is 2 k steps x 3 taps = 6 stages of
+// 24 MFMAs per wave (wave = 32 ci x 64 co x 3 taps = 2 x 4 tiles of 16 x 16, 96 accumulators).
+// Transposing reads for this operand shape put the four 16-lane groups of a wave on pixels 8 g .. 8 g + 7 of the SAME 16
+// channels: with 64-byte pixel records, groups g and g + 1 of a 32-lane bank group would hit the same banks (8 pixels =
+// 512 bytes).  The two 16-channel halves of a record therefore swap places on pixel columns with bit 3 set
+// (swizzle by the column inside the padded row, applied by the staging stores and by every fragment address): conflict free
+// for every tap shift.
+// One barrier per row pair, placed BEFORE the last stage: every LDS read of the pair has completed by then, so the last
+// stage prefetches the first fragments of the next pair from the other buffer and no wave starts a pair by waiting for
+// LDS (the 32x32 block stalls there, both waves of a SIMD at once).
+__device__ __forceinline__ f16x8 tr_read8h2(const unsigned char* lo_addr, const unsigned char* hi_addr) {
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lo_addr));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(hi_addr));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(f16x8, v);
+}
+
+template <int ABL = 0>
+__global__ __launch_bounds__(W8_THREADS) void conv3x3_wgrad_f16x3_w16_kernel(WgradArgsP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wci = wave >> 1, wco = wave & 1;
+  const int C = p.C, N = p.N;
+  const int ntn = N / WG3_T;
+  int bs, kh, tile;
+  w8_decode(blockIdx.x, p.S, (C / WG3_T) * ntn, bs, kh, tile);
+  const int c0 = (tile / ntn) * WG3_T, n0 = (tile % ntn) * WG3_T;
+  const int nchc = C / 16, nchn = N / 16;
+  const int pairs_per_img = p.H / WG_ROWS;
+  const int total_pairs = p.B * pairs_per_img;
+  const int pair_begin = (int)((long long)bs * total_pairs / p.S);
+  const int pair_end = (int)((long long)(bs + 1) * total_pairs / p.S);
+
+  f32x4 acc[3][2][4];   // [kw][ci tile][co tile]
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: as in the 32x32 block (wave-uniform row, scalar offsets); the LDS destination carries the swizzle
+  i32x4 xreg[4], dreg[4];
+  const __amdgpu_buffer_rsrc_t xs_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.xs), 0, 0x80000000, kBufWord3);
+  const __amdgpu_buffer_rsrc_t ds_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.dys), 0, 0x80000000, kBufWord3);
+  const int u = tid & 3, upl = u >> 1, uh = u & 1;
+  const int spix = (tid >> 2) & 63, scol = spix & 31, scc = (tid >> 8) & 1;
+  const int wrow = (wave & 3) >> 1;
+  const unsigned vlane = (unsigned)(((scc * 1024 + scol) * 2 + upl) * 32 + uh * 16);
+  const int xdst0 = upl * X3_PLANE + (wrow * kPW + scol + 1) * 64 + (scc ^ (((scol + 1) >> 3) & 1)) * 32 + uh * 16;
+  const int ddst0 = 2 * X3_PLANE + upl * D3_PLANE + spix * 64 + (scc ^ ((scol >> 3) & 1)) * 32 + uh * 16;
+  const unsigned xtile = (unsigned)((c0 >> 4) * 65536), dtile = (unsigned)((n0 >> 4) * 65536);
+  int fb = 0, fr = 0;
+  unsigned sx = 0, sd = 0, vx = vlane;
+  auto set_fetch = [&](int b, int r) {
+    fb = b; fr = r;
+    const int hx = r * WG_ROWS + kh - 1 + wrow;
+    sx = (unsigned)(b * nchc) * 65536u + xtile + (unsigned)(hx * (kW * 64));
+    sd = (unsigned)(b * nchn) * 65536u + dtile + (unsigned)((r * WG_ROWS + wrow) * (kW * 64));
+    vx = vlane | ((unsigned)hx >= (unsigned)p.H ? 0x80000000u : 0u);
+  };
+  auto gload_x1 = [&](int i) {
+    if (ABL & 2) return;
+    xreg[i] = __builtin_amdgcn_raw_buffer_load_b128(xs_rsrc, vx, sx + (unsigned)i * 131072u, 0);
+  };
+  auto gload_d1 = [&](int i) {
+    if (ABL & 2) return;
+    dreg[i] = __builtin_amdgcn_raw_buffer_load_b128(ds_rsrc, vlane, sd + (unsigned)i * 131072u, 0);
+  };
+  auto store_x = [&](unsigned char* buf, int i) {
+    if (!(ABL & 1)) *reinterpret_cast<i32x4*>(buf + xdst0 + i * X3_HALF) = xreg[i];
+  };
+  auto store_d = [&](unsigned char* buf, int i) {
+    if (!(ABL & 1)) *reinterpret_cast<i32x4*>(buf + ddst0 + i * D3_HALF) = dreg[i];
+  };
+
+  // fragment addressing: lane = (k group g = lane >> 4: pixels 8 g .. 8 g + 7; q, pq: the 4 pixels x 4 channel quads a
+  // 16-lane group presents to the transposing read).  Padded column of the pixel a lane addresses in read s (0: pixels
+  // .. + 3, 1: .. + 7) of tap kw: pc = kw + 8 g + q + 4 s; its swizzle bit (pc >> 3) & 1 = (g + carry) & 1 with
+  // carry = (kw + q + 4 s) >> 3 -- three distinct lane patterns: no carry (every s = 0 read, kw = 0, all of dy),
+  // (kw = 1, s = 1), (kw = 2, s = 1).
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+  const int lane_px = (8 * g + q) * 64 + pq * 8;
+  const int par0 = g & 1, par1 = (g + ((1 + q + 4) >> 3)) & 1, par2 = (g + ((2 + q + 4) >> 3)) & 1;
+  // x: [variant: 0 no carry, 1 (kw 1, s 1), 2 (kw 2, s 1)][ci tile]
+  int xoff[3][2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    xoff[0][ti] = wci * X3_HALF + lane_px + (ti ^ par0) * 32;
+    xoff[1][ti] = wci * X3_HALF + lane_px + (ti ^ par1) * 32;
+    xoff[2][ti] = wci * X3_HALF + lane_px + (ti ^ par2) * 32;
+  }
+  int doff[2];   // [co sub-tile inside a 32-channel record]
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) doff[tj] = 2 * X3_PLANE + (wco * 2) * D3_HALF + lane_px + (tj ^ par0) * 32;
+
+  f16x8 af[2][2][2], bfr[2][4][2];                     // [buffer][ci tile][plane], [buffer][co tile][plane]
+  auto read_a = [&](const unsigned char* buf, int slot, int rr, int kw) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const int o = pl * X3_PLANE + (rr * kPW + kw) * 64;
+        af[slot][ti][pl] = tr_read8h2(buf + xoff[0][ti] + o, buf + xoff[kw][ti] + o + 4 * 64);
+      }
+  };
+  auto read_b = [&](const unsigned char* buf, int slot, int rr) {
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const unsigned char* a = buf + doff[tj & 1] + pl * D3_PLANE + (tj >> 1) * D3_HALF + rr * kW * 64;
+        bfr[slot][tj][pl] = tr_read8h2(a, a + 4 * 64);
+      }
+  };
+
+  const bool stamp = p.stamps && blockIdx.x == 0 && threadIdx.x == 0;
+  if (stamp) { p.stamps[0] = __builtin_amdgcn_s_memtime(); p.stamps[30] = __builtin_amdgcn_s_memrealtime(); }
+  if (tid < 256) {   // the zero halo columns (pixel columns 0 and 33) of both rows, planes, halves and buffers
+    const int rec = tid >> 2;
+    const int zb = rec >> 5, zpl = (rec >> 4) & 1, zh = (rec >> 2) & 3, zr = (rec >> 1) & 1, zc = (rec & 1) * (kPW - 1);
+    const i32x4 z = {0, 0, 0, 0};
+    *reinterpret_cast<i32x4*>(smem + zb * WG3_BUF + zpl * X3_PLANE + zh * X3_HALF + (zr * kPW + zc) * 64 + (tid & 3) * 16) = z;
+  }
+  const int last = pair_end - 1;
+  int b_acc = pair_begin < pair_end ? pair_begin / pairs_per_img : 0;
+  auto advance_fetch = [&]() {
+    if (fb * pairs_per_img + fr < last) {
+      int r = fr + 1, b = fb;
+      if (r == pairs_per_img) { r = 0; ++b; }
+      set_fetch(b, r);
+    }
+  };
+  if (pair_begin < pair_end) {
+    set_fetch(b_acc, pair_begin - b_acc * pairs_per_img);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_x1(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_d1(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_x(smem, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_d(smem, i);
+    advance_fetch();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_x1(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gload_d1(i);
+  }
+  __syncthreads();
+  read_b(smem, 0, 0);
+  read_a(smem, 0, 0, 0);
+  if (stamp) p.stamps[1] = __builtin_amdgcn_s_memtime();
+  int b_now = b_acc, r_now = pair_begin - b_acc * pairs_per_img;
+  for (int pr = pair_begin; pr < pair_end; ++pr) {
+    if (stamp && pr - pair_begin < 20) p.stamps[2 + pr - pair_begin] = __builtin_amdgcn_s_memtime();
+    const int cur = (pr - pair_begin) & 1;
+    const unsigned char* bc = smem + cur * WG3_BUF;
+    unsigned char* bn = smem + (cur ^ 1) * WG3_BUF;
+    advance_fetch();                                   // -> pair pr + 2 (the registers hold pr + 1)
+    if (b_now != b_acc) {                              // next image: move the accumulators to its units (exact powers of two)
+      const int d = (clamped_exp(row_max16(p.xmax, b_acc)) - clamped_exp(row_max16(p.xmax, b_now))) +
+                    (clamped_exp(row_max16(p.dymax, b_acc)) - clamped_exp(row_max16(p.dymax, b_now)));
+      if (d != 0) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[t][i][j][r] = ldexpf(acc[t][i][j][r], d);
+      }
+      b_acc = b_now;
+    }
+    if (++r_now == pairs_per_img) { r_now = 0; ++b_now; }
+#pragma unroll
+    for (int st = 0; st < 6; ++st) {                   // st = rr * 3 + kw: image row rr of the pair (one k step), tap kw
+      const int rr = st / 3, kw = st - rr * 3;
+      if (st == 5) __syncthreads();                    // every LDS read of this pair is done: the other buffer is complete
+      if (st < 5) read_a(bc, (st + 1) & 1, (st + 1) / 3, (st + 1) % 3);
+      else read_a(bn, 0, 0, 0);                        // first fragments of the next pair
+      if (st == 1) read_b(bc, 1, 1);
+      if (st == 5) read_b(bn, 0, 0);
+      if (st < 4) { store_x(bn, st); gload_x1(st); store_d(bn, st); gload_d1(st); }
+#pragma unroll
+      for (int term = 0; term < 3; ++term) {
+        constexpr int PA[3] = {1, 0, 0};
+        constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj)
+            acc[kw][ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[st & 1][ti][PA[term]], bfr[rr][tj][PB[term]],
+                                                                     acc[kw][ti][tj], 0, 0, 0);
+      }
+      // the stage as a pipeline: one transposing read behind each of the first 8 (24: the stages that also fetch the
+      // eight dy fragments) MFMAs, the two LDS stores and the two global loads of the stage spread behind later ones
+#pragma unroll
+      for (int gq = 0; gq < 24; ++gq) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (gq < 8 || st == 1 || st == 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (st < 4 && (gq == 9 || gq == 13)) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (st < 4 && (gq == 11 || gq == 15)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if (stamp) p.stamps[22] = __builtin_amdgcn_s_memtime();
+  float sdummy, inv_x, inv_g;
+  scale_of(row_max16(p.xmax, b_acc), sdummy, inv_x);
+  scale_of(row_max16(p.dymax, b_acc), sdummy, inv_g);
+  float* slab = p.slab + (size_t)bs * 9 * C * N;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int n = n0 + wco * 64 + tj * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = c0 + wci * 32 + ti * 16 + 4 * g + r;
+          slab[((size_t)(kh * 3 + kw) * C + c) * N + n] = (acc[kw][ti][tj][r] * inv_x) * inv_g;
+        }
+      }
+  if (stamp) { p.stamps[23] = __builtin_amdgcn_s_memtime(); p.stamps[31] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// split count of the eight-wave kernel: any S works (w8_decode keeps a pixel range's blocks on one XCD), so a launch
+// that owns the chip takes 255-256 CUs; beside the main chain (share_chip) the balance point stays 120 blocks
+int wgrad_splits_w8(int B, int H, int C, int N, int share_chip) {
+  const int tiles = (C / WG3_T) * (N / WG3_T);
+  const int pairs = B * (H / WG_ROWS);
+  int target = share_chip == 1 && tiles <= 2 ? 120 : 256;
+  if (g_mulan_tune[1] > 0) target = g_mulan_tune[1];
+  int S = target / (3 * tiles);
+  if (S < 1) S = 1;
+  if (S > pairs) S = pairs;
+  return S;
+}
+
 __global__ void slab_reduce_h_kernel(const float* __restrict__ slab, float* __restrict__ out, int S, int E,
                                      int accumulate) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1451,7 +1942,8 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, co
 
 MULAN_API size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip) {
   if (W != kW || H % WG_ROWS != 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
-  return (size_t)wgrad_splits_p(B, H, C, N, share_chip) * 9 * C * N * sizeof(float);
+  const int Sw = wgrad_splits_w8(B, H, C, N, share_chip), Sp = wgrad_splits_p(B, H, C, N, share_chip);
+  return (size_t)(Sw > Sp ? Sw : Sp) * 9 * C * N * sizeof(float);     // (either kernel: tune[29] picks at launch time)
 }
 
 // dw[3,3,C,N] (+)= sum x (x) dy from the split planes written by mulan_conv3x3_fwd_f16x3 (xs: of the forward input,
@@ -1468,6 +1960,53 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
     if (e != hipSuccess) return (int)e;
     configured = true;
+  }
+  const int E = 9 * C * N;
+  if (g_mulan_tune[29] != 1) {        // the eight-wave block (default); tune[29] = 1: the four-wave block (dev A/B)
+    static bool configured8 = false;
+    if (!configured8) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w8_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w8_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+      if (e != hipSuccess) return (int)e;
+      configured8 = true;
+    }
+    const int S8 = wgrad_splits_w8(B, H, C, N, share_chip);
+    WgradArgsP a8{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
+                  B, H, C, N, S8, g_mulan_debug_buffer};
+    const dim3 grid8(3 * S8 * (C / WG3_T) * (N / WG3_T));
+#define MULAN_W8_ABL(V)                                                                                          \
+  case V:                                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w8_kernel<V>),                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);                          \
+    hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w8_kernel<V>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);      \
+    break;
+    if (g_mulan_tune[29] == 0) {      // 16x16x32 block (shipped)
+      static bool configured16 = false;
+      if (!configured16) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w16_kernel<0>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+        if (e == hipSuccess)
+          e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w16_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+        if (e != hipSuccess) return (int)e;
+        configured16 = true;
+      }
+      if (g_mulan_tune[7] == 3)
+        hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w16_kernel<3>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
+      else
+        hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w16_kernel<0>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
+    } else
+    switch (g_mulan_tune[7]) {   // tune[29] = 2: the 32x32x16 eight-wave block; dev: timing probes (wrong numbers)
+      MULAN_W8_ABL(2) MULAN_W8_ABL(3) MULAN_W8_ABL(16) MULAN_W8_ABL(19)
+      default:
+        hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w8_kernel<0>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
+    }
+#undef MULAN_W8_ABL
+    hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S8, E, accumulate);
+    MULAN_CHECK_LAUNCH();
   }
   const int S = wgrad_splits_p(B, H, C, N, share_chip);
   WgradArgsP a{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
@@ -1491,7 +2030,6 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
       hipLaunchKernelGGL(conv3x3_wgrad_f16x3_planes_kernel<3>, grid, dim3(256), WG3_SMEM + 64, stream, a);
   }
 #undef MULAN_WG_ABL
-  const int E = 9 * C * N;
   hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, workspace, dw, S, E, accumulate);
   MULAN_CHECK_LAUNCH();
 }
