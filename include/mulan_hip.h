@@ -443,7 +443,9 @@ int mulan_rowmean(const float* x, float* out, int rows, int cols, mulan_stream_t
  * Probability-flow drift of VDM.reverse_ode (model_mulan_velocity.py:393-421 modes 0 / 1 = velocity /
  * velocity_from_epsilon, model_mulan_epsilon.py:459-478 and model_vdm.py:243-260 mode 2) from the network output, and
  * the cotangent d(sum drift * hutch)/d net that the U-Net's input-gradient pass is fed for the Hutchinson estimator
- * (notebook_utils._get_value_div_fn, :203-215).  cot / hutch may be NULL (drift only). */
+ * (notebook_utils._get_value_div_fn, :203-215).  cot / hutch may be NULL (drift only).  mode | 4 (both entry points):
+ * reverse_ode(high_precision=True), the selects alpha = exp(-g/2) where 1 - sigmoid(g) <= 1e-3 and sigma = exp(g/2)
+ * where sigmoid(g) <= 1e-3 of model_mulan_velocity.py:410-417 / model_mulan_epsilon.py:472-475. */
 int mulan_ode_drift(const float* net, const float* x, const float* gt, const float* gp, const float* hutch, float* drift,
                     float* cot, size_t n, int mode, int g_per_sample, mulan_stream_t stream);
 /* div[b] = sum_i (gx_i + diag_i hutch_i) hutch_i: gx = U-Net input gradient for `cot`, diag = the closed-form

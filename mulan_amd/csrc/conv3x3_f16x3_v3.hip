@@ -432,6 +432,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
     stgB[0] = load_slot(slot_of(tid, 2), c2);
     stgB[1] = load_slot(slot_of(tid, 3), c2);
   }
+  // (DMA) the pieces of the first two chunks were issued above and other waves read them behind this barrier: nothing but
+  // the issuing wave's vmcnt orders a global_load_lds against another wave's ds_read, and the barrier drains lgkmcnt
+  // only (the in-loop barriers carry the same wait; ADVICE r05: this one had been left to whatever vmcnt(0) the compiler
+  // happened to emit, which the TR = 4 / 2 and KS = 2 instantiations change)
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int xaddr = xlane + (sel ? x_unit_off(bufA, bufB, 1) : x_unit_off(bufA, bufB, 0));   // of the step being multiplied
   read_x(xf[0], xaddr, 0);
@@ -566,6 +571,8 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void conv3x3_f16x3_v3_ke
           a[0] += o[0]; a[1] += o[1]; a[2] += o[2]; a[3] += o[3];
         }
     };
+    // (DMA) the exchange overlays the patch buffers: no piece of any wave may still be in flight towards them
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                   // every wave is through its last LDS read and has its scales
     if (kgrp == 0) send(IH{}); else send(I0{});
     __syncthreads();

@@ -11,18 +11,34 @@
 
 namespace {
 
-// mode 0 velocity, 1 velocity_from_epsilon, 2 epsilon (MuLAN epsilon model and the plain VDM)
+// mode & 3: 0 velocity, 1 velocity_from_epsilon, 2 epsilon (MuLAN epsilon model and the plain VDM)
 // c = 0.5 alpha sigma gamma'   (velocity):  drift = v c,  v = net | -e^{g/2} x + sqrt(1 + e^g) net
 // epsilon:                                  drift = 0.5 (net - sigma x) sigma gamma'
 // cot = d(sum drift * hutch) / d net   (the cotangent handed to the U-Net's input-gradient pass)
+// mode & 4: reverse_ode(high_precision=True) -- the two selects of ldm/model_mulan_velocity.py:410-417 (alpha and sigma)
+// and ldm/model_mulan_epsilon.py:472-475 (sigma): where 1 - sigmoid(g) <= 1e-3 alpha = exp(-g / 2), where
+// sigmoid(g) <= 1e-3 sigma = exp(g / 2); the square roots elsewhere
+__device__ __forceinline__ void ode_alpha_sigma(float g, bool hp, float& alpha, float& sigma) {
+  const float s = sigmoid_f(g);
+  sigma = sqrtf(s);
+  alpha = sqrtf(sigmoid_f(-g));
+  if (hp) {
+    if (s <= 1e-3f) sigma = expf(0.5f * g);
+    if (1.f - s <= 1e-3f) alpha = expf(-0.5f * g);
+  }
+}
+
 __global__ void ode_drift_kernel(const float* __restrict__ net, const float* __restrict__ x,
                                  const float* __restrict__ gt, const float* __restrict__ gp,
                                  const float* __restrict__ hutch, float* __restrict__ drift, float* __restrict__ cot,
-                                 size_t n, int mode, int g_per_sample) {
+                                 size_t n, int mode_hp, int g_per_sample) {
+  const int mode = mode_hp & 3;
+  const bool hp = (mode_hp & 4) != 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const size_t gi = g_per_sample ? i / (size_t)g_per_sample : i;
     const float g = gt[gi], dg = gp[gi];
-    const float sigma = sqrtf(sigmoid_f(g)), alpha = sqrtf(sigmoid_f(-g));
+    float sigma, alpha;
+    ode_alpha_sigma(g, hp, alpha, sigma);
     float d, k;      // drift = d, d drift / d net = k
     if (mode == 2) {
       k = 0.5f * sigma * dg;
@@ -47,8 +63,10 @@ __global__ void ode_drift_kernel(const float* __restrict__ net, const float* __r
 // network (0 for mode 0); gx = the U-Net's input gradient for the cotangent above.  One 256-thread block per sample.
 __global__ __launch_bounds__(256) void ode_div_kernel(const float* __restrict__ gx, const float* __restrict__ gt,
                                                       const float* __restrict__ gp, const float* __restrict__ hutch,
-                                                      float* __restrict__ div, int d, int mode, int g_per_sample) {
+                                                      float* __restrict__ div, int d, int mode_hp, int g_per_sample) {
   __shared__ float red[4];
+  const int mode = mode_hp & 3;
+  const bool hp = (mode_hp & 4) != 0;
   const int b = blockIdx.x;
   float s = 0.f;
   for (int j = threadIdx.x; j < d; j += 256) {
@@ -58,9 +76,11 @@ __global__ __launch_bounds__(256) void ode_div_kernel(const float* __restrict__ 
     if (mode != 0) {
       const size_t gi = g_per_sample ? (size_t)b : i;
       const float g = gt[gi], dg = gp[gi];
-      const float var = sigmoid_f(g);
-      if (mode == 2) diag = -0.5f * var * dg;
-      else diag = -expf(0.5f * g) * 0.5f * sqrtf(sigmoid_f(-g)) * sqrtf(var) * dg;
+      float sigma, alpha;
+      ode_alpha_sigma(g, hp, alpha, sigma);
+      // (the plain forms keep the expressions of rounds 3-5: sigma^2 is taken as sigmoid(g) itself)
+      if (mode == 2) diag = -0.5f * (hp ? sigma * sigma : sigmoid_f(g)) * dg;
+      else diag = -expf(0.5f * g) * 0.5f * alpha * sigma * dg;
     }
     s += (gx[i] + diag * h) * h;
   }
@@ -216,7 +236,7 @@ int grid_for(size_t n) { return (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) 
 
 MULAN_API int mulan_ode_drift(const float* net, const float* x, const float* gt, const float* gp, const float* hutch,
                               float* drift, float* cot, size_t n, int mode, int g_per_sample, hipStream_t stream) {
-  if (n == 0 || mode < 0 || mode > 2 || g_per_sample < 0 || (cot && !hutch)) return (int)hipErrorInvalidValue;
+  if (n == 0 || mode < 0 || mode > 6 || (mode & 3) == 3 || g_per_sample < 0 || (cot && !hutch)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(ode_drift_kernel, dim3(grid_for(n)), dim3(256), 0, stream, net, x, gt, gp, hutch, drift, cot, n,
                      mode, g_per_sample);
   MULAN_CHECK_LAUNCH();
@@ -224,7 +244,7 @@ MULAN_API int mulan_ode_drift(const float* net, const float* x, const float* gt,
 
 MULAN_API int mulan_ode_div(const float* gx, const float* gt, const float* gp, const float* hutch, float* div, int B,
                             int d, int mode, int g_per_sample, hipStream_t stream) {
-  if (B <= 0 || d <= 0 || mode < 0 || mode > 2) return (int)hipErrorInvalidValue;
+  if (B <= 0 || d <= 0 || mode < 0 || mode > 6 || (mode & 3) == 3) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(ode_div_kernel, dim3(B), dim3(256), 0, stream, gx, gt, gp, hutch, div, d, mode, g_per_sample);
   MULAN_CHECK_LAUNCH();
 }

@@ -241,7 +241,7 @@ def get_ode_likelihood_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, a
             draw = probes if probes is not None else hutch.noise
             n_x = B * 3072
 
-            f = ode_function(model, params, ctx, B, dev, True, cache=graphs)   # a replayed HIP graph (model.GraphedOdeFunction)
+            f = ode_function(model, params, ctx, B, dev, True, cache=graphs, high_precision=high_precision)   # a replayed HIP graph
 
             def ode_func(t, y32, out):
                 f(t, y32[:n_x].view(B, 3072), draw(), out[:n_x].view(B, 3072), out[n_x:])
@@ -284,7 +284,7 @@ def get_sample_fn(experiment, hutchinson_type='Rademacher', rtol=1e-5, atol=1e-5
         try:
             ctx = model.ode_context_from_embedding(params, emb)
 
-            f = ode_function(model, params, ctx, sample_size, dev, False)
+            f = ode_function(model, params, ctx, sample_size, dev, False, high_precision=high_precision)
 
             def ode_func(t, y32, out):
                 f(t, y32.view(sample_size, 3072), None, out.view(sample_size, 3072))

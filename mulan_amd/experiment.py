@@ -217,6 +217,26 @@ class GraphedStep:
         return state, metrics
 
 
+def choose_step_form(cfg_hip_graph, env, world, batch_size_train, n_embd, opt_in_overlap):
+    """-> (replay the step as a HIP graph?, is a failed capture an error?).  cfg_hip_graph: config.training.hip_graph
+    (True / False / None), env: MULAN_HIP_GRAPH ('1' / '0' / anything else = unset).
+    Asked for explicitly (config or environment): a failed capture is an error.  Chosen by default -- the multi-rank
+    heuristic included: a warning and the eager step (a training run must not lose the replay without anybody noticing,
+    and on several ranks one rank raising while the others enter their collectives would hang the job:
+    parallel.GradReducer.eager_order exists so that a rank CAN fall back).  `required` is therefore decided from the
+    explicit inputs only, before the heuristic turns `want` into a bool."""
+    want = cfg_hip_graph
+    required = want is True or (env == "1" and want is not False)
+    if want is None and env not in ("0", "1") and world > 1 and not opt_in_overlap:
+        local = max(1, int(batch_size_train) // world)
+        want = local * (float(n_embd) / 128.0) ** 2 < 96
+    if env in ("0", "1"):
+        want = env == "1" and want is not False
+    elif want is None:
+        want = True
+    return bool(want), required
+
+
 class Experiment(abc.ABC):
     """Boilerplate for training and evaluating VDM models (ldm/experiment.py:42-104)."""
 
@@ -271,18 +291,10 @@ class Experiment(abc.ABC):
         # replay WITH overlap (signal words, GRAPH_OVERLAP above) is opt-in until it has run on a multi-GPU RCCL box.
         self.graph_overlap = bool(config.training.get("graph_overlap", GRAPH_OVERLAP)) and self.world > 1
         self.graph_collectives = bool(config.training.get("graph_collectives", GRAPH_COLLECTIVES)) and self.world > 1
-        env = os.environ.get("MULAN_HIP_GRAPH", "")
-        want = config.training.get("hip_graph", None)
-        if want is None and env not in ("0", "1") and self.world > 1 and not (self.graph_overlap or self.graph_collectives):
-            local = max(1, int(config.training.batch_size_train) // self.world)
-            want = local * (float(config.model.sm_n_embd) / 128.0) ** 2 < 96
-        # asked for explicitly (config or environment): a failed capture is an error; chosen by default: a warning and
-        # the eager step (a training run must not lose the replay without anybody noticing)
-        self.hip_graph_required = want is True or (env == "1" and want is not False)
-        if env in ("0", "1"):
-            want = env == "1" and want is not False
-        elif want is None:
-            want = True
+        want, self.hip_graph_required = choose_step_form(
+            config.training.get("hip_graph", None), os.environ.get("MULAN_HIP_GRAPH", ""), self.world,
+            int(config.training.batch_size_train), float(config.model.sm_n_embd),
+            self.graph_overlap or self.graph_collectives)
         self.hip_graph = bool(want) and torch.device(self.device).type == "cuda"
         self._graphed = None
         self._eager_steps = 0

@@ -209,7 +209,7 @@ class GraphedOdeFunction:
     (tests/test_gpu_ode.py::test_replayed_ode_function_equals_the_eager_one).  The weights must stay as they are while the
     object lives (the caller holds the ParamPacker refresh)."""
 
-    def __init__(self, model, params, ctx, B, device, with_div):
+    def __init__(self, model, params, ctx, B, device, with_div, high_precision=False):
         self.model, self.B, self.with_div, self.params = model, B, with_div, params
         f32 = dict(device=device, dtype=torch.float32)
         # the per-batch context (embedding, schedule coefficients) in buffers of its own: set_context() re-targets a
@@ -221,7 +221,7 @@ class GraphedOdeFunction:
         self.drift = torch.empty((B, D), **f32)
         self.div = torch.empty((B,), **f32) if with_div else None
         run = lambda: model.reverse_ode(params, self.x, ctx, None, self.probe, drift_out=self.drift, div_out=self.div,
-                                        tt=self.tt)
+                                        tt=self.tt, **({"high_precision": True} if high_precision else {}))
         for _ in range(2):             # eager first: every kernel configured, the allocator warm
             run()
         torch.cuda.synchronize()
@@ -245,7 +245,7 @@ class GraphedOdeFunction:
             div_out.copy_(self.div.view_as(div_out))
 
 
-def ode_function(model, params, ctx, B, device, with_div, graph=None, cache=None):
+def ode_function(model, params, ctx, B, device, with_div, graph=None, cache=None, high_precision=False):
     """-> f(t, x [B, 3072], probe | None, drift_out, div_out | None): VDM.reverse_ode as the ODE solvers call it; a
     replayed HIP graph by default (MULAN_ODE_GRAPH), eager where the capture fails (logged).  cache (a dict the caller
     keeps while the weights stay as they are): the captured graph of a batch size is re-used for the next batch / the
@@ -253,13 +253,19 @@ def ode_function(model, params, ctx, B, device, with_div, graph=None, cache=None
     if graph is None:
         graph = ODE_GRAPH
     if graph and torch.device(device).type == "cuda":
-        key = (B, bool(with_div), id(params))
+        # the key names what the captured kernels were chosen by: batch, with / without the divergence term and the
+        # arithmetic mode (as GraphedStep.matches does; the developer tuning words of mulan_set_tuning are not product
+        # state: a caller that flips them drops the cache); the parameter tree is held by the entry and compared by identity -- an id() alone could be re-used by a new tree once the old one is freed
+        # (ADVICE r05).  drop_ode_graphs(cache) releases the graph's private pool (a forward + backward pass of
+        # activations) when the caller goes back to training.
+        key = (B, bool(with_div), ops.CONV_MODE, bool(high_precision))
         hit = cache.get(key) if cache is not None else None
-        if hit is not None:
+        if hit is not None and hit.params is params:
             hit.set_context(ctx)
             return hit
         try:
-            g = GraphedOdeFunction(model, params, ctx, B, device, with_div)
+            g = GraphedOdeFunction(model, params, ctx, B, device, with_div, high_precision)
+            g.params = params
             if cache is not None:
                 cache.clear()            # (one graph at a time: its pool holds a forward + backward pass of activations)
                 cache[key] = g
@@ -268,8 +274,17 @@ def ode_function(model, params, ctx, B, device, with_div, graph=None, cache=None
             import logging
             logging.getLogger("mulan").warning("HIP-graph capture of the ODE function evaluation failed (%s: %s); "
                                                "evaluating eagerly", type(e).__name__, e)
+    hp = {"high_precision": True} if high_precision else {}
     return lambda t, x, probe, drift_out, div_out=None: model.reverse_ode(params, x, ctx, t, probe, drift_out=drift_out,
-                                                                          div_out=div_out)
+                                                                          div_out=div_out, **hp)
+
+
+def drop_ode_graphs(cache):
+    """Release the captured ODE function evaluations of `cache` (the dict handed to ode_function) and their private
+    memory pools: call it when the likelihood evaluation is over and training continues."""
+    if cache:
+        cache.clear()
+        torch.cuda.empty_cache()
 
 
 def resnet_block(p, x1, x2, cond, drop):
@@ -632,16 +647,19 @@ class MulanVDM(_VDMBase):
         with torch.no_grad():
             return dict(emb=emb, kl=None, coeffs=poly_coefficients(params["gamma"], emb), logits=None)
 
-    def _ode_mode(self):
+    def _ode_mode(self, high_precision=False):
+        hp = 4 if high_precision else 0       # mulan_ode_drift / mulan_ode_div: mode | 4 = the high_precision selects
         if self.parameterization == "velocity":
-            return 1 if self.config.velocity_from_epsilon else 0
-        return 2
+            return (1 if self.config.velocity_from_epsilon else 0) | hp
+        return 2 | hp
 
-    def reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_out=None, tt=None):
+    def reverse_ode(self, params, x, ctx, t, hutch=None, drift_out=None, div_out=None, tt=None, high_precision=False):
         """VDM.reverse_ode at time t for x [B, 3072]; with `hutch` also the Hutchinson estimate
         hutch^T (d drift / d x) hutch per sample (notebook_utils._get_value_div_fn): returns (drift, div | None).
-        tt (optional, [B] fp32 device tensor): the time as a stream-ordered parameter (GraphedOdeFunction) instead of t"""
+        tt (optional, [B] fp32 device tensor): the time as a stream-ordered parameter (GraphedOdeFunction) instead of t.
+        high_precision: the alpha / sigma selects of ldm/model_mulan_velocity.py:410-417, model_mulan_epsilon.py:472-475"""
         cfg = self.config
+        mode = self._ode_mode(high_precision)
         B = x.shape[0]
         a, b, c = ctx["coeffs"]
         if tt is None:
@@ -653,14 +671,14 @@ class MulanVDM(_VDMBase):
         if hutch is None:
             with torch.no_grad():
                 net = score_unet(params["score_model"], cfg, xin.view(B, HW, 3), g_in, ctx["emb"], _Drop(None, 0.0))
-                drift, _ = ops.ode_drift(net.reshape(B, D), xin, gt, gp, None, self._ode_mode(), drift_out)
+                drift, _ = ops.ode_drift(net.reshape(B, D), xin, gt, gp, None, mode, drift_out)
             return drift, None
         xin.requires_grad_(True)
         with torch.enable_grad():
             net = score_unet(params["score_model"], cfg, xin.view(B, HW, 3), g_in, ctx["emb"], _Drop(None, 0.0))
-        drift, cot = ops.ode_drift(net.detach().reshape(B, D), xin.detach(), gt, gp, hutch, self._ode_mode(), drift_out)
+        drift, cot = ops.ode_drift(net.detach().reshape(B, D), xin.detach(), gt, gp, hutch, mode, drift_out)
         (gx,) = torch.autograd.grad(net, xin, cot.view_as(net))
-        div = ops.ode_div(gx.reshape(B, D), gt, gp, hutch, self._ode_mode(), div_out)
+        div = ops.ode_div(gx.reshape(B, D), gt, gp, hutch, mode, div_out)
         return drift, div
 
 

@@ -1128,21 +1128,6 @@ def _gn_forward(ctx, x1, x2, gamma, beta, groups, eps, act, keep, seed, offset):
     return y, x1, x2
 
 
-# (dev probe, round 5; results WRONG: timing only) the GroupNorm backward launches of the train step on the streaming
-# kernel with all-zero group sums -- what the kernel would gain in the step if the input-gradient convolutions left the
-# sums for it (DESIGN: GroupNorm).  MULAN_TUNE=21=3 selects the thin (64-register, 256-thread) form.
-GN_BWD_STREAM_PROBE = _os.environ.get("MULAN_GN_BWD_STREAM_PROBE", "0") == "1"
-_ZERO_GSTATS = {}
-
-
-def _probe_gstats(B, Ct, device):
-    key = (B, Ct, device)
-    z = _ZERO_GSTATS.get(key)
-    if z is None:
-        z = _ZERO_GSTATS[key] = torch.zeros((B, 4, Ct // 4, 2), device=device, dtype=torch.float32)
-    return z
-
-
 def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False, add1b=None):
     """dx1, dx2 (+ the gradients add1 / add2 that reach x1 / x2 through a skip path), dgamma, dbeta.  The written dx1
     carries its maxima and per-sample channel sums for the convolution in front (whose dy it is).
@@ -1170,15 +1155,7 @@ def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False, add1b=None):
         dgamma = _fresh(gvg) if gvg is not None else torch.empty(C1, device=dy.device, dtype=torch.float32)
         dbeta = _fresh(gvb) if gvb is not None else torch.empty(C1, device=dy.device, dtype=torch.float32)
         sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
-        if GN_BWD_STREAM_PROBE:
-            parts4 = torch.empty((3, 4 * B, C1), device=dy.device, dtype=torch.float32)
-            call("mulan_groupnorm_bwd_stream", ptr(dy), ptr(dymax_in[0]), ptr(x1), None, C1, 0, ptr(gamma), ptr(beta),
-                 ptr(mean), ptr(rstd), ptr(_probe_gstats(B, C1, dy.device)), None, None, ptr(dxp), ptr(parts4[0]),
-                 ptr(parts4[1]), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(bound), None, None, None, None,
-                 ptr(parts4[2]), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2), ptr(_gn_tickets(dy.device)),
-                 ptr(getattr(ctx, "keepbits", None)), stream())
-        else:
-          call("mulan_groupnorm_bwd_fused_planes", ptr(dy), ptr(dymax_in[0]), ptr(x1), C1, ptr(gamma), ptr(beta), ptr(mean),
+        call("mulan_groupnorm_bwd_fused_planes", ptr(dy), ptr(dymax_in[0]), ptr(x1), C1, ptr(gamma), ptr(beta), ptr(mean),
              ptr(rstd), ptr(dxp), ptr(parts[0]), ptr(parts[1]), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(bound),
              ptr(csum), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2), ptr(_gn_tickets(dy.device)),
              ptr(getattr(ctx, "keepbits", None)), stream())
@@ -1202,16 +1179,7 @@ def _gn_backward(ctx, dy, add1=None, add2=None, planes_out=False, add1b=None):
     dbeta = _fresh(gvb) if gvb is not None else torch.empty(Ct, device=dy.device, dtype=torch.float32)
     cpg = Ct // groups
     fused = (GN_FUSED_REDUCE and C1 % 32 == 0 and C2 % 32 == 0 and Ct // 32 <= 16 and cpg % 4 == 0 and 32 % cpg == 0)
-    if fused and GN_BWD_STREAM_PROBE:
-        sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
-        parts4 = torch.empty((3, 4 * B, Ct), device=dy.device, dtype=torch.float32)
-        call("mulan_groupnorm_bwd_stream", ptr(dy), None, ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean),
-             ptr(rstd), ptr(_probe_gstats(B, Ct, dy.device)), ptr(dx1), ptr(dx2), None, ptr(parts4[0]), ptr(parts4[1]), B,
-             HW, groups, act, keep, sv, offset, ptr(sd), ptr(m1), ptr(m2), ptr(_c(add1)), ptr(_c(add2)), ptr(_c(add1b)),
-             ptr(parts4[2]), ptr(dgamma), ptr(dbeta), ptr(sink), ptr(sink2), ptr(_gn_tickets(dy.device)), None, stream())
-        if sink is not None:
-            dx1._biasdone = (sink, sink2, dx1._version)
-    elif fused:       # the sums over the samples (dgamma, dbeta, the bias gradient of the convolution in front) in-kernel
+    if fused:         # the sums over the samples (dgamma, dbeta, the bias gradient of the convolution in front) in-kernel
         sink, sink2 = ctx.bias_sink if ctx.bias_sink is not None else (None, None)
         call("mulan_groupnorm_bwd_fused", ptr(dy), ptr(x1), ptr(x2), C1, C2, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
              ptr(dx1), ptr(dx2), ptr(dgp), ptr(dbp), B, HW, groups, act, keep, sv, offset, ptr(sd), ptr(m1), ptr(m2),

@@ -339,22 +339,27 @@ def gumbel_kl_loss(logits):
     return (q * (logq - math.log(1.0 / logits.shape[-1]))).sum(dim=-1)
 
 
-def ode_drift(net, x, g_t, g_p, kind):
+def ode_drift(net, x, g_t, g_p, kind, high_precision=False):
     """the closed form around the network in VDM.reverse_ode: kind 'velocity' / 'vfe' (velocity_from_epsilon)
-    (ldm/model_mulan_velocity.py:403-421), 'epsilon' (ldm/model_mulan_epsilon.py:471-478)"""
+    (ldm/model_mulan_velocity.py:403-421), 'epsilon' (ldm/model_mulan_epsilon.py:471-478); high_precision: the
+    jnp.where selects of model_mulan_velocity.py:410-417 / model_mulan_epsilon.py:472-475"""
     sigma = torch.sqrt(torch.sigmoid(g_t))
+    if high_precision:
+        sigma = torch.where(torch.sigmoid(g_t) <= 1e-3, torch.exp(g_t / 2), sigma)
     if kind == "epsilon":
         return 0.5 * (-sigma * x + net) * sigma * g_p
     v_hat = net
     if kind == "vfe":
         v_hat = -torch.exp(0.5 * g_t) * x + torch.sqrt(1 + torch.exp(g_t)) * net
     alpha = torch.sqrt(1 - torch.sigmoid(g_t))
+    if high_precision:
+        alpha = torch.where(1 - torch.sigmoid(g_t) <= 1e-3, torch.exp(-g_t / 2), alpha)
     return v_hat * (0.5 * alpha * sigma * g_p)
 
 
-def reverse_ode(params, cfg, x, emb, t):
+def reverse_ode(params, cfg, x, emb, t, high_precision=False):
     """VDM.reverse_ode (ldm/model_mulan_velocity.py:393-421 incl. velocity_from_epsilon; ldm/model_mulan_epsilon.py:
-    459-478), high_precision False; x [B,32,32,3], t float"""
+    459-478); x [B,32,32,3], t float"""
     B = x.shape[0]
     a, b, c = poly_coefficients(emb, params["gamma"])
     tt = torch.full((B,), float(t), dtype=x.dtype)
@@ -364,8 +369,8 @@ def reverse_ode(params, cfg, x, emb, t):
     g_in = g_t if per_pixel else g_t.reshape(B, -1).mean(dim=1)
     net = score_unet(x, g_in, emb, params["score_model"], cfg["n_embd"], cfg["n_layer"], per_pixel)
     if cfg["vdm_type"] == "mulan_velocity":
-        return ode_drift(net, x, g_t, g_p, "vfe" if cfg.get("velocity_from_epsilon", False) else "velocity")
-    return ode_drift(net, x, g_t, g_p, "epsilon")
+        return ode_drift(net, x, g_t, g_p, "vfe" if cfg.get("velocity_from_epsilon", False) else "velocity", high_precision)
+    return ode_drift(net, x, g_t, g_p, "epsilon", high_precision)
 
 
 def plain_reverse_ode(params, cfg, x, emb, t, gmin=GAMMA_MIN, gmax=GAMMA_MAX):

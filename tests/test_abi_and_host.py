@@ -724,3 +724,25 @@ def test_committed_bench_record_keeps_the_driver_contract():
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["cores"] >= 1
     assert set(rec["configs"]) >= {"3", "4", "5", "sampler", "ode"}
+
+
+def test_step_form_choice_only_explicit_requests_make_a_failed_capture_fatal():
+    """the multi-rank default heuristic may pick the replayed step, but only an explicit request
+    (config.training.hip_graph=True or MULAN_HIP_GRAPH=1) turns a failed capture into an error -- a default-chosen
+    replay must fall back to the eager step with a warning, or one rank raising would hang the others' collectives."""
+    from mulan_amd.experiment import choose_step_form as f
+    # one rank, nothing said: replay, not required
+    assert f(None, "", 1, 128, 128, False) == (True, False)
+    # several ranks, small local batch: the heuristic picks the replay -- still not required
+    assert f(None, "", 8, 512, 128, False) == (True, False)          # 64 per GPU < 96
+    assert f(None, "", 8, 1024, 128, False) == (False, False)        # 128 per GPU: eager overlapped step
+    assert f(None, "", 8, 1024, 256, False) == (False, False)        # E = 256 counts four-fold
+    assert f(None, "", 8, 128, 256, False) == (True, False)          # 16 per GPU x 4 = 64 < 96
+    # explicit requests
+    assert f(True, "", 8, 1024, 128, False) == (True, True)
+    assert f(None, "1", 8, 1024, 128, False) == (True, True)
+    assert f(False, "1", 8, 1024, 128, False) == (False, False)      # the config's False wins over the environment
+    assert f(None, "0", 1, 128, 128, False) == (False, False)
+    assert f(True, "0", 1, 128, 128, False) == (False, True)         # asked for by config, switched off by the environment
+    # the opt-in overlap forms keep the replay as their default
+    assert f(None, "", 8, 1024, 128, True) == (True, False)

@@ -161,6 +161,79 @@ def test_normal_logp_and_hard_topk():
     assert torch.equal(emb0, torch.ones_like(emb0)) and float(kl0.abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("kind,mode", [("velocity", 0), ("vfe", 1), ("epsilon", 2)])
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_ode_drift_and_divergence_high_precision(kind, mode, per_sample):
+    """reverse_ode(high_precision=True): the selects of ldm/model_mulan_velocity.py:410-417 (alpha, sigma) and
+    ldm/model_mulan_epsilon.py:472-475 (sigma) in mulan_ode_drift / mulan_ode_div (mode | 4) against the oracle's
+    float64 closed form, with gamma on both sides of both thresholds (sigmoid(g) <= 1e-3 below -6.9, 1 - sigmoid(g)
+    <= 1e-3 above +6.9); drift, the cotangent d drift / d net and the explicit diagonal term of the divergence."""
+    from mulan_amd import ops
+    rng = np.random.default_rng(3)
+    B, d = 4, 3072
+    g = rng.uniform(-15.0, 15.0, (B, 1) if per_sample else (B, d)).astype(np.float32)
+    g[np.abs(np.abs(g) - 6.9068) < 2e-3] += 0.01          # fp32 and float64 may disagree exactly at a threshold
+    gp = rng.uniform(0.5, 20.0, g.shape).astype(np.float32)
+    net, x = rng.standard_normal((B, d)).astype(np.float32), rng.standard_normal((B, d)).astype(np.float32)
+    h = (rng.integers(0, 2, (B, d)) * 2.0 - 1.0).astype(np.float32)
+    gx = rng.standard_normal((B, d)).astype(np.float32)
+    c = lambda a: torch.tensor(a).cuda()
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64)
+    for hp in (False, True):
+        drift, cot = ops.ode_drift(c(net), c(x), c(g.reshape(-1)), c(gp.reshape(-1)), c(h), mode | (4 if hp else 0))
+        div = ops.ode_div(c(gx), c(g.reshape(-1)), c(gp.reshape(-1)), c(h), mode | (4 if hp else 0))
+        n64, x64 = t64(net).requires_grad_(True), t64(x).requires_grad_(True)
+        f = tr.ode_drift(n64, x64, t64(g), t64(gp), kind, hp)
+        dn, dx = torch.autograd.grad(f.sum(), (n64, x64), allow_unused=True)
+        dx = torch.zeros_like(f) if dx is None else dx
+        assert _rel(drift.cpu().numpy(), f.detach().numpy()) < 2e-6, hp
+        assert _rel(cot.cpu().numpy(), (dn * t64(h)).numpy()) < 2e-6, hp
+        div_ref = ((t64(gx) + dx * t64(h)) * t64(h)).sum(dim=1).numpy()
+        assert np.abs(div.cpu().double().numpy() - div_ref).max() < 2e-5 * np.abs(div_ref).max() + 1e-3, hp
+    # the selects change something: where sigmoid(g) <= 1e-3 the plain sigma = sqrt(sigmoid(g)) and exp(g / 2) differ
+    # (sqrt(sigmoid(g)) = exp(g / 2) / sqrt(1 + exp(g)): relative difference exp(g) / 2)
+    lo = torch.tensor(g < -7.0).expand(B, d)
+    a = tr.ode_drift(t64(net), t64(x), t64(g), t64(gp), kind, False)
+    b = tr.ode_drift(t64(net), t64(x), t64(g), t64(gp), kind, True)
+    assert float(((a - b).abs() / (b.abs() + 1e-300))[lo].max()) > 0.2 * math.exp(float(g[g < -7.0].max()))
+
+
+def test_reverse_ode_high_precision_reaches_the_kernels():
+    """VDM.reverse_ode(high_precision=True) and the likelihood function built with it evaluate the selected forms (not
+    silently the plain ones): at t = 0 (gamma = -13.3: sigmoid(g) = 1.7e-6 <= 1e-3) the drift agrees with the
+    oracle's high_precision drift, eager and replayed; the plain model_vdm.VDM has no such argument (ldm/model_vdm.py:243)
+    and raises like the reference's apply() would."""
+    from mulan_amd import model as M
+    vdm, params, ref_params, ocfg = _setup("mulan_velocity", "vdm", True)
+    rng = np.random.default_rng(11)
+    B = 2
+    img = rng.integers(0, 256, (B, 32, 32, 3)).astype(np.uint8)
+    ctx = vdm.ode_context(params, torch.tensor(img).cuda())
+    x = torch.tensor(rng.standard_normal((B, 3072)).astype(np.float32)).cuda()
+    h = torch.tensor((rng.integers(0, 2, (B, 3072)) * 2.0 - 1.0).astype(np.float32)).cuda()
+    dev_params = params_on_device(ref_params)
+    emb = ctx["emb"].cpu().double()
+    for t in (0.0, 0.4):
+        drift, div = vdm.reverse_ode(params, x, ctx, t, h, high_precision=True)
+        ref = on_device(lambda xx, ee: tr.reverse_ode(dev_params, ocfg, xx, ee, t, True))(
+            x.cpu().double().reshape(B, 32, 32, 3), emb)
+        assert _rel(drift.cpu().numpy(), ref.reshape(B, -1).numpy()) < 3e-4, t
+        f = M.ode_function(vdm, params, ctx, B, "cuda", True, high_precision=True)
+        assert isinstance(f, M.GraphedOdeFunction)
+        d2, v2 = torch.empty_like(drift), torch.empty_like(div)
+        f(t, x, h, d2, v2)
+        assert torch.equal(d2, drift) and torch.equal(v2, div)
+    plain, _ = vdm.reverse_ode(params, x, ctx, 0.0, h)
+    hp, _ = vdm.reverse_ode(params, x, ctx, 0.0, h, high_precision=True)
+    assert not torch.equal(plain, hp)
+    from mulan_amd.rng import PRNGKey
+    cfg, _ = make_cfg()
+    pvdm = M.make_vdm("vdm", dataclasses.replace(cfg, gamma_type="learnable_scalar", z_conditioning=False, reparam_type="noise"))
+    pparams = M.tree_map(lambda t: t.cuda(), pvdm.init(PRNGKey(0)))
+    with pytest.raises(TypeError):
+        pvdm.reverse_ode(pparams, x, pvdm.ode_context(pparams, torch.tensor(img).cuda()), 0.5, h, high_precision=True)
+
+
 # ------------------------------------------------------------------------------------------------ model level
 def _setup(vdm_type, unet_type, vfe, seed=5, E=128):
     from mulan_amd import model as M
