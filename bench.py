@@ -187,6 +187,77 @@ def cpu_baseline(cfg_path, vdm_type, batch, steps):
                                             f"learnable_nnet, no dropout), same U-Net, fp32, {dt_b:.1f} s of CPU work"}}
 
 
+class Telemetry:
+    """What the chip held while a timed region ran (config #4 read 542 -> 536 -> 510 images/s over three
+    driver runs with nothing on the line to tell a slower box from a slower build): shader clock, socket power, power cap
+    and temperatures of THIS process's GPU, sampled from the amdgpu hwmon files of its PCI device every 10 ms by a host
+    thread (reads of sysfs: nothing is launched), plus the caching allocator's high-water mark.  Every field is None where
+    the file is not readable."""
+
+    def __init__(self, device_index=0):
+        self.dir = None
+        try:
+            import glob
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if want in os.path.realpath(d).lower():
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw:
+                        self.dir = hw[0]
+                    break
+        except Exception:       # noqa: BLE001  telemetry never fails a run
+            self.dir = None
+        self.samples, self._stop, self._thread = [], None, None
+
+    def _read(self, name, scale):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip()) * scale
+        except Exception:       # noqa: BLE001
+            return None
+
+    def sample(self):
+        if self.dir is None:
+            return None
+        return (self._read("freq1_input", 1e-6), self._read("power1_input", 1e-6), self._read("temp2_input", 1e-3),
+                self._read("temp3_input", 1e-3))
+
+    def __enter__(self):
+        import threading
+        import torch
+        torch.cuda.reset_peak_memory_stats()
+        self.samples = []
+        if self.dir is not None:
+            self._stop = threading.Event()
+
+            def run():
+                while not self._stop.is_set():
+                    self.samples.append(self.sample())
+                    self._stop.wait(0.01)
+            self._thread = threading.Thread(target=run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+        return False
+
+    def summary(self):
+        import torch
+        col = lambda i: [x[i] for x in self.samples if x is not None and x[i] is not None]
+        stat = lambda v, nd=0: None if not v else {"min": round(min(v), nd), "mean": round(sum(v) / len(v), nd), "max": round(max(v), nd)}
+        return {"sclk_mhz": stat(col(0)), "socket_power_w": stat(col(1)),
+                "power_cap_w": None if self.dir is None else self._read("power1_cap", 1e-6),
+                "temp_c": {"junction": stat(col(2)), "hbm": stat(col(3))} if self.dir is not None else None,
+                "samples": len(self.samples), "source": (self.dir + "/{freq1_input,power1_input,power1_cap,temp2_input,"
+                                                         "temp3_input}, one read per 10 ms of the timed region") if self.dir else None,
+                "allocator_peak_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+
+
 def _latest_pmc():
     """the newest committed PMC summary of the convolution kernel (profiles/rNN_pmc_conv3x3_f16x3.json)"""
     d = os.path.join(ROOT, "profiles")
@@ -319,12 +390,76 @@ def conv_roofline(exp, state, batch, a, rank, world, B, E, step_s):
             roof.update({"achieved": round(ach_alone, 2), "frac": round(ach_alone / roof["peak"], 4),
                          "executed_mfma_tflops": round(3 * ach_alone, 1) if roof["executed_mfma_tflops"] else None,
                          "avg_launch_us": round(t_alone / len(mine) * 1e6, 1),
-                         "share_of_step": None,
+                         # this kernel's launches, each alone on the chip, as a share of the timed step (as_run.share_of_step:
+                         # the same launches as they ran, stretched by the weight-gradient stream beside them)
+                         "share_of_step": round(t_alone / step_s, 3),
+                         "frac_as_run": roof["as_run"]["frac"],
                          "symbols": {k: {"launches_per_step": v[2], "avg_launch_us": round(v[0] / v[2] * 1e6, 1),
                                          "tflops": round(v[1] / v[0] / 1e12, 1)} for k, v in per_lab.items()},
                          "measured": "one extra train step with the weight-gradient stream off (MULAN_SIDE_STREAM=0): no "
                                      "other kernel on the chip while a launch of this kernel runs"})
     return state, roof
+
+
+def multi_rank_report(exp, state, batches, B, steps, warmup, world, dev, elapsed, elapsed_local, barrier):
+    """What a --gpus N run must say about itself (the driver's one SCALE run is the only RCCL evidence
+    this build gets: ldm/experiment.py:89-95,341).  After the K timed steps, on every rank:
+      * replicas_in_sync: max |difference| over the ranks of the flat parameter buffer and of the EMA buffer (element-wise
+        MAX minus MIN all-reduce): data parallelism keeps replicas bit-identical -- every rank adds the same all-reduced
+        gradient with the same optimizer kernel -- so anything but 0.0 is a bug and the run exits non-zero;
+      * ms_per_step of every rank (its own clock around the same timed region);
+      * allreduce_exposed_ms: the timed step minus the same step with the collectives left out
+        (GradReducer.skip_collectives), i.e. what of the gradient exchange is NOT hidden under the backward pass;
+      * n1_equivalent: the throughput one GPU of this run reaches on its per-GPU batch with no exchange at all, and the
+        scaling efficiency of the line against N times that (the driver computes its own from the per-N lines)."""
+    import torch
+    import torch.distributed as dist
+    tl = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+    allt = [torch.zeros_like(tl) for _ in range(world)]
+    dist.all_gather(allt, tl)
+    per_rank = [round(float(x[0]) / steps * 1e3, 3) for x in allt]
+
+    def spread(buf):
+        mx, mn = buf.detach().clone(), buf.detach().clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        return float((mx - mn).abs().max())
+    d_params, d_ema = spread(state.flat), spread(state.ema)
+    rep = {"replicas_in_sync": d_params == 0.0 and d_ema == 0.0, "max_abs_param_difference_over_ranks": d_params,
+           "max_abs_ema_difference_over_ranks": d_ema, "checked": "flat parameter buffer and EMA buffer after the timed steps",
+           "ms_per_step_by_rank": per_rank, "ms_per_step_min": min(per_rank), "ms_per_step_max": max(per_rank)}
+    red = exp.reducer
+    captured = bool(exp._graphed is not None and getattr(exp._graphed, "captured_collectives", False))
+    if red.enabled and not captured:
+        red.skip_collectives = True
+        try:
+            for i in range(2):
+                state, _ = exp.train_step(exp._train_rng, state, batches[i % len(batches)])
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            n = max(2, min(steps, 10))
+            for i in range(n):
+                state, _ = exp.train_step(exp._train_rng, state, batches[i % len(batches)])
+            torch.cuda.synchronize()
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / n], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        finally:
+            red.skip_collectives = False
+        no_coll_ms = float(t[0]) * 1e3
+        ms = elapsed / steps * 1e3
+        rep.update({"ms_per_step_without_collectives": round(no_coll_ms, 3),
+                    "allreduce_exposed_ms": round(ms - no_coll_ms, 3),
+                    "n1_equivalent": {"images_per_sec_per_gpu": round(B / no_coll_ms * 1e3, 2),
+                                      "what": "this run's per-GPU batch with the gradient exchange left out (max over ranks): what "
+                                              "one GPU does alone",
+                                      "scaling_efficiency": round((B * world / ms) / (world * B / no_coll_ms), 4)},
+                    "note": "the steps without collectives ran AFTER the replica check (the replicas drift apart from there on)"})
+    else:
+        rep.update({"allreduce_exposed_ms": None, "n1_equivalent": None,
+                    "note": "collectives captured into the step's graph: cannot be left out of a replay"})
+    return rep
 
 
 def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f32_reference):
@@ -368,20 +503,25 @@ def train_workload(a, rank, world, cfg_path, vdm_type, vfe, B, steps, warmup, f3
         state, _ = exp.train_step(exp._train_rng, state, batches[i % len(batches)])
     torch.cuda.synchronize()
     barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        state, m = exp.train_step(exp._train_rng, state, batches[(warmup + i) % len(batches)])
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    tele = Telemetry(torch.cuda.current_device())
+    with tele:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            state, m = exp.train_step(exp._train_rng, state, batches[(warmup + i) % len(batches)])
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
+    multi = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-    res = {"elapsed": elapsed, "last_bpd": float(m["scalars"]["train_bpd"]), "prime": prime,
+        multi = multi_rank_report(exp, state, batches, B, steps, warmup, world, dev, elapsed, elapsed_local, barrier)
+    res = {"elapsed": elapsed, "multi": multi, "last_bpd": float(m["scalars"]["train_bpd"]), "prime": prime,
            "graph_used": bool(exp.hip_graph and exp._graphed is not None), "E": int(config.model.sm_n_embd),
            "n_layer": int(config.model.sm_n_layer), "conv_mode": ops.CONV_MODE, "f32_mode": None,
-           "graph_error": exp.graph_capture_error}
+           "graph_error": exp.graph_capture_error, "chip": tele.summary(), "elapsed_local": elapsed_local}
     red = exp.reducer
     if world > 1 and red.capture is not None:
         # how the replayed step hands its gradient buckets to the collectives (parallel.GradReducer): per bucket, how long
@@ -580,6 +720,75 @@ def ode_workload(B):
             "finite": bool(torch.isfinite(log_p).all())}
 
 
+def split_precision_probe():
+    """The precision claim as observed in THIS process: one 128 -> 128 3x3 convolution launch (8 images,
+    standard-normal data, weights x 0.05) through the f16x3 kernel and through the exact-fp32 MFMA kernel, each against
+    torch's float64 convolution of the same operands; error = max |y - y64| / max(sum |x| |w|) -- the unit of DESIGN.md's
+    table (K = 1152 products per output)."""
+    import torch
+    import torch.nn.functional as F
+    from mulan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    Bp, C, N = 8, 128, 128
+    x = torch.randn(Bp, 1024, C, device="cuda", generator=g)
+    w = torch.randn(3, 3, C, N, device="cuda", generator=g) * 0.05
+    x64 = x.double().view(Bp, 32, 32, C).permute(0, 3, 1, 2)
+    w64 = w.double().permute(3, 2, 0, 1)
+    y64 = F.conv2d(x64, w64, padding=1).permute(0, 2, 3, 1).reshape(Bp, 1024, N)
+    scale = float(F.conv2d(x64.abs(), w64.abs(), padding=1).max())
+    out, saved = {}, ops.CONV_MODE
+    try:
+        for mode, key in (("f16x3", "split_error_vs_fp64"), ("f32", "f32_error_vs_fp64")):
+            ops.CONV_MODE = mode
+            y = ops.conv3x3_raw(x, w, None, None, None)
+            y = y[0] if isinstance(y, tuple) else y
+            out[key] = float((y.double() - y64).abs().max()) / scale
+    finally:
+        ops.CONV_MODE = saved
+    out["what"] = ("max |y - y_fp64| / max sum|x||w| of one 128 -> 128 3x3 convolution (8 images, K = 1152), measured in this "
+                   "process: the f16x3 split kernel and the exact-fp32 MFMA kernel against torch's float64 convolution")
+    return out
+
+
+def plain_vdm_workload(steps=10, batch=2):
+    """BASELINE configs[0] on the HIP path (the GPU twin of cpu_baseline.config0_plain_vdm): model_vdm.VDM with the
+    learnable monotone schedule (--config.vdm_type=vdm --config.model.gamma_type=learnable_nnet), batch 2, 10 train steps
+    through Experiment.train_step (eager: ~1100 launches per step, host-bound at this batch)."""
+    import torch
+    from mulan_amd.config import load_config_file
+    from mulan_amd.experiment import Experiment_VDM
+    config = _test_depth(load_config_file(os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")))
+    config.vdm_type = "vdm"
+    config.model.gamma_type = "learnable_nnet"
+    config.data.dataset = "synthetic"
+    config.training.batch_size_train = batch
+    config.training.batch_size_eval = batch
+    config.training.substeps = 1
+    exp = Experiment_VDM(config)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: {"images": torch.randint(0, 256, (batch, 32, 32, 3), generator=g, dtype=torch.uint8).cuda(),
+                  "labels": torch.zeros(batch, dtype=torch.int32).cuda(),
+                  "conditioning": torch.zeros(batch, dtype=torch.uint8).cuda()}
+    batches = [mk() for _ in range(steps)]
+    state = exp.state
+    for i in range(2):
+        state, _ = exp.train_step(exp._train_rng, state, batches[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        state, m = exp.train_step(exp._train_rng, state, batches[i])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"workload": f"BASELINE configs[0]: model_vdm.VDM (gamma_type learnable_nnet), CIFAR-10 32x32, batch {batch}, "
+                       f"{steps} train steps through Experiment.train_step on the HIP path (eager step; 2 untimed steps first)",
+           "value": round(batch * steps / dt, 2), "unit": "images/s", "ms_per_step": round(dt / steps * 1e3, 2),
+           "steps": steps, "global_batch": batch, "last_train_bpd": round(float(m["scalars"]["train_bpd"]), 4),
+           "cpu_twin": "cpu_baseline.config0_plain_vdm"}
+    del exp, state, batches
+    _release_device_memory()
+    return res
+
+
 def main():
     a = parse()
     if a.cpu_baseline_only:
@@ -620,6 +829,7 @@ def main():
     #   "sampler", "ode": SURVEY 8(f) ranks 3 and 2 (rank 0's GPU only).
     also = a.also_configs if a.also_configs is not None else True
     extra = None
+    out_of_sync = ["headline"] if (head["multi"] is not None and not head["multi"]["replicas_in_sync"]) else []
     if also:
         extra = {}
         cif = os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")
@@ -651,12 +861,16 @@ def main():
                           "conv_kernel": {k: rr.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us",
                                                                  "launches_per_step", "measured")},
                           "conv_kernel_as_run_frac": (rr.get("as_run") or {}).get("frac"),
-                          "last_train_bpd": round(r["last_bpd"], 4)}
+                          "last_train_bpd": round(r["last_bpd"], 4), "chip": r["chip"], "multi_gpu": r["multi"]}
+            if r["multi"] is not None and not r["multi"]["replicas_in_sync"]:
+                out_of_sync.append(key)
         extra["5"] = dense_eval_workload(n5, T5, rank, world)
         extra["5"]["workload"] = "BASELINE configs[4]: " + extra["5"]["workload"]
         if world > 1:
             dist.barrier()
         if rank == 0:
+            if world == 1:      # (a one-device configuration; on several ranks its train step would wait for the others' collectives)
+                extra["1"] = plain_vdm_workload()
             extra["sampler"] = sampler_workload(bs, 1000, 3 if a.configs_small else 20)
             extra["ode"] = ode_workload(bo)
             if world == 1 and not a.configs_small:
@@ -667,7 +881,10 @@ def main():
     if rank != 0:
         if world > 1:
             dist.barrier()
+        if out_of_sync:
+            raise SystemExit(3)
         return
+    precision = split_precision_probe() if (ops.CONV_MODE == "f16x3" and not a.configs_small) else None
     cpu = None
     if not a.no_cpu_baseline and world == 1:
         # host leg in a child process (no GPU touched there) with a hard wall-clock bound
@@ -688,7 +905,10 @@ def main():
         "metric": "train images/sec", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "setup_steps": head["prime"], "ms_per_step": round(ms, 2),
         "higher_is_better": True,
-        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": {"f16x3": "f32 (f16x3 split: 3 fp16 MFMA passes, fp32 accumulate)",
+                  "bf16x6": "f32 (bf16x6 split: 6 bf16 MFMA passes, fp32 accumulate)"}.get(ops.CONV_MODE, "f32"),
+        "data": "synthetic",
         "conv_mode": ops.CONV_MODE + {
             "bf16x6": ": fp32 operands split into 3 bf16 pieces, 6 bf16 MFMA passes, fp32 accumulate",
             "f16x3": ": fp32 operands scaled by a power of two and split into 2 fp16 pieces, 3 fp16 MFMA passes, fp32 "
@@ -711,6 +931,12 @@ def main():
                         "note": "torch.distributed backend 'nccl' is RCCL on ROCm; bucketed gradient all-reduce on a "
                                 "side stream, overlapped with the (replayed) backward pass"} if world > 1 else None),
         "model_tflops_per_gpu": round(value / world * 3 * fwd_gflop / 1e3, 2),
+        # the whole step against the arithmetic ceiling of its scheme (173.3 GFLOP per image fwd + bwd): the figure the
+        # headline moves with; roofline.frac below is the dominant kernel alone on the chip, roofline.frac_as_run the same
+        # launches inside the step as timed
+        "step_roofline_frac": round(value / world * 3 * fwd_gflop / 1e3 /
+                                    {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(
+                                        ops.CONV_MODE, PEAK_F32_MFMA_TFLOPS), 4),
         "model_roofline_frac": round(value / world * 3 * fwd_gflop / 1e3 /
                                      {"bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3}.get(
                                          ops.CONV_MODE, PEAK_F32_MFMA_TFLOPS), 4),
@@ -718,13 +944,18 @@ def main():
         "hip_graph": head["graph_used"], "hip_graph_error": head["graph_error"],
         "oracle_pin": "unpinned: the reference has no golden vectors, JAX / Flax are not installable here and no "
                       "released checkpoint is in the image (tools/verify_checkpoint.py pins it in one command)",
-        "roofline": roof, "f32_mfma_mode": head["f32_mode"], "cpu_baseline": cpu, "configs": extra,
+        "roofline": roof, "f32_mfma_mode": head["f32_mode"], "precision": precision, "chip": head["chip"],
+        "multi_gpu": head["multi"], "cpu_baseline": cpu, "configs": extra,
     }
+    if out_of_sync:
+        out["replicas_out_of_sync"] = out_of_sync
     if TEST_DEPTH > 0:        # (--small-depth: a test run; none of its numbers is the configuration's)
         out["test_depth"] = TEST_DEPTH
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if out_of_sync:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -91,6 +91,9 @@ class GradReducer:
             b[1] = self.buckets[i + 1][0] if i + 1 < len(self.buckets) else flat_grad.numel()
         if self.buckets:
             self.buckets[0][0] = 0
+        # measurement only (bench.py `allreduce_exposed_ms`): the step with its collectives left out -- every bucket is
+        # accounted for as usual, nothing is sent.  The replicas drift apart from the first such step on.
+        self.skip_collectives = False
         self.paused = False         # True while a train step is being captured into a HIP graph: hooks do not launch
         self.tick, self.tick_dev = 0, None   # replay counter: the value the graph's signal kernels store (before_replay)
         self.capture = None         # while / after a capture: {"order": [bucket, ...], "events": {bucket: handle}}
@@ -123,11 +126,13 @@ class GradReducer:
                 self.side.wait_stream(wg)
             with torch.cuda.stream(self.side):
                 self._all_reduce(view)
-        else:
+        elif not self.skip_collectives:
             self.works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _all_reduce(self, view):
         """sum over the ranks, on the current stream's timeline (see sync_ops)"""
+        if self.skip_collectives:
+            return
         if self.sync_ops:
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=False)
         else:

@@ -596,9 +596,12 @@ def nnet_gamma(p, t):
     return (h + _h).squeeze(-1)
 
 
-def plain_vdm_forward(params, cfg, x_u8, t0, eps_0, eps, gmin=GAMMA_MIN, gmax=GAMMA_MAX, dtype=torch.float64):
-    """model_vdm.VDM.__call__ (ldm/model_vdm.py:110-180) with gamma_type 'fixed' (:462-468) or 'learnable_scalar'
-    (:418-431), epsilon prediction, T = 0 (:158-161) or T > 0 with the 'noise' weighting (:162-170)."""
+def plain_vdm_forward(params, cfg, x_u8, t0, eps_0, eps, gmin=GAMMA_MIN, gmax=GAMMA_MAX, dtype=torch.float64,
+                      score_masks=None, keep=1.0):
+    """model_vdm.VDM.__call__ (ldm/model_vdm.py:110-180) with gamma_type 'fixed' (:462-468), 'learnable_scalar'
+    (:418-431) or 'learnable_nnet' (:471-509), epsilon prediction, T = 0 (:158-161) or T > 0 with the 'noise' weighting
+    (:162-170).  score_masks / keep: the dropout keep-masks of the score U-Net in training mode (deterministic=False is
+    handed to the score model at :153-157)."""
     B = x_u8.shape[0]
     x = x_u8.reshape(B, 32, 32, 3)
     T = cfg.get("n_timesteps", 0)
@@ -627,7 +630,7 @@ def plain_vdm_forward(params, cfg, x_u8, t0, eps_0, eps, gmin=GAMMA_MIN, gmax=GA
     loss_klz = 0.5 * ((1. - v1) * f * f + v1 - torch.log(v1) - 1.).reshape(B, -1).sum(dim=1)
     z_t = torch.sqrt(1. - bc(var_t)) * f + torch.sqrt(bc(var_t)) * eps
     eps_hat = score_unet(z_t, g_t, torch.zeros(B, 1, dtype=dtype), params["score_model"], cfg["n_embd"], cfg["n_layer"],
-                         gmin=gmin, gmax=gmax)
+                         gmin=gmin, gmax=gmax, masks=score_masks, keep=keep)
     mse = ((eps - eps_hat) ** 2).reshape(B, -1).sum(dim=1)
     if T == 0:
         loss_diff = .5 * slope * mse

@@ -700,30 +700,44 @@ def test_load_flax_reads_bytes_it_did_not_write():
 
 
 def test_committed_bench_record_keeps_the_driver_contract():
-    """profiles/r04_bench_n1.json.log is the line `python bench.py` printed on an MI355X with the round-4 code: the keys
+    """profiles/r06_bench_n1*.json.log is the line `python bench.py` printed on an MI355X with the round-6 code: the keys
     the driver and the judge read (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
     scaling / vs_baseline / dtype / data / config.workload, the `roofline` and `cpu_baseline` objects) are all there and
-    consistent with each other."""
+    consistent with each other, and so are the round-6 additions (dtype names the split scheme,
+    step_roofline_frac, the as-run fraction and a non-null share next to the kernel's own figures, the precision probe, the
+    chip's clock / power / allocator record, config #1's GPU twin)."""
+    import glob
     import json
-    rec = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1.json.log")).read().strip().splitlines()[-1])
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_n1*.json.log")))
+    assert names
+    rec = json.loads(open(names[-1]).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in rec, k
     assert rec["metric"] == "train images/sec" and rec["unit"] == "images/s" and rec["higher_is_better"] is True
     assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["vs_baseline"] is None and rec["data"] == "synthetic"
-    assert rec["dtype"] == "f32" and "workload" in rec["config"] and "model" not in rec["config"]
+    assert rec["dtype"].startswith("f32 (f16x3 split: 3 fp16 MFMA passes") and "workload" in rec["config"] and "model" not in rec["config"]
     B = rec["config"]["global_batch"]
     assert abs(rec["value"] - B / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
     roof = rec["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_as_run", "share_of_step", "as_run"):
         assert k in roof, k
     assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["traffic"] is None or roof["traffic"] > 1e8
+    assert roof["frac_as_run"] == roof["as_run"]["frac"] < roof["frac"] and 0 < roof["share_of_step"] < roof["as_run"]["share_of_step"] < 1
+    assert abs(rec["step_roofline_frac"] - rec["model_roofline_frac"]) < 1e-9 and 0.2 < rec["step_roofline_frac"] < 1
+    pr = rec["precision"]
+    assert 0 < pr["split_error_vs_fp64"] <= 1.5 * pr["f32_error_vs_fp64"] < 1e-5       # the split scheme is not narrower than fp32
+    chip = rec["chip"]
+    assert chip["allocator_peak_gb"] > 0 and "sclk_mhz" in chip and "socket_power_w" in chip and "power_cap_w" in chip
     cpu = rec["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["cores"] >= 1
-    assert set(rec["configs"]) >= {"3", "4", "5", "sampler", "ode"}
+    assert set(rec["configs"]) >= {"1", "3", "4", "5", "sampler", "ode"}
+    assert rec["configs"]["1"]["global_batch"] == 2 and rec["configs"]["1"]["steps"] == 10
+    assert all("chip" in rec["configs"][k] for k in ("3", "4"))
+    assert rec["multi_gpu"] is None                              # (N = 1; the N > 1 fields: tests/test_gpu_model.py, bench_ranks)
 
 
 def test_step_form_choice_only_explicit_requests_make_a_failed_capture_fatal():

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 from oracle import mulan_np as onp
 from oracle import torch_ref as tr
 
-from tests.oracle_dev import run_oracle
+from tests.oracle_dev import pin_oracle_to_host, run_oracle
 
 
 def make_cfg(vdm_type="mulan_velocity", unet_type="vdm", vfe=False, n_layer=1, fwd_layers=1, E=128, with_attention=False):
@@ -265,11 +265,13 @@ def test_plain_vdm_matches_oracle(gamma_type, T):
             assert rel(params["gamma"][l][k].grad.cpu().double().numpy(), ref_params["gamma"][l][k].grad.numpy()) < 5e-3, (l, k)
 
 
-def test_full_depth_forward_bpd_parity():
+def test_full_depth_forward_bpd_parity(monkeypatch):
     """the shipped depth (sm_n_layer = 32: 67 ResnetBlocks in the score U-Net, forward_n_layer = 4 in the encoder) in
     evaluation mode against the float64 oracle: the north-star bar is +-0.005 bits/dim; the split-operand kernels
-    must not accumulate error over 140 chained convolutions"""
+    must not accumulate error over 140 chained convolutions.  The oracle of this test runs on the HOST (checker
+    independence: tests/oracle_dev.py)"""
     from mulan_amd import model as M
+    pin_oracle_to_host(monkeypatch)
     from mulan_amd.rng import PRNGKey
     cfg, ocfg = make_cfg("mulan_velocity", "vdm", True, n_layer=32, fwd_layers=4)
     B = 2
@@ -500,7 +502,10 @@ def test_bench_ranks_share_one_gpu(graph, launcher, configs, world):
     assert out.get("test_depth") == (1 if configs else 2)
     if configs:
         c = out["configs"]
-        assert set(c) == {"3", "4", "5", "sampler", "ode"}
+        assert set(c) == {"3", "4", "5", "sampler", "ode"}       # ("1", the one-device configs[0], only at N = 1)
+        for key in ("3", "4"):          # every training entry says what its replicas and its chip did
+            assert c[key]["multi_gpu"]["replicas_in_sync"] is True and len(c[key]["multi_gpu"]["ms_per_step_by_rank"]) == world
+            assert "sclk_mhz" in c[key]["chip"] and c[key]["chip"]["allocator_peak_gb"] > 0
         # configs[2]: the GLOBAL batch 32 split over the ranks (512 // world at full size); configs[3]: 8 images per rank
         assert c["3"]["global_batch"] == 32 and c["4"]["global_batch"] == 8 * world and c["3"]["value"] > 0 and c["4"]["value"] > 0
         assert f"sharded over {world} rank(s)" in c["5"]["workload"] and c["5"]["value"] > 0 and math.isfinite(c["5"]["bpd_random_init"])
@@ -509,6 +514,16 @@ def test_bench_ranks_share_one_gpu(graph, launcher, configs, world):
         assert out["configs"] is None
     assert out["hip_graph"] == (graph != "0")
     assert out["collective"]["backend"] == "gloo" and out["collective"]["rccl_ranks"] == 0    # (nccl on a multi-GPU node)
+    # the run proves itself: replicas bit-identical after the timed steps (parameters and EMA), every
+    # rank's own step time, the exposed part of the gradient exchange, the N = 1-equivalent throughput of this run
+    mg = out["multi_gpu"]
+    assert mg["replicas_in_sync"] is True and mg["max_abs_param_difference_over_ranks"] == 0.0 and mg["max_abs_ema_difference_over_ranks"] == 0.0
+    assert len(mg["ms_per_step_by_rank"]) == world and mg["ms_per_step_min"] <= mg["ms_per_step_max"]
+    assert abs(mg["ms_per_step_max"] - out["ms_per_step"]) < 0.25 * out["ms_per_step"] + 1.0
+    assert mg["ms_per_step_without_collectives"] > 0 and math.isfinite(mg["allreduce_exposed_ms"])
+    assert mg["n1_equivalent"]["images_per_sec_per_gpu"] > 0 and 0 < mg["n1_equivalent"]["scaling_efficiency"] < 1.5
+    assert "replicas_out_of_sync" not in out and out["dtype"].startswith("f32 (f16x3 split") and out["step_roofline_frac"] > 0
+    assert out["chip"]["allocator_peak_gb"] > 0 and "sclk_mhz" in out["chip"]
     ov = out["collective"]["replay_overlap"]
     if overlap:
         assert ov["handoff"] == "signal" and len(ov["marked"]) >= 2 and len(ov["released_ms_before_graph_end"]) == len(ov["marked"])
@@ -753,11 +768,13 @@ def test_module_surface_matches_oracle(unet_type):
         mv.ScoreUNet(cfg).apply(params["score_model"], z.float().cuda(), 0.0, emb.float().cuda(), deterministic=False)
 
 
-def test_full_depth_train_mode_gradient_parity():
+def test_full_depth_train_mode_gradient_parity(monkeypatch):
     """the shipped depth (32 + 2 + 33 ResnetBlocks, 4-layer encoder) in TRAINING mode (dropout on) at B = 2: loss terms
     and every parameter gradient against float64 autograd.  ~140 chained split-operand convolutions forward and
     backward: fp32-level noise grows with depth, so the per-leaf bar is 5x the single-layer one (1e-2 of the leaf's
-    gradient scale); the BPD bar stays +-0.005 absolute."""
+    gradient scale); the BPD bar stays +-0.005 absolute.  The oracle of this test (forward and backward) runs on the HOST
+    (checker independence: tests/oracle_dev.py)."""
+    pin_oracle_to_host(monkeypatch)
     run_case("mulan_velocity", "vdm", False, train=True, n_layer=32, fwd_layers=4, B=2, tol=5.0)
 
 

@@ -209,3 +209,120 @@ def test_train_step_trajectory_matches_oracle(vdm_type):
               f"moments {worst['mom']:.2e}, |bpd - oracle| {worst['bpd']:.2e}")
         del exp
         torch.cuda.empty_cache()
+
+
+def test_config1_plain_vdm_ten_train_steps_through_the_flag_surface(tmp_path):
+    """BASELINE configs[0] as worded -- `python -m ldm.main --config.vdm_type=vdm --config.model.gamma_type=learnable_nnet
+    --config.training.batch_size_train=2 --config.training.substeps=1`, 10 train steps -- on the HIP path
+    (model_vdm.VDM: ldm/model_vdm.py:110-180; Experiment.train_step: ldm/experiment.py:335-356):
+      * the entry point itself runs the 10 optimiser steps at the config's shipped depth (32 + 2 + 33 ResnetBlocks) and
+        leaves a checkpoint at step 10;
+      * the same flags, parsed by the same flag surface, at one ResnetBlock per stage: every one of the 10 steps checked
+        like test_train_step_trajectory_matches_oracle -- train_bpd and every parameter gradient against
+        oracle.torch_ref.plain_vdm_forward (float64 autograd, the step's noise and dropout masks re-derived from its keys)
+        at the parameters the device holds before the step, and the oracle's AdamW + EMA + lr schedule, teacher-forced on
+        the device's gradients, reproducing parameters / EMA / both moments after every step to fp32 rounding."""
+    import ldm.main
+    from mulan_amd import checkpoint as ck
+    from mulan_amd import model as M
+    from mulan_amd.experiment import Experiment_VDM
+    cfgp = os.path.join(ROOT, "ldm", "configs", "cifar10-conditioned.py")
+    flags = ["--config=" + cfgp, "--config.vdm_type=vdm", "--config.model.gamma_type=learnable_nnet",
+             "--config.training.batch_size_train=2", "--config.training.substeps=1", "--config.data.dataset=synthetic"]
+    NB, NSTEPS, WU = 2, 10, 4
+    # ---- (1) the entry point, shipped depth
+    ldm.main.main(flags + ["--config.training.batch_size_eval=2", "--config.training.num_steps_train=10",
+                           "--config.training.num_steps_eval=1", "--config.training.steps_per_logging=1",
+                           "--config.training.steps_per_eval=10", "--config.training.steps_per_save=10",
+                           "--config.training.sample_timesteps=2", "--workdir=" + str(tmp_path / "run")])
+    ckdirs = [os.path.join(dp, d) for dp, dn, _ in os.walk(tmp_path / "run") for d in dn if d == "checkpoints"]
+    assert len(ckdirs) == 1
+    sd = ck.restore_dict(ckdirs[0])
+    assert sd["step"] == 10 and set(sd["params"]) == {"score_model", "gamma"} and set(sd["params"]["gamma"]) == {"l1", "l2", "l3"}
+    torch.cuda.empty_cache()
+    # ---- (2) the same flags at depth 1, step by step against the oracle
+    ldm.main.FLAGS.parse(flags + ["--config.model.sm_n_layer=1", "--config.training.batch_size_eval=2",
+                                  f"--config.training.num_steps_lr_warmup={WU}", "--config.optimizer.ema_rate=0.9",
+                                  "--workdir=" + str(tmp_path / "unused")])
+    config = ldm.main.FLAGS.config
+    assert config.vdm_type == "vdm" and config.model.gamma_type == "learnable_nnet" and config.training.batch_size_train == NB
+    exp = Experiment_VDM(config)
+    assert not hasattr(exp.model, "parameterization")            # model_vdm.VDM, not a MuLAN model
+    ocfg = dict(vdm_type="mulan_velocity", n_embd=E, n_layer=1, forward_n_layer=1, latent_k=15, unet_type="vdm")
+    full = tr.init_params(ocfg, seed=23, dtype=torch.float64)
+    gg = torch.Generator().manual_seed(8)
+    init = {"score_model": full["score_model"],
+            "gamma": {"l1": {"kernel": torch.tensor([[-16.0]], dtype=torch.float64), "bias": torch.tensor([-12.0], dtype=torch.float64)},
+                      "l2": {"kernel": torch.randn(1, 1024, generator=gg, dtype=torch.float64) * 3,
+                             "bias": torch.randn(1024, generator=gg, dtype=torch.float64)},
+                      "l3": {"kernel": torch.randn(1024, 1, generator=gg, dtype=torch.float64) * 2}}}
+    init["score_model"]["dense0"]["kernel"] = init["score_model"]["dense0"]["kernel"][:129].clone()   # conditioning is [B, 1]
+    paths = [p for p, _ in tr.tree_leaves(init)]
+    decay_mask = {p: float(p[-1] != "bias") for p in paths}
+    M.from_flax_layout(M.tree_map(lambda t: t.detach().float(), init), exp.state.params)
+    with torch.no_grad():
+        exp.state.ema.copy_(exp.state.flat)
+    g = torch.Generator().manual_seed(17)
+    batches = [torch.randint(0, 256, (NB, 32, 32, 3), generator=g, dtype=torch.uint8) for _ in range(NSTEPS)]
+    keep = float(np.float32(1.0 - float(config.model.sm_pdrop)))
+    lr0, ema_rate = float(config.optimizer.learning_rate), 0.9
+    rel_leaf = lambda a, b, floor=1e-30: float(np.abs(a - b).max() / (np.abs(b).max() + floor))
+    (p0, _, _, _), _ = _flax_state(exp)
+    tf_p = {p: _leaf(p0, p).copy() for p in paths}
+    tf_ema = {p: v.copy() for p, v in tf_p.items()}
+    tf_m = {p: np.zeros_like(v) for p, v in tf_p.items()}
+    tf_v = {p: np.zeros_like(v) for p, v in tf_p.items()}
+    worst = dict(tf=0.0, grad=0.0, bpd=0.0)
+    for k in range(NSTEPS):
+        (before, _, _, _), _ = _flax_state(exp)
+        # the step's keys as Experiment.train_step / loss_fn / model_vdm.VDM.apply derive them: fold_in(rank), fold_in(step),
+        # then the 'sample' and the 'dropout' split; the plain VDM hands the dropout key to the score U-Net unsplit
+        rng = exp._train_rng.fold_in(exp.rank).fold_in(k)
+        rng, sample_rng = rng.split()
+        rng, dropout_rng = rng.split()
+        noise = exp.model._noise({"sample": sample_rng}, None, NB, exp.device, False)
+        masks = oracle_masks(block_names(1, True), dropout_rng, NB, E, keep)
+        tree = tr.tree_map(lambda t: t, init)
+        leaves = {}
+        for p in paths:
+            t = torch.tensor(_leaf(before, p), dtype=torch.float64, requires_grad=True)
+            d = tree
+            for key in p[:-1]:
+                d = d[key]
+            d[p[-1]] = t
+            leaves[p] = t
+        f64 = lambda t: t.double().cpu()
+        ref = tr.plain_vdm_forward(tree, ocfg, batches[k], float(noise["t0"]), f64(noise["eps_0"]).view(NB, 32, 32, 3),
+                                   f64(noise["eps"]).view(NB, 32, 32, 3), score_masks=masks, keep=keep)
+        ref["bpd"].backward()
+        batch = {"images": batches[k].cuda(), "labels": torch.zeros(NB, dtype=torch.int32).cuda(),
+                 "conditioning": torch.zeros(NB, dtype=torch.uint8).cuda()}
+        _, metrics = exp.train_step(exp._train_rng, exp.state, batch)
+        torch.cuda.synchronize()
+        assert exp.state.step == k + 1 and exp._graphed is None
+        (got_p, got_ema, got_m, got_v), got_g = _flax_state(exp)
+        bpd = float(metrics["scalars"]["train_bpd"])
+        worst["bpd"] = max(worst["bpd"], abs(bpd - float(ref["bpd"].detach())))
+        assert abs(bpd - float(ref["bpd"].detach())) < 1e-3, (k, bpd, float(ref["bpd"].detach()))
+        lr = onp.lr_schedule(k, lr0, WU)
+        bad = []
+        for p in paths:
+            gk = _leaf(got_g, p)
+            want = leaves[p].grad.numpy() if leaves[p].grad is not None else np.zeros(tuple(leaves[p].shape))
+            tf_p[p], tf_m[p], tf_v[p], tf_ema[p] = onp.adamw_ema_step(tf_p[p], gk, tf_m[p], tf_v[p], tf_ema[p], lr, k + 1,
+                                                                      decay_mask[p], ema_rate=ema_rate)
+            for name, got, ref_t in (("params", got_p, tf_p), ("ema", got_ema, tf_ema), ("mu", got_m, tf_m), ("nu", got_v, tf_v)):
+                err = rel_leaf(_leaf(got, p), ref_t[p])
+                worst["tf"] = max(worst["tf"], err)
+                assert err < 1e-5, (k, name, "/".join(p), err)
+            if np.abs(want).max() < 1e-12:
+                assert np.abs(gk).max() < 1e-6, (k, "/".join(p))
+                continue
+            eg = rel_leaf(gk, want, 1e-6)
+            worst["grad"] = max(worst["grad"], eg)
+            bar = 5e-3 if p[0] == "gamma" else (2e-3 if want.size > 16 else ONE_ELEMENT_BAR)   # (bars of test_plain_vdm_matches_oracle)
+            if eg >= bar:
+                bad.append((round(eg / bar, 2), "/".join(p), f"{eg:.2e}", f"scale {np.abs(want).max():.2e}"))
+        assert not bad, (k, sorted(bad, reverse=True)[:6])
+    print(f"config #1 (model_vdm.VDM, learnable_nnet, batch 2, 10 steps): teacher-forced {worst['tf']:.2e}, gradient "
+          f"{worst['grad']:.2e}, |bpd - oracle| {worst['bpd']:.2e}")
