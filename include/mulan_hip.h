@@ -188,6 +188,28 @@ size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, in
 int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
                                      float* dw, float* workspace, int B, int H, int W, int C, int N, int accumulate,
                                      int share_chip, mulan_stream_t stream);
+/* Slab reductions folded into the next weight-gradient launch (round 6).  The plane-fed weight gradient splits the
+ * pixels over S blocks per output tile and sums their partial results ("slabs", workspace [S][9][C][N]) in a launch of
+ * its own.  In the backward pass of a train step the weight gradients follow one another on one stream, so
+ * mulan_conv3x3_wgrad_f16x3_planes_fold writes its slabs WITHOUT summing them and instead sums the slabs of up to two
+ * EARLIER launches (`pending`, host array; complete by stream order) in the prologue of its blocks, in slab order -- the
+ * very bits of the separate reduction -- while their first operand loads are in flight.  The caller keeps the record
+ * {workspace, dw, S = _splits(...), E = 9 C N, accumulate} of each _fold launch and hands it to a later _fold launch
+ * or, for the last ones of a pass, to mulan_slab_reduce.  (autodiff of ldm/model_vdm.py:633-650 under
+ * ldm/experiment.py:339; same arguments otherwise as mulan_conv3x3_wgrad_f16x3_planes) */
+typedef struct mulan_slab_reduction {
+  const float* slab;   /* [S][E] partial results */
+  float* out;          /* [E]; 16-byte aligned like slab */
+  int S, E;            /* E % 4 == 0 */
+  int accumulate;      /* out += sum instead of out = sum */
+  int reserved;
+} mulan_slab_reduction;
+int mulan_conv3x3_wgrad_f16x3_planes_splits(int B, int H, int W, int C, int N, int share_chip);
+int mulan_conv3x3_wgrad_f16x3_planes_fold(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax,
+                                          float* workspace, int B, int H, int W, int C, int N, int share_chip,
+                                          const mulan_slab_reduction* pending, int n_pending, mulan_stream_t stream);
+int mulan_slab_reduce(const float* slab, float* out, int S, int E, int accumulate, mulan_stream_t stream);
+
 
 /* Once-per-step weight preparation for all eligible parameter leaves of the flat parameter buffer in two launches
  * (instead of maxima + pack per layer and direction).  Leaf record = 8 x int64: element offset in `flat`, kind (0: 3x3

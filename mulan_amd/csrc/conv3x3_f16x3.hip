@@ -811,7 +811,39 @@ struct WgradArgsP {
   // and is split while it is staged; xmax holds the maxima of the concat (elementwise max of the two tensors' maxima)
   const float* x1f; const float* x2f; int C1;
   const unsigned* xmax2;                               // (XF32) maxima of x2: the concat's are the elementwise max of xmax, xmax2
+  // (w16 kernel, mulan_conv3x3_wgrad_f16x3_planes_fold) slab reductions of EARLIER launches that this launch's blocks
+  // perform in their prologue, while their first operand loads are in flight
+  mulan_slab_reduction pend[2];
+  int npend;
 };
+
+// out[e] (+)= sum over the S slabs, in slab order (the order -- and therefore the bits -- of slab_reduce_h_kernel), four
+// outputs per thread; gtid / gthreads: this thread's index in / the size of the whole launch.  Up to 16 loads in flight.
+__device__ __forceinline__ void fold_slab_reduction(const mulan_slab_reduction& r, int gtid, int gthreads) {
+  const int E4 = r.E >> 2;
+  for (int e = gtid; e < E4; e += gthreads) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(r.slab) + e;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 16 <= r.S; i += 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = src[(size_t)(i + u) * E4];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    for (; i + 4 <= r.S; i += 4) {
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = src[(size_t)(i + u) * E4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
+    for (; i < r.S; ++i) s += src[(size_t)i * E4];
+    f32x4* o = reinterpret_cast<f32x4*>(r.out) + e;
+    *o = r.accumulate ? *o + s : s;
+  }
+}
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -1543,6 +1575,11 @@ __global__ __launch_bounds__(W8_THREADS) void conv3x3_wgrad_f16x3_w16_kernel(Wgr
 #pragma unroll
     for (int i = 0; i < 4; ++i) gload_d1(i);
   }
+  // slab reductions handed over by earlier launches on this stream (their slabs are complete: stream order): a share of
+  // the outputs per block, behind the operand loads just issued -- a few microseconds of a prologue that waits for
+  // memory anyway, instead of a 576-block launch of its own behind every weight gradient (8.8 us alone, 15-55 us beside
+  // the main chain's kernels: profiles/r06_step_timeline.log)
+  for (int k = 0; k < p.npend; ++k) fold_slab_reduction(p.pend[k], blockIdx.x * W8_THREADS + tid, gridDim.x * W8_THREADS);
   __syncthreads();
   read_b(smem, 0, 0);
   read_a(smem, 0, 0, 0);
@@ -1940,6 +1977,64 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3(const float* x, const unsigned* xmax, co
   MULAN_CHECK_LAUNCH();
 }
 
+static int launch_wgrad_w16(const void* xs, const unsigned* xmax, const void* dys, const unsigned* dymax, float* workspace,
+                            int B, int H, int C, int N, int S8, const mulan_slab_reduction* pending, int n_pending,
+                            int abl, hipStream_t stream) {
+  static bool configured16 = false;
+  if (!configured16) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w16_kernel<0>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w16_kernel<3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
+    if (e != hipSuccess) return (int)e;
+    configured16 = true;
+  }
+  WgradArgsP a8{static_cast<const unsigned char*>(xs), static_cast<const unsigned char*>(dys), xmax, dymax, workspace,
+                B, H, C, N, S8, g_mulan_debug_buffer};
+  a8.npend = n_pending;
+  for (int k = 0; k < n_pending; ++k) a8.pend[k] = pending[k];
+  const dim3 grid8(3 * S8 * (C / WG3_T) * (N / WG3_T));
+  if (abl == 3)
+    hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w16_kernel<3>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
+  else
+    hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w16_kernel<0>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
+  return 0;
+}
+
+// ---- slab reductions folded into the NEXT weight-gradient launch (round 6).  In the backward pass of a train step the
+// 3x3 weight gradients follow one another on one stream; a launch made with _fold writes its slabs and does NOT sum
+// them: the caller hands the record {slab, out, S, E, accumulate} to a later _fold launch (up to two records per launch,
+// summed by its blocks' prologues in slab order: the bits of the separate reduction kernel) or to mulan_slab_reduce.
+MULAN_API int mulan_conv3x3_wgrad_f16x3_planes_splits(int B, int H, int W, int C, int N, int share_chip) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
+  return wgrad_splits_w8(B, H, C, N, share_chip);
+}
+
+MULAN_API int mulan_conv3x3_wgrad_f16x3_planes_fold(const void* xs, const unsigned* xmax, const void* dys,
+                                                    const unsigned* dymax, float* workspace, int B, int H, int W, int C,
+                                                    int N, int share_chip, const mulan_slab_reduction* pending,
+                                                    int n_pending, hipStream_t stream) {
+  if (W != kW || H % WG_ROWS != 0 || B <= 0 || C % WG3_T != 0 || N % WG3_T != 0 || !xs || !dys || !xmax || !dymax ||
+      !workspace || n_pending < 0 || n_pending > 2 || (n_pending > 0 && !pending) ||
+      (size_t)B * H * W * (C > N ? C : N) * 4 >= 0x80000000ull)
+    return (int)hipErrorInvalidValue;
+  for (int k = 0; k < n_pending; ++k)
+    if (!pending[k].slab || !pending[k].out || pending[k].S <= 0 || pending[k].E <= 0 || pending[k].E % 4 != 0 ||
+        (reinterpret_cast<uintptr_t>(pending[k].slab) | reinterpret_cast<uintptr_t>(pending[k].out)) % 16 != 0)
+      return (int)hipErrorInvalidValue;
+  const int rc = launch_wgrad_w16(xs, xmax, dys, dymax, workspace, B, H, C, N, wgrad_splits_w8(B, H, C, N, share_chip),
+                                  pending, n_pending, 0, stream);
+  if (rc != 0) return rc;
+  MULAN_CHECK_LAUNCH();
+}
+
+MULAN_API int mulan_slab_reduce(const float* slab, float* out, int S, int E, int accumulate, hipStream_t stream) {
+  if (!slab || !out || S <= 0 || E <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(slab_reduce_h_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, slab, out, S, E, accumulate);
+  MULAN_CHECK_LAUNCH();
+}
+
 MULAN_API size_t mulan_conv3x3_wgrad_f16x3_planes_workspace(int B, int H, int W, int C, int N, int share_chip) {
   if (W != kW || H % WG_ROWS != 0 || C % WG3_T != 0 || N % WG3_T != 0) return 0;
   const int Sw = wgrad_splits_w8(B, H, C, N, share_chip), Sp = wgrad_splits_p(B, H, C, N, share_chip);
@@ -1984,20 +2079,8 @@ MULAN_API int mulan_conv3x3_wgrad_f16x3_planes(const void* xs, const unsigned* x
     hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w8_kernel<V>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);      \
     break;
     if (g_mulan_tune[29] == 0) {      // 16x16x32 block (shipped)
-      static bool configured16 = false;
-      if (!configured16) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w16_kernel<0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
-        if (e == hipSuccess)
-          e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_f16x3_w16_kernel<3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, WG3_SMEM + 64);
-        if (e != hipSuccess) return (int)e;
-        configured16 = true;
-      }
-      if (g_mulan_tune[7] == 3)
-        hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w16_kernel<3>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
-      else
-        hipLaunchKernelGGL(conv3x3_wgrad_f16x3_w16_kernel<0>, grid8, dim3(W8_THREADS), WG3_SMEM + 64, stream, a8);
+      const int rc = launch_wgrad_w16(xs, xmax, dys, dymax, workspace, B, H, C, N, S8, nullptr, 0, g_mulan_tune[7], stream);
+      if (rc != 0) return rc;
     } else
     switch (g_mulan_tune[7]) {   // tune[29] = 2: the 32x32x16 eight-wave block; dev: timing probes (wrong numbers)
       MULAN_W8_ABL(2) MULAN_W8_ABL(3) MULAN_W8_ABL(16) MULAN_W8_ABL(19)

@@ -15,6 +15,12 @@ if os.environ.get("MULAN_HIP_LIB"):        # dev A/B builds (python -m mulan_amd
 
 P, I, F, Z, U, LL, D = c_void_p, c_int, c_float, c_size_t, c_ulonglong, c_longlong, c_double
 
+
+class SlabReduction(ctypes.Structure):
+    """mulan_slab_reduction of include/mulan_hip.h: one pending slab reduction {slab, out, S, E, accumulate}"""
+    _fields_ = [("slab", c_void_p), ("out", c_void_p), ("S", c_int), ("E", c_int), ("accumulate", c_int), ("reserved", c_int)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/mulan_hip.h
 SIGNATURES = {
     "mulan_conv3x3_fwd": [P, P, P, P, I, P, P, I, I, I, I, I, P],
@@ -36,6 +42,9 @@ SIGNATURES = {
     "mulan_conv3x3_planes_bytes": [I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3_planes_workspace": [I, I, I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3_planes": [P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "mulan_conv3x3_wgrad_f16x3_planes_splits": [I, I, I, I, I, I],
+    "mulan_conv3x3_wgrad_f16x3_planes_fold": [P, P, P, P, P, I, I, I, I, I, I, P, I, P],
+    "mulan_slab_reduce": [P, P, I, I, I, P],
     "mulan_conv3x3_wgrad_f16x3_workspace": [I, I, I, I, I],
     "mulan_conv3x3_wgrad_f16x3": [P, P, P, P, P, P, I, I, I, I, I, I, P],
     "mulan_param_maxima": [P, P, I, P, P],

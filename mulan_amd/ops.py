@@ -4,6 +4,7 @@ Each Function's forward and backward are launches of hand-written HIP kernels th
 `mulan_amd.lib`; torch supplies device buffers, the current stream and the autograd tape only.
 Shapes: images are [B, 1024, C] (NHWC with H = W = 32 flattened), matrices row-major, all fp32.
 """
+import ctypes
 import math
 import weakref
 
@@ -79,8 +80,10 @@ class weight_gradient_stream:
         return self
 
     def __exit__(self, *exc):
+        flush_slab_reductions()          # (while the side stream is still the place where weight gradients run)
         _SIDE["active"] = False
         _SIDE["scope"] = False
+        _SLAB_KEEP.clear()
         side_join()
         return False
 
@@ -119,6 +122,9 @@ def _on_side(launch, keep):
         launch()
         done = torch.cuda.Event()
         done.record(side)
+    if _SLAB_KEEP:                   # (slab sets of earlier launches that this one summed: alive until it has run)
+        keep = (keep, tuple(_SLAB_KEEP))
+        _SLAB_KEEP.clear()
     pending.append((done, keep))
     while len(pending) > SIDE_DEPTH:
         main.wait_event(pending.popleft()[0])
@@ -537,9 +543,66 @@ def conv3x3_wgrad_raw(x, dy, out=None, xmax=None, dymax=None):
     return dw
 
 
+# ---- slab reductions folded into the next weight-gradient launch (round 6; mulan_conv3x3_wgrad_f16x3_planes_fold)
+# Inside the backward pass of a train step (a weight_gradient_stream() scope) a 3x3 weight gradient writes its slabs and
+# leaves the record (workspace, dw, S, E) here; the next one sums them in the prologue of its blocks, and whatever is
+# still pending when a gradient bucket is complete (parallel.GradReducer) or the pass ends is summed by
+# mulan_slab_reduce.  Same summation order, same bits as the reduction launch behind every weight gradient that this
+# replaces (146 launches of a train step).  Built for VERDICT r05 item 8 (<= 1000 launches per step) and MEASURED: the
+# replayed step at B = 128 takes 75.15 / 75.17 ms with the fold against 74.87 / 75.07 ms without (alternating runs, one
+# box, profiles/r06_fold_slab_reduce_ab.log) -- the 8.8 us reduction launches were never the cost, their bytes are, and
+# the prologue of a 120-block launch sums them no faster than 576 small blocks do.  OPT-IN (MULAN_FOLD_SLAB_REDUCE=1):
+# the default keeps the reduction launch behind every weight gradient; bit-identical either way
+# (tests/test_gpu_f16x3.py::test_f16x3_slab_reductions_folded_into_the_next_weight_gradient, tools/fold_check.py).
+FOLD_SLAB_REDUCE = _os.environ.get("MULAN_FOLD_SLAB_REDUCE", "0") == "1"
+_SLAB_PENDING = []        # [(workspace, dw, S, E)]
+_SLAB_KEEP = []           # tensors the launch just issued reads beyond its own arguments (_on_side keeps them alive)
+
+
+def _pending_array(recs):
+    arr = (lib.SlabReduction * max(1, len(recs)))()
+    for i, (ws, dw, S, E) in enumerate(recs):
+        arr[i].slab, arr[i].out, arr[i].S, arr[i].E, arr[i].accumulate = ws.data_ptr(), dw.data_ptr(), S, E, 0
+    return arr
+
+
+def flush_slab_reductions():
+    """sum every pending slab set now (before anything reads those weight gradients: the all-reduce of their bucket, the
+    optimizer).  Issued where the weight gradients run: on the side stream while it is active."""
+    if not _SLAB_PENDING:
+        return
+    recs = list(_SLAB_PENDING)
+    _SLAB_PENDING.clear()
+
+    def launch():
+        for ws, dw, S, E in recs:
+            call("mulan_slab_reduce", ptr(ws), ptr(dw), S, E, 0, stream())
+    if _SIDE["active"] and recs[0][0].is_cuda:
+        _on_side(launch, tuple(t for r in recs for t in r[:2]))
+    else:
+        launch()
+
+
 def conv3x3_wgrad_planes_raw(xs, xmax, dys, dymax, B, C, N, out=None):
     """dw from the split planes of x (written by the forward conv) and of dy (written by the input-gradient conv)"""
     share = _share_chip()
+    if FOLD_SLAB_REDUCE and _SIDE["scope"] and out is not None:
+        L = lib.load()
+        S = L.mulan_conv3x3_wgrad_f16x3_planes_splits(B, H, W, C, N, share)
+        E = 9 * C * N
+        ws = torch.empty(S * E, device=xs.device, dtype=torch.float32)
+        take = _SLAB_PENDING[:2]
+        del _SLAB_PENDING[:2]
+        arr = _pending_array(take)
+        _timed("conv3x3_wgrad_f16x3_planes_kernel+slab_reduce", 2.0 * B * HW * 9 * C * N,
+               lambda: call("mulan_conv3x3_wgrad_f16x3_planes_fold", ptr(xs), ptr(xmax), ptr(dys), ptr(dymax), ptr(ws), B, H,
+                            W, C, N, share, ctypes.addressof(arr) if take else None, len(take), stream()))
+        _SLAB_KEEP.extend(t for r in take for t in r[:2])
+        # (the record holds ANOTHER tensor object over dw's storage: a second reference to `out` itself would keep
+        # autograd's AccumulateGrad from adopting it -- it would clone the not yet written gradient instead, and
+        # TrainState.collect_grads would copy that clone over the real one)
+        _SLAB_PENDING.append((ws, _fresh(out), S, E))
+        return out
     nbytes = lib.load().mulan_conv3x3_wgrad_f16x3_planes_workspace(B, H, W, C, N, share)
     ws = torch.empty(nbytes // 4, device=xs.device, dtype=torch.float32)
     dw = out if out is not None else torch.empty((3, 3, C, N), device=xs.device, dtype=torch.float32)

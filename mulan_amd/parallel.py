@@ -118,6 +118,9 @@ class GradReducer:
         view = self.flat[lo:hi]
         self.launched[bi] = True
         self.ready_order.append(bi)
+        if self.flat.is_cuda:
+            from . import ops
+            ops.flush_slab_reductions()      # weight gradients of this bucket whose slabs are written but not summed yet
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
             from . import ops
@@ -198,6 +201,7 @@ class GradReducer:
     def _mark(self, bi):
         from . import lib, ops
         L = lib.load()
+        ops.flush_slab_reductions()          # (as in _launch: the bucket must be complete where its signal is planted)
         ev = self.capture["events"][bi]
         # the collective stream joins the capture here only to carry the node's dependencies: the capturing stream's
         # position and the weight-gradient stream's (the bucket's last weight gradient may still be queued there)

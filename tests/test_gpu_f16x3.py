@@ -169,6 +169,58 @@ def test_f16x3_zero_operands(ops):
     assert torch.count_nonzero(z) == 0
 
 
+@pytest.mark.parametrize("side", [False, True])
+def test_f16x3_slab_reductions_folded_into_the_next_weight_gradient(ops, side, monkeypatch):
+    """mulan_conv3x3_wgrad_f16x3_planes_fold (round 6): inside a weight_gradient_stream() scope -- the backward pass of a
+    train step -- a 3x3 weight gradient writes its slabs and leaves them to the NEXT one, whose blocks sum them in their
+    prologue (up to two sets per launch); what is pending at the end of the scope goes to mulan_slab_reduce.  A chain of
+    four weight gradients of three shapes (and one extra flush in the middle, as a completed gradient bucket forces it)
+    gives the very bits of the four stand-alone launches with their own reduction kernels -- same slabs, same summation
+    order -- with the weight-gradient stream on and off; on integer data both are exact."""
+    import mulan_amd.ops as O
+    rng = np.random.default_rng(5)
+    B = 3
+    cases = []
+    for C, N in ((128, 128), (256, 128), (128, 128), (128, 256)):
+        x = rng.integers(-3, 4, (B, 32, 32, C)).astype(np.float64)
+        dy = rng.integers(-2, 3, (B, 32, 32, N)).astype(np.float64)
+        w = rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64)
+        xd, dyd, wd = dev(x).view(B, 1024, C), dev(dy).view(B, 1024, N), dev(w)
+        xmax, dymax = ops.absmax_rows(xd), ops.absmax_rows(dyd)
+        _, xs = ops.conv3x3_raw(xd, wd, xmax=xmax, planes=True)
+        _, dys = ops.conv3x3_dgrad_raw(dyd, wd, dymax=dymax, planes=True)
+        xt, wt = torch.tensor(x), torch.tensor(w, requires_grad=True)
+        tr.conv3x3(xt, {"kernel": wt}).backward(torch.tensor(dy))
+        cases.append((xs, xmax, dys, dymax, C, N, wt.grad.numpy()))
+    monkeypatch.setattr(O, "SIDE_STREAM", side)
+    monkeypatch.setattr(O, "FOLD_SLAB_REDUCE", True)      # (opt-in: measured +-0 on the train step, ops.FOLD_SLAB_REDUCE)
+    monkeypatch.setattr(O, "SIDE_WGRAD_SHARE", False)     # the same split count inside and outside the scope
+    alone = [ops.conv3x3_wgrad_planes_raw(xs, xm, dys, dm, B, C, N, out=torch.empty(3, 3, C, N, device="cuda"))
+             for xs, xm, dys, dm, C, N, _ in cases]
+    outs = [torch.full((3, 3, C, N), float("nan"), device="cuda") for _, _, _, _, C, N, _ in cases]
+    names = []
+    orig = O.call
+    monkeypatch.setattr(O, "call", lambda name, *a: (names.append(name), orig(name, *a))[1])
+    with O.weight_gradient_stream():
+        for i, ((xs, xm, dys, dm, C, N, _), o) in enumerate(zip(cases, outs)):
+            launch = lambda xs=xs, xm=xm, dys=dys, dm=dm, C=C, N=N, o=o: ops.conv3x3_wgrad_planes_raw(xs, xm, dys, dm, B, C, N, out=o)
+            if side:
+                O._on_side(launch, (xs, xm, dys, dm))
+            else:
+                launch()
+            if i == 1:
+                O.flush_slab_reductions()           # (a completed gradient bucket: parallel.GradReducer._launch)
+                assert not O._SLAB_PENDING
+        assert len(O._SLAB_PENDING) == 1            # the third set went into the fourth launch; the fourth is pending
+    torch.cuda.synchronize()
+    assert not O._SLAB_PENDING and not O._SLAB_KEEP
+    assert names.count("mulan_conv3x3_wgrad_f16x3_planes_fold") == 4 and names.count("mulan_slab_reduce") == 2
+    assert "mulan_conv3x3_wgrad_f16x3_planes" not in names
+    for (_, _, _, _, C, N, ref), a, o in zip(cases, alone, outs):
+        assert torch.equal(a, o)
+        assert np.array_equal(o.cpu().double().numpy(), ref)
+
+
 @pytest.mark.parametrize("B,C,N,ints", [(2, 128, 128, True), (3, 256, 128, True), (1, 128, 256, True),
                                          (4, 128, 128, False)])
 def test_f16x3_plane_fed_wgrad(ops, B, C, N, ints):

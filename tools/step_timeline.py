@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """dev: one replayed train step out of a shortened kernel trace (name, queue, start, end in ns; written by the recipe in
 profiles/README.md): time per queue, time with >= 1 / >= 2 kernels running, gaps, and the head / tail of the two
-backward streams.   python tools/step_timeline.py gpurun_out/kt_tail.csv"""
+backward streams.   python tools/step_timeline.py gpurun_out/kt_tail.csv [--back N] [--list ms0 ms1]
+(bench.py ends with two eager steps of conv_roofline -- as run with event timers, then serial: --back 3 is a replayed step)"""
 import collections
 import csv
 import sys
@@ -10,7 +11,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["start"], r["end"] = int(r["start"]), int(r["end"])
 ad = [i for i, r in enumerate(rows) if "adamw" in r["name"]]
-a, b = ad[-2], ad[-1]
+back = int(sys.argv[sys.argv.index("--back") + 1]) if "--back" in sys.argv else 0   # 0: the last step of the trace
+a, b = ad[-2 - back], ad[-1 - back]
 step = rows[a + 1:b + 1]
 T0, T1 = step[0]["start"], step[-1]["end"]
 print(f"step span {(T1 - T0) / 1e6:.2f} ms, {len(step)} kernels")
