@@ -19,8 +19,9 @@ B = 128
 # (kernel substring, label, launches, algorithmic bytes per launch, MFMA 32x32x16 instructions per launch)
 PX = B * 1024
 GROUPS = [
-    ("conv3x3_wgrad_f16x3_planes_kernel<3,", "wgrad_128_128", 6, PX * 128 * 4 * 2, 3.0 * PX * 9 * 128 * 128 / (32 * 32 * 16)),
-    ("conv3x3_wgrad_f16x3_planes_kernel<3,", "wgrad_256_128", 5, PX * (256 + 128) * 4, 3.0 * PX * 9 * 256 * 128 / (32 * 32 * 16)),
+    # (round 6: the 3x3 weight gradient runs on conv3x3_wgrad_f16x3_w16_kernel -- eight waves, 16x16x32 MFMAs)
+    ("conv3x3_wgrad_f16x3_w16_kernel", "wgrad_128_128", 6, PX * 128 * 4 * 2, 3.0 * PX * 9 * 128 * 128 / (16 * 16 * 32)),
+    ("conv3x3_wgrad_f16x3_w16_kernel", "wgrad_256_128", 5, PX * (256 + 128) * 4, 3.0 * PX * 9 * 256 * 128 / (16 * 16 * 32)),
     ("gn_fwd_kernel", "groupnorm_fwd_128_dropout", 6, PX * 128 * 4 * 2, 0),
     ("gn_fwd_kernel", "groupnorm_fwd_256_concat", 5, PX * 256 * 4 * 2, 0),
     ("gn_bwd_kernel_1pass", "groupnorm_bwd_128_dropout", 6, PX * 128 * 4 * 3, 0),
