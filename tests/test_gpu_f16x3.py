@@ -222,7 +222,11 @@ def test_f16x3_slab_reductions_folded_into_the_next_weight_gradient(ops, side, m
 
 
 @pytest.mark.parametrize("B,C,N,ints", [(2, 128, 128, True), (3, 256, 128, True), (1, 128, 256, True),
-                                         (4, 128, 128, False)])
+                                         (4, 128, 128, False),
+                                         # round 6 (eight-wave block, one-dimensional grid): split counts that are not a
+                                         # multiple of 8 -- S = 85 at one tile (the remainder group of w8_decode), 42 at
+                                         # two, 21 at four -- with ragged pixel ranges that cross image boundaries
+                                         (6, 128, 128, True), (11, 256, 128, True), (7, 256, 256, True), (9, 128, 128, False)])
 def test_f16x3_plane_fed_wgrad(ops, B, C, N, ints):
     """weight gradient from the split planes that the forward / input-gradient convolutions write as a by-product:
     bit exact on integers; on random data with very different per-image magnitudes (exercises the per-image ->
@@ -233,7 +237,7 @@ def test_f16x3_plane_fed_wgrad(ops, B, C, N, ints):
         dy = rng.integers(-2, 3, (B, 32, 32, N)).astype(np.float64)
         x[0] *= 4.0                      # different power-of-two scales per image
     else:
-        mags = np.array([1.0, 3e-3, 40.0, 1e-6])[:B, None, None, None]
+        mags = np.resize(np.array([1.0, 3e-3, 40.0, 1e-6]), B)[:, None, None, None]
         x = rng.standard_normal((B, 32, 32, C)) * mags
         dy = rng.standard_normal((B, 32, 32, N)) * mags[::-1]
     w = rng.integers(-2, 3, (3, 3, C, N)).astype(np.float64)
