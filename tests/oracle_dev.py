@@ -7,11 +7,12 @@ pass takes 40 s on the host cores and under a second on the MI355X's fp64 units)
 OWN CODE, unchanged, with its tensors on the device.  This is still the checker -- torch's generic float64 kernels
 (rocBLAS dgemm, the native convolution), nothing of mulan_amd -- and MULAN_ORACLE_DEVICE=cpu puts it back on the host.
 
-Independence from the device's libraries does not rest on that one agreement test alone: the two full-depth comparisons of
-the suite (tests/test_gpu_model.py::test_full_depth_forward_bpd_parity and ::test_full_depth_train_mode_gradient_parity: the
-shipped 32 + 2 + 33 + 4-block depth, forward and training-mode backward) are PINNED TO THE HOST (`pin_oracle_to_host`), so
-every run of the suite holds the HIP path against float64 arithmetic that never touched the GPU, at the depth where an
-error of the checker would matter most (~45 s of the suite's budget).
+Independence from the device's libraries does not rest on that one agreement test alone: two whole-model comparisons of the
+suite are PINNED TO THE HOST (`pin_oracle_to_host`) -- tests/test_gpu_model.py::test_full_depth_forward_bpd_parity (the
+shipped 32 + 2 + 33 + 4-block depth, forward, the +-0.005 bits/dim bar) and ::test_deeper_stack_train_gradients (19 + 4
+ResnetBlocks in training mode: losses and every parameter gradient through float64 autograd) -- so every run of the suite
+holds the HIP path, forward and backward, against float64 arithmetic that never touched the GPU (35 + 10 s of the suite's
+budget; the full-depth BACKWARD pass in float64 takes 40-100 s on the host cores and stays on the device).
 """
 import os
 
