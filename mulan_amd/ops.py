@@ -77,6 +77,8 @@ class weight_gradient_stream:
     def __enter__(self):
         _SIDE["active"] = SIDE_STREAM
         _SIDE["scope"] = True
+        _SLAB_PENDING.clear()            # (records of a backward pass that an exception cut short must not reach this one)
+        _SLAB_KEEP.clear()
         return self
 
     def __exit__(self, *exc):
