@@ -76,6 +76,9 @@ def parse():
 TEST_DEPTH = 0
 
 
+ALSO_WARMUP = 8          # untimed steps in front of the timed ones of every extra training configuration
+
+
 def _test_depth(config):
     """(tests only, --small-depth N) N ResnetBlocks per U-Net stage instead of the configuration's 32 / 4: the control flow
     of a multi-rank run in seconds.  Never set by the driver; the JSON line says so (`test_depth`) when it is."""
@@ -850,13 +853,16 @@ def main():
             table["3_at_64_per_gpu"] = (cif, "mulan_velocity", False, 64, "BASELINE configs[2] at its 8-GPU per-GPU size: "
                                         "MuLAN-velocity CIFAR-10, 64 images per GPU (512 / 8)")
         for key, (cfgp, vt, vfe, bsz, label) in table.items():
-            r = train_workload(a, rank, world, cfgp, vt, vfe, bsz, a.also_steps, 3, False)
+            # (8 untimed replays: after the set-up of a new workload the chip has idled for seconds and its clock ramps over
+            # the first steps -- with 3 the `chip` record of config #4 showed 1.3-1.5 GHz in the first timed step and the entry
+            # read 522-536 images/s instead of 550-568, profiles/r06_box_spread.log)
+            r = train_workload(a, rank, world, cfgp, vt, vfe, bsz, a.also_steps, ALSO_WARMUP, False)
             ips = bsz * world * a.also_steps / r["elapsed"]
             gf = FWD_GFLOP_BY_WIDTH[r["E"]]
             rr = r["roof"] or {}
             extra[key] = {"workload": label + f"; full train step, {world} GPU(s) x {bsz}", "value": round(ips, 2),
                           "unit": "images/s", "global_batch": bsz * world, "ms_per_step": round(r["elapsed"] / a.also_steps * 1e3, 2),
-                          "steps": a.also_steps, "warmup": 3, "hip_graph": r["graph_used"],
+                          "steps": a.also_steps, "warmup": ALSO_WARMUP, "hip_graph": r["graph_used"],
                           "model_tflops_per_gpu": round(ips / world * 3 * gf / 1e3, 2),
                           "conv_kernel": {k: rr.get(k) for k in ("kernel", "achieved", "peak", "frac", "avg_launch_us",
                                                                  "launches_per_step", "measured")},
